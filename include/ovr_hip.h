@@ -1,0 +1,165 @@
+/* ovr_hip.h - C ABI of the MI355X (gfx950) ray-marching backend for OVR's renderer API.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  Every entry point
+ * replaces one member of the reference's device interface; `file:line` citations are relative to the
+ * reference tree (VIDILabs/open-volume-renderer).  The reference-side binding (a ~150-line
+ * `DeviceHIP : ovr::MainRenderer` compiled against the reference's own headers and exported as
+ * `ovr_create_renderer__hip`, the symbol ovr/renderer.cpp:55-58 looks up) lives in plugin/device_hip.cpp
+ * and is described in INTEGRATION.md.
+ *
+ * Error model: every function returns 0 on success and a negative OVR_HIP_E* code on failure;
+ * ovr_hip_last_error() returns the message.  The reference reports errors as std::runtime_error
+ * (ovr/common/cuda/cuda_misc.h:44-100); the C++ binding rethrows with the same text.
+ *
+ * Threading: like the reference (SURVEY.md 8b "Threading") setters may be called from any thread,
+ * commit/render/mapframe/swap from one render thread at a time.
+ */
+#ifndef OVR_HIP_H
+#define OVR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OVR_HIP_ABI_VERSION 1
+
+/* error codes */
+#define OVR_HIP_OK 0
+#define OVR_HIP_EINVAL (-1)   /* bad argument (the reference throws std::runtime_error) */
+#define OVR_HIP_EDEVICE (-2)  /* HIP runtime error / no gfx950 device */
+#define OVR_HIP_ESTATE (-3)   /* call order violated (e.g. render before a volume was set) */
+
+/* Scalar types: numeric values of ovr::ValueType, ovr/scene.h:32-53 */
+#define OVR_HIP_TYPE_UINT8 100
+#define OVR_HIP_TYPE_INT8 101
+#define OVR_HIP_TYPE_UINT16 200
+#define OVR_HIP_TYPE_INT16 201
+#define OVR_HIP_TYPE_UINT32 300
+#define OVR_HIP_TYPE_INT32 301
+#define OVR_HIP_TYPE_FLOAT 400
+#define OVR_HIP_TYPE_DOUBLE 500
+
+/* where a buffer lives (mirrors CrossDeviceBuffer::Device, ovr/common/cross_device_buffer.h:22-27) */
+#define OVR_HIP_MEM_HOST 0
+#define OVR_HIP_MEM_DEVICE 1
+
+/* shading modes.  FULL = what the reference's live marcher always does (shaders_raymarching.cu:124-158) */
+#define OVR_HIP_SHADE_NONE 0     /* absorption + emission: value tap + TF only (BASELINE config 2)        */
+#define OVR_HIP_SHADE_GRADIENT 1 /* + forward-difference gradient and |N.L| term, no shadow march (config 3) */
+#define OVR_HIP_SHADE_FULL 2     /* + per-sample shadow march toward the fixed directional light            */
+
+/* grid convention */
+#define OVR_HIP_GRID_CELL_CENTRED 0   /* in-tree OptiX device (default)        */
+#define OVR_HIP_GRID_VERTEX_CENTRED 1 /* OSPRay wrapper's structuredRegular     */
+
+typedef struct ovr_hip_renderer ovr_hip_renderer; /* opaque; one per GPU */
+
+/* counters of the most recent render() (the metric's "sample" = one primary marching-loop iteration) */
+typedef struct ovr_hip_stats {
+  uint64_t rays;            /* primary rays (pixels x spp) launched by this rank                             */
+  uint64_t samples;         /* primary marching-loop iterations                                               */
+  uint64_t shaded_samples;  /* primary samples with corrected opacity > 0 (gradient/shadow taps executed)    */
+  uint64_t shadow_samples;  /* shadow-march iterations executed                                               */
+  uint64_t active_pixels;   /* pixels rendered (sparse sampling / tile sharding reduce it below W*H)         */
+  double kernel_ms;         /* hipEvent time of the ray-march kernel of the last render()                     */
+  double render_ms;         /* wall time of the last render() call, as DeviceOptix7::render measures it       */
+  int32_t frame_index;      /* accumulation frame counter after the last render (device_impl.cpp:241)         */
+  int32_t reserved;
+} ovr_hip_stats;
+
+const char* ovr_hip_last_error(void);
+int ovr_hip_abi_version(void);
+
+/* replaces create_renderer("hip") / new DeviceOptix7 + Impl::init (ovr/renderer.cpp:42-61, device_impl.cpp:70-100).
+ * device_id = HIP device ordinal; the reference hard-codes 0 (device_impl.cpp:371-372). */
+int ovr_hip_create(ovr_hip_renderer** out, int device_id);
+void ovr_hip_destroy(ovr_hip_renderer* r);
+
+/* Use a caller-owned hipStream_t for all device work (e.g. torch's current stream); NULL = private streams,
+ * one per framebuffer set like DoubleBufferObject (optix7_common.h:328-414). */
+int ovr_hip_set_stream(ovr_hip_renderer* r, void* hip_stream);
+
+/* replaces Impl::buildScene + StructuredRegularVolume::load_from_array3d_scalar + CreateArray3DScalarOptix7
+ * (device_impl.cpp:283-302, volume.cpp:181-257, array.cpp:287-351).  `data` = dims[0]*dims[1]*dims[2] scalars,
+ * x fastest.  The volume is re-laid out into HBM-resident bricks; `data` is not referenced after the call returns. */
+int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int value_type, const int32_t dims[3],
+                       const float grid_origin[3], const float grid_spacing[3]);
+int ovr_hip_set_grid_convention(ovr_hip_renderer* r, int convention);
+
+/* replaces MainRenderer::set_transfer_function -> StructuredRegularVolume::set_transfer_function
+ * (ovr/renderer.h:154-161, volume.cpp:110-129): colors = n_colors flat RGB triples, alphas = n_alphas flat
+ * (position, alpha) pairs (position ignored, as in the reference), range in raw data units. */
+int ovr_hip_set_transfer_function(ovr_hip_renderer* r, const float* colors_rgb, int32_t n_colors,
+                                  const float* alphas_pos_alpha, int32_t n_alphas, float range_lo, float range_hi);
+
+/* replaces MainRenderer::set_camera (ovr/renderer.h:140-152); fovy in degrees (scene.h:219 default 60) */
+int ovr_hip_set_camera(ovr_hip_renderer* r, const float from[3], const float at[3], const float up[3], float fovy);
+/* ovr/renderer.h:135-138 */
+int ovr_hip_set_fbsize(ovr_hip_renderer* r, int32_t width, int32_t height);
+/* ovr/renderer.h:170-173 */
+int ovr_hip_set_sample_per_pixel(ovr_hip_renderer* r, int32_t spp);
+/* ovr/renderer.h:200-203 -> StructuredRegularVolume::set_sampling_rate (volume.cpp:156-162) */
+int ovr_hip_set_volume_sampling_rate(ovr_hip_renderer* r, float rate);
+/* ovr/renderer.h:195-198 */
+int ovr_hip_set_frame_accumulation(ovr_hip_renderer* r, int32_t enabled);
+/* ovr/renderer.h:180-183 */
+int ovr_hip_set_sparse_sampling(ovr_hip_renderer* r, int32_t enabled);
+/* ovr/renderer.h:163-168 */
+int ovr_hip_set_focus(ovr_hip_renderer* r, float center_x, float center_y, float scale, float base_noise);
+/* blue-noise / STBN tile used by the sparse-sampling mask: xy*xy*64 floats, layout [y][x][t]
+ * (ovr/common/random/blue_noise.h:44-47,95-99).  The reference embeds the tile at build time (ovr/CMakeLists.txt:67-72). */
+int ovr_hip_set_noise_tile(ovr_hip_renderer* r, const float* tile, int32_t xy);
+/* extension: select the sub-mode BASELINE.json's configs name; default OVR_HIP_SHADE_FULL (= reference) */
+int ovr_hip_set_shading(ovr_hip_renderer* r, int32_t mode);
+/* extension (multi-GPU): this renderer draws only the image tiles owned by `rank` of `world`;
+ * owner(tile_x, tile_y) = (tile_x + tile_y) % world.  world = 1 restores the single-GPU behaviour. */
+int ovr_hip_set_image_shard(ovr_hip_renderer* r, int32_t rank, int32_t world, int32_t tile_w, int32_t tile_h);
+
+/* replaces DeviceOptix7::Impl::commit (device_impl.cpp:113-197): applies every queued setter; any change resets
+ * the accumulation (frame_index restarts at 1 on the next render). */
+int ovr_hip_commit(ovr_hip_renderer* r);
+
+/* replaces DeviceOptix7::render (optix7/device.cpp:35-43, device_impl.cpp:199-269): one frame, blocking until the
+ * frame is complete on the device; adds the elapsed milliseconds to the value ovr_hip_render_time_ms() returns. */
+int ovr_hip_render(ovr_hip_renderer* r);
+/* non-blocking variant: enqueues the frame on the renderer's stream and returns (for hipEvent timing / graphs) */
+int ovr_hip_render_async(ovr_hip_renderer* r);
+/* waits for everything enqueued by render_async */
+int ovr_hip_sync(ovr_hip_renderer* r);
+
+/* replaces Impl::mapframe (device_impl.cpp:271-281): publishes the CURRENT framebuffer set.
+ * mem_kind DEVICE: device pointers (as the reference hands out, CrossDeviceBuffer::DEVICE_CUDA);
+ * mem_kind HOST: the frame is copied to pinned host memory owned by the renderer (what the caller's
+ * CrossDeviceBuffer::to_cpu() would do, cross_device_buffer.h:130-159) and stays valid until the next mapframe
+ * of the same set.  rgba = W*H*4 floats, row 0 = bottom; grad = W*H*3 floats (may be NULL to skip). */
+int ovr_hip_mapframe(ovr_hip_renderer* r, int mem_kind, const float** rgba, size_t* rgba_bytes, const float** grad,
+                     size_t* grad_bytes);
+/* replaces Impl::swap (device_impl.cpp:102-111): waits for the current set's stream, flips to the other set */
+int ovr_hip_swap(ovr_hip_renderer* r);
+
+/* MainRenderer::render_time (ovr/renderer.h:87): accumulated milliseconds spent in ovr_hip_render */
+double ovr_hip_render_time_ms(const ovr_hip_renderer* r);
+int ovr_hip_get_stats(const ovr_hip_renderer* r, ovr_hip_stats* out);
+
+/* multi-GPU helpers.  pack: copies this rank's tiles out of its W*H framebuffer into a compact
+ * [n_owned_tiles][tile_h][tile_w][4] device buffer (the RCCL gather payload); unpack: scatters the gathered payload
+ * of `src_rank` into a W*H*4 frame on the gathering rank.  Both run on the renderer's stream. */
+int ovr_hip_owned_tiles(const ovr_hip_renderer* r, int32_t rank, int32_t* n_tiles);
+int ovr_hip_pack_tiles(ovr_hip_renderer* r, float* dst_device, size_t dst_bytes);
+int ovr_hip_unpack_tiles(ovr_hip_renderer* r, int32_t src_rank, const float* src_device, size_t src_bytes,
+                         float* frame_device, size_t frame_bytes);
+
+/* stand-alone pieces of the path, exposed for known-answer tests through the same ABI (device buffers) */
+/* ovr/common/generate_mask.cu:100-120: compacted (x,y) list for this frame; returns the int32 count in *n_out */
+int ovr_hip_sparse_mask(ovr_hip_renderer* r, int32_t frame_index, int32_t* out_xy_device, size_t out_bytes,
+                        int64_t* n_out);
+/* ovr/common/random/random.h:146-188: n (v0,v1) states -> 2n floats, states advanced in place */
+int ovr_hip_tea_floats(ovr_hip_renderer* r, uint32_t* v0v1_device, float* out_device, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVR_HIP_H */

@@ -1,0 +1,832 @@
+// ovr_hip_api.cpp - C ABI (include/ovr_hip.h) of the MI355X ray-marching backend: host-side state machine.
+//
+// Mirrors the host half of the reference's GPU device (citations relative to the reference tree):
+//   queued setters + commit diffing ... ovr/renderer.h:135-285, ovr/devices/optix7/device_impl.cpp:113-197
+//   render / frame_index / reset ...... device_impl.cpp:199-269
+//   double-buffered framebuffer ....... ovr/devices/optix7/optix7_common.h:328-414, device_impl.cpp:102-111,271-281
+//   volume + TF upload ................ volume.cpp:110-179, array.cpp:287-351
+// No CPU fallback exists: every entry point needs a HIP device and fails with OVR_HIP_EDEVICE otherwise.
+#include "../../include/ovr_hip.h"
+#include "ovr_hip_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <chrono>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace ovrhip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg)
+{
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                                  \
+  do {                                                                                                                 \
+    hipError_t e__ = (expr);                                                                                           \
+    if (e__ != hipSuccess)                                                                                             \
+      return fail(OVR_HIP_EDEVICE, std::string("[hip] ") + #expr + " failed: " + hipGetErrorString(e__));            \
+  } while (0)
+
+struct V3 { float x, y, z; };
+inline V3 sub(V3 a, V3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+inline float dot(V3 a, V3 b) { return std::fmaf(a.x, b.x, std::fmaf(a.y, b.y, a.z * b.z)); }
+inline V3 cross(V3 a, V3 b) { return { a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y }; }
+inline V3 normalize(V3 v) { const float l = std::sqrt(dot(v, v)); return { (v.x * 1.f) / l, (v.y * 1.f) / l, (v.z * 1.f) / l }; }
+inline V3 scale(float s, V3 a) { return { s * a.x, s * a.y, s * a.z }; }
+
+// array.h:68-106
+float integer_normalize(float value, int type)
+{
+  switch (type) {
+  case OVR_HIP_TYPE_UINT8: return (float)(uint8_t)value / 255.f;
+  case OVR_HIP_TYPE_INT8: { const float n = (float)(int8_t)value / 127.f; return n < -1.f ? -1.f : n; }
+  case OVR_HIP_TYPE_UINT16: return (float)(uint16_t)value / 65535.f;
+  case OVR_HIP_TYPE_INT16: { const float n = (float)(int16_t)value / 32767.f; return n < -1.f ? -1.f : n; }
+  case OVR_HIP_TYPE_UINT32: return (float)(uint32_t)value / (float)UINT32_MAX;
+  case OVR_HIP_TYPE_INT32: { const float n = (float)(int32_t)value / (float)INT32_MAX; return n < -1.f ? -1.f : n; }
+  default: return value;
+  }
+}
+// the ValueType the reference's device volume ends up with (array.cpp:322-347): u16 / i16 / f64 are sampled as RAW float
+int device_value_type(int t)
+{
+  if (t == OVR_HIP_TYPE_UINT16 || t == OVR_HIP_TYPE_INT16 || t == OVR_HIP_TYPE_DOUBLE) return OVR_HIP_TYPE_FLOAT;
+  return t;
+}
+size_t value_type_size(int t)
+{
+  switch (t) {
+  case OVR_HIP_TYPE_UINT8: case OVR_HIP_TYPE_INT8: return 1;
+  case OVR_HIP_TYPE_UINT16: case OVR_HIP_TYPE_INT16: return 2;
+  case OVR_HIP_TYPE_UINT32: case OVR_HIP_TYPE_INT32: case OVR_HIP_TYPE_FLOAT: return 4;
+  case OVR_HIP_TYPE_DOUBLE: return 8;
+  default: return 0;
+  }
+}
+
+template <typename T> struct Queued { // vidi::TransactionalValue (ovr/common/vidi_transactional_value.h:26-168), minus the template
+  T queued{}, current{};
+  bool dirty = false;
+  void set(const T& v) { queued = v; dirty = true; }
+  bool update() { if (!dirty) return false; current = queued; dirty = false; return true; }
+};
+
+struct CameraP { float from[3] = { 0, 0, 0 }, at[3] = { 0, 0, -1 }, up[3] = { 0, 1, 0 }; float fovy = 60.f; };
+struct FocusP { float cx = 0.5f, cy = 0.5f, scale = 0.2f, base_noise = 0.1f; }; // params.h:82-84
+struct TfnP { std::vector<float> colors, alphas; float lo = 1, hi = -1; };
+struct ShardP { int rank = 0, world = 1, tw = 64, th = 64; };
+struct Size2 { int w = 0, h = 0; };
+
+} // namespace
+
+struct ovr_hip_renderer {
+  int device = 0;
+  std::mutex mtx; // protects the queued values (setters may come from any thread)
+  hipStream_t own_stream[2] = { nullptr, nullptr };
+  hipStream_t user_stream = nullptr;
+  bool use_user_stream = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  Queued<Size2> fbsize;
+  Queued<CameraP> camera;
+  Queued<TfnP> tfn;
+  Queued<FocusP> focus;
+  Queued<int> spp, sparse, accumulate, shading, grid_convention;
+  Queued<float> rate;
+  Queued<ShardP> shard;
+
+  // volume
+  void* d_volume = nullptr;
+  size_t volume_bytes = 0;
+  VolumeDesc vd{};
+  int value_type = 0;
+  float origin[3] = { 0, 0, 0 }, spacing[3] = { 1, 1, 1 };
+  bool have_volume = false;
+
+  // transfer function
+  float* d_tf_color = nullptr;
+  float* d_tf_alpha = nullptr;
+  int n_color = 0, n_alpha = 0;
+  bool have_tfn = false;
+
+  // framebuffer sets
+  float* d_rgba[2] = { nullptr, nullptr };
+  float* d_grad[2] = { nullptr, nullptr };
+  float* h_rgba[2] = { nullptr, nullptr };
+  float* h_grad[2] = { nullptr, nullptr };
+  float* d_accum = nullptr;
+  size_t fb_pixels = 0;
+  int cur = 0;
+  bool fb_reset = true;
+  int frame_index = 0;
+  bool camera_dirty = true;
+
+  // sparse sampling
+  float* d_noise = nullptr;
+  int noise_xy = 0;
+  int32_t* d_sparse_xy = nullptr;
+  unsigned int* d_block_counts = nullptr;
+  unsigned long long* d_sparse_count = nullptr;
+  size_t sparse_pixels = 0;
+
+  // counters
+  unsigned long long* d_counters = nullptr;
+  unsigned long long* h_counters = nullptr; // pinned
+
+  RayMarchParams P{};
+  ovr_hip_stats stats{};
+  double render_time_ms = 0.0;
+  bool async_pending = false;
+
+  hipStream_t stream() const { return use_user_stream ? user_stream : own_stream[cur]; }
+};
+
+namespace {
+
+int set_device(ovr_hip_renderer* r) { HIP_TRY(hipSetDevice(r->device)); return 0; }
+
+int free_framebuffers(ovr_hip_renderer* r)
+{
+  for (int i = 0; i < 2; ++i) {
+    if (r->d_rgba[i]) HIP_TRY(hipFree(r->d_rgba[i]));
+    if (r->d_grad[i]) HIP_TRY(hipFree(r->d_grad[i]));
+    if (r->h_rgba[i]) HIP_TRY(hipHostFree(r->h_rgba[i]));
+    if (r->h_grad[i]) HIP_TRY(hipHostFree(r->h_grad[i]));
+    r->d_rgba[i] = r->d_grad[i] = r->h_rgba[i] = r->h_grad[i] = nullptr;
+  }
+  if (r->d_accum) HIP_TRY(hipFree(r->d_accum));
+  r->d_accum = nullptr;
+  if (r->d_sparse_xy) HIP_TRY(hipFree(r->d_sparse_xy));
+  if (r->d_block_counts) HIP_TRY(hipFree(r->d_block_counts));
+  r->d_sparse_xy = nullptr;
+  r->d_block_counts = nullptr;
+  r->sparse_pixels = 0;
+  r->fb_pixels = 0;
+  return 0;
+}
+
+int resize_framebuffers(ovr_hip_renderer* r, int w, int h)
+{
+  HIP_TRY(hipDeviceSynchronize()); // device_impl.cpp:117 stops all async rendering first
+  if (int e = free_framebuffers(r)) return e;
+  const size_t n = (size_t)w * (size_t)h;
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(hipMalloc((void**)&r->d_rgba[i], n * 4 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&r->d_grad[i], n * 3 * sizeof(float)));
+    HIP_TRY(hipMemset(r->d_rgba[i], 0, n * 4 * sizeof(float)));
+    HIP_TRY(hipMemset(r->d_grad[i], 0, n * 3 * sizeof(float)));
+  }
+  HIP_TRY(hipMalloc((void**)&r->d_accum, n * 4 * sizeof(float)));
+  HIP_TRY(hipMemset(r->d_accum, 0, n * 4 * sizeof(float)));
+  r->fb_pixels = n;
+  return 0;
+}
+
+// device_impl.cpp:125-144
+void update_camera(ovr_hip_renderer* r)
+{
+  const CameraP& c = r->camera.current;
+  const int W = r->fbsize.current.w, H = r->fbsize.current.h;
+  const float t = 2.f * std::tan(c.fovy * 0.5f * (float)M_PI / 180.f);
+  const float aspect = (float)W / (float)H;
+  const V3 from = { c.from[0], c.from[1], c.from[2] }, at = { c.at[0], c.at[1], c.at[2] }, up = { c.up[0], c.up[1], c.up[2] };
+  const V3 dir = normalize(sub(at, from));
+  const V3 hor = scale(t * aspect, normalize(cross(dir, up)));
+  const V3 cr = cross(hor, dir);
+  const V3 ver = { cr.x / aspect, cr.y / aspect, cr.z / aspect };
+  RayMarchParams& P = r->P;
+  P.cam_pos = { from.x, from.y, from.z };
+  P.cam_dir = { dir.x, dir.y, dir.z };
+  P.cam_hor = { hor.x, hor.y, hor.z };
+  P.cam_ver = { ver.x, ver.y, ver.z };
+  // inverse-transpose of get_xfm_world_to_camera().l (shaders_common.h:276-289; LinearSpace.h:215-224,321)
+  const V3 x = normalize(hor), y = normalize(ver), zz = normalize(dir);
+  const V3 z = { -zz.x, -zz.y, -zz.z };
+  const V3 vx = { x.x, y.x, z.x }, vy = { x.y, y.y, z.y }, vz = { x.z, y.z, z.z };
+  const float det = dot(vx, cross(vy, vz));
+  const V3 c0 = cross(vy, vz), c1 = cross(vz, vx), c2 = cross(vx, vy);
+  const float m[9] = { c0.x / det, c0.y / det, c0.z / det, c1.x / det, c1.y / det, c1.z / det, c2.x / det, c2.y / det, c2.z / det };
+  std::memcpy(P.wtc_it, m, sizeof(m));
+}
+
+// volume.cpp:131-145 + device_impl.cpp:288-296 + volume.cpp:172-179
+void update_volume_params(ovr_hip_renderer* r)
+{
+  RayMarchParams& P = r->P;
+  const bool vertex = r->grid_convention.current == OVR_HIP_GRID_VERTEX_CENTRED;
+  const int n[3] = { r->vd.nx, r->vd.ny, r->vd.nz };
+  float inv[3], wp[3], cs[3], cb[3], gs[3];
+  for (int k = 0; k < 3; ++k) {
+    const float ext = vertex ? (float)(n[k] - 1) : (float)n[k];
+    const float sc = r->spacing[k] * ext;
+    inv[k] = 1.f / sc;
+    wp[k] = -(inv[k] * r->origin[k]);
+    cs[k] = vertex ? (float)(n[k] - 1) : (float)n[k];
+    cb[k] = vertex ? 0.f : -0.5f;
+    gs[k] = vertex ? 1.f / (float)(n[k] - 1) : 1.f / (float)n[k];
+  }
+  P.inv_scale = { inv[0], inv[1], inv[2] };
+  P.wto_p = { wp[0], wp[1], wp[2] };
+  P.otw_it = P.inv_scale;
+  P.coord_scale = { cs[0], cs[1], cs[2] };
+  P.coord_bias = { cb[0], cb[1], cb[2] };
+  P.grad_step = { gs[0], gs[1], gs[2] };
+  const V3 L = normalize({ -907.108f, 2205.875f, -400.0267f }); // params.h:79
+  P.light = { L.x, L.y, L.z };
+  P.vol = r->vd;
+  P.vol.data = r->d_volume;
+}
+
+void update_tfn_range(ovr_hip_renderer* r)
+{
+  RayMarchParams& P = r->P;
+  const int dt = device_value_type(r->value_type);
+  const TfnP& t = r->tfn.current;
+  if (t.hi >= t.lo) { // volume.cpp:135
+    P.tf_upper = integer_normalize(t.hi, dt);
+    P.tf_lower = integer_normalize(t.lo, dt);
+  }
+  P.tf_scale = 1.f / (P.tf_upper - P.tf_lower);
+}
+
+int upload_tfn(ovr_hip_renderer* r)
+{
+  const TfnP& t = r->tfn.current;
+  const int nc = (int)(t.colors.size() / 3), na = (int)(t.alphas.size() / 2);
+  if (nc == 0 || na == 0) return 0; // volume.cpp:125: nothing happens for an empty TF
+  std::vector<float> c4((size_t)nc * 4), a((size_t)na);
+  for (int i = 0; i < nc; ++i) { // volume.cpp:112-118
+    c4[4 * i + 0] = t.colors[3 * i + 0];
+    c4[4 * i + 1] = t.colors[3 * i + 1];
+    c4[4 * i + 2] = t.colors[3 * i + 2];
+    c4[4 * i + 3] = 1.f;
+  }
+  for (int i = 0; i < na; ++i) a[i] = t.alphas[2 * i + 1]; // volume.cpp:120-123
+  HIP_TRY(hipDeviceSynchronize());
+  if (r->n_color != nc) {
+    if (r->d_tf_color) HIP_TRY(hipFree(r->d_tf_color));
+    HIP_TRY(hipMalloc((void**)&r->d_tf_color, c4.size() * sizeof(float)));
+    r->n_color = nc;
+  }
+  if (r->n_alpha != na) {
+    if (r->d_tf_alpha) HIP_TRY(hipFree(r->d_tf_alpha));
+    HIP_TRY(hipMalloc((void**)&r->d_tf_alpha, a.size() * sizeof(float)));
+    r->n_alpha = na;
+  }
+  HIP_TRY(hipMemcpy(r->d_tf_color, c4.data(), c4.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(r->d_tf_alpha, a.data(), a.size() * sizeof(float), hipMemcpyHostToDevice));
+  r->have_tfn = true;
+  return 0;
+}
+
+int ensure_sparse_buffers(ovr_hip_renderer* r)
+{
+  const size_t n = r->fb_pixels;
+  if (r->sparse_pixels == n && r->d_sparse_xy) return 0;
+  if (r->d_sparse_xy) HIP_TRY(hipFree(r->d_sparse_xy));
+  if (r->d_block_counts) HIP_TRY(hipFree(r->d_block_counts));
+  HIP_TRY(hipMalloc((void**)&r->d_sparse_xy, n * 2 * sizeof(int32_t)));
+  HIP_TRY(hipMalloc((void**)&r->d_block_counts, sparse_mask_workspace_elems(r->fbsize.current.w, r->fbsize.current.h) * sizeof(unsigned int)));
+  r->sparse_pixels = n;
+  return 0;
+}
+
+SparseMaskParams make_mask_params(ovr_hip_renderer* r, int frame_index, int32_t* out_xy)
+{
+  SparseMaskParams m{};
+  const FocusP& f = r->focus.current;
+  m.noise = r->d_noise;
+  m.noise_xy = r->noise_xy;
+  m.width = r->fbsize.current.w;
+  m.height = r->fbsize.current.h;
+  m.frame_index = frame_index;
+  m.mean_x = f.cx;
+  m.mean_y = f.cy;
+  m.sigma_rcp2 = 1.f / (f.scale * f.scale); // generate_mask.cu:90
+  m.base_noise = f.base_noise;
+  m.out_xy = out_xy;
+  m.block_counts = r->d_block_counts;
+  m.count = r->d_sparse_count;
+  return m;
+}
+
+// Impl::render up to and including the launch (device_impl.cpp:199-262); no host synchronisation
+int enqueue_frame(ovr_hip_renderer* r)
+{
+  if (!r->have_volume) return fail(OVR_HIP_ESTATE, "[hip] render() called before a volume was set");
+  if (!r->have_tfn) return fail(OVR_HIP_ESTATE, "[hip] render() called before a transfer function was set");
+  const int W = r->fbsize.current.w, H = r->fbsize.current.h;
+  if (W <= 0 || H <= 0) return 0; // device_impl.cpp:216-217
+  hipStream_t st = r->stream();
+  RayMarchParams& P = r->P;
+  const bool accumulate = r->accumulate.current != 0;
+  const bool sparse = r->sparse.current != 0;
+  const size_t n = r->fb_pixels;
+  if (accumulate) { // device_impl.cpp:226-233
+    if (r->fb_reset) {
+      for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipMemsetAsync(r->d_rgba[i], 0, n * 4 * sizeof(float), st));
+        HIP_TRY(hipMemsetAsync(r->d_grad[i], 0, n * 3 * sizeof(float), st));
+      }
+      // the reference leaves the accumulation buffer as it is (device_impl.cpp:229-230 are commented out), which is
+      // only sound because frame 1 overwrites it; sparse frames do not overwrite every pixel, so it is cleared here
+      if (sparse) HIP_TRY(hipMemsetAsync(r->d_accum, 0, n * 4 * sizeof(float), st));
+      r->fb_reset = false;
+      r->frame_index = 0;
+    }
+  }
+  else if (sparse) { // device_impl.cpp:234-239
+    for (int i = 0; i < 2; ++i) {
+      HIP_TRY(hipMemsetAsync(r->d_rgba[i], 0, n * 4 * sizeof(float), st));
+      HIP_TRY(hipMemsetAsync(r->d_grad[i], 0, n * 3 * sizeof(float), st));
+    }
+  }
+  r->frame_index++;
+
+  P.rgba = r->d_rgba[r->cur];
+  P.grad = r->d_grad[r->cur];
+  P.accum = r->d_accum;
+  P.width = W;
+  P.height = H;
+  P.frame_index = r->frame_index;
+  P.accumulate = accumulate ? 1 : 0;
+  P.spp = r->spp.current;
+  P.shading = r->shading.current;
+  P.step = 1.f / r->rate.current; // volume.cpp:176
+  P.base = 1.f;                   // volume.h:125
+  P.shadow_stride = (P.step * 10.f) * P.step; // shaders_raymarching.cu:221 then :64
+  P.tf_color = r->d_tf_color;
+  P.tf_alpha = r->d_tf_alpha;
+  P.n_color = r->n_color;
+  P.n_alpha = r->n_alpha;
+  P.rank = r->shard.current.rank;
+  P.world = r->shard.current.world;
+  P.tile_w = r->shard.current.tw;
+  P.tile_h = r->shard.current.th;
+  P.counters = r->d_counters;
+  P.sparse_xy = nullptr;
+  P.sparse_count = nullptr;
+  HIP_TRY(hipMemsetAsync(r->d_counters, 0, 8 * sizeof(unsigned long long), st));
+  if (sparse) { // createSparseSamples, device_impl.cpp:304-342
+    if (!r->d_noise) return fail(OVR_HIP_ESTATE, "[hip] sparse sampling enabled but no noise tile was set (ovr_hip_set_noise_tile)");
+    if (int e = ensure_sparse_buffers(r)) return e;
+    HIP_TRY(launch_sparse_mask(make_mask_params(r, r->frame_index, r->d_sparse_xy), st));
+    P.sparse_xy = r->d_sparse_xy;
+    P.sparse_count = r->d_sparse_count;
+  }
+  HIP_TRY(hipEventRecord(r->ev0, st));
+  HIP_TRY(launch_raymarch(P, st));
+  HIP_TRY(hipEventRecord(r->ev1, st));
+  HIP_TRY(hipMemcpyAsync(r->h_counters, r->d_counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  r->async_pending = true;
+  return 0;
+}
+
+int finish_frame(ovr_hip_renderer* r)
+{
+  if (!r->async_pending) return 0;
+  HIP_TRY(hipStreamSynchronize(r->stream()));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, r->ev0, r->ev1));
+  r->stats.kernel_ms = ms;
+  r->stats.rays = r->h_counters[0];
+  r->stats.samples = r->h_counters[1];
+  r->stats.shaded_samples = r->h_counters[2];
+  r->stats.shadow_samples = r->h_counters[3];
+  r->stats.active_pixels = r->h_counters[4];
+  r->stats.frame_index = r->frame_index;
+  r->async_pending = false;
+  return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* ovr_hip_last_error(void) { return g_last_error.c_str(); }
+int ovr_hip_abi_version(void) { return OVR_HIP_ABI_VERSION; }
+
+int ovr_hip_create(ovr_hip_renderer** out, int device_id)
+{
+  if (!out) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_create: null output pointer");
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(OVR_HIP_EDEVICE, "[hip] no HIP device available - this backend has no CPU fallback");
+  if (device_id < 0 || device_id >= count) return fail(OVR_HIP_EINVAL, "[hip] invalid device ordinal " + std::to_string(device_id));
+  HIP_TRY(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    return fail(OVR_HIP_EDEVICE, std::string("[hip] device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
+  ovr_hip_renderer* r = new ovr_hip_renderer();
+  r->device = device_id;
+  HIP_TRY(hipStreamCreate(&r->own_stream[0]));
+  HIP_TRY(hipStreamCreate(&r->own_stream[1]));
+  HIP_TRY(hipEventCreate(&r->ev0));
+  HIP_TRY(hipEventCreate(&r->ev1));
+  HIP_TRY(hipMalloc((void**)&r->d_counters, 8 * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc((void**)&r->d_sparse_count, sizeof(unsigned long long)));
+  HIP_TRY(hipHostMalloc((void**)&r->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+  std::memset(r->h_counters, 0, 8 * sizeof(unsigned long long));
+  // defaults of the reference's parameter block (params.h:55-99, renderer.h:255-285)
+  r->spp.current = r->spp.queued = 1;
+  r->sparse.current = r->sparse.queued = 0;
+  r->accumulate.current = r->accumulate.queued = 0;
+  r->shading.current = r->shading.queued = OVR_HIP_SHADE_FULL;
+  r->grid_convention.current = r->grid_convention.queued = OVR_HIP_GRID_CELL_CENTRED;
+  r->rate.current = r->rate.queued = 1.f;
+  *out = r;
+  return 0;
+}
+
+void ovr_hip_destroy(ovr_hip_renderer* r)
+{
+  if (!r) return;
+  (void)hipSetDevice(r->device);
+  (void)hipDeviceSynchronize();
+  (void)free_framebuffers(r);
+  if (r->d_volume) (void)hipFree(r->d_volume);
+  if (r->d_tf_color) (void)hipFree(r->d_tf_color);
+  if (r->d_tf_alpha) (void)hipFree(r->d_tf_alpha);
+  if (r->d_noise) (void)hipFree(r->d_noise);
+  if (r->d_counters) (void)hipFree(r->d_counters);
+  if (r->d_sparse_count) (void)hipFree(r->d_sparse_count);
+  if (r->h_counters) (void)hipHostFree(r->h_counters);
+  if (r->ev0) (void)hipEventDestroy(r->ev0);
+  if (r->ev1) (void)hipEventDestroy(r->ev1);
+  for (int i = 0; i < 2; ++i)
+    if (r->own_stream[i]) (void)hipStreamDestroy(r->own_stream[i]);
+  delete r;
+}
+
+int ovr_hip_set_stream(ovr_hip_renderer* r, void* s)
+{
+  if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
+  if (int e = finish_frame(r)) return e;
+  r->user_stream = (hipStream_t)s;
+  r->use_user_stream = (s != nullptr);
+  return 0;
+}
+
+int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int value_type, const int32_t dims[3],
+                       const float grid_origin[3], const float grid_spacing[3])
+{
+  if (!r || !data || !dims || !grid_origin || !grid_spacing) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_volume: null argument");
+  if (dims[0] < 1 || dims[1] < 1 || dims[2] < 1) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_volume: dims must be positive");
+  const int vt = device_voxel_type(value_type);
+  if (vt < 0) return fail(OVR_HIP_EINVAL, "[Optix7] unexpected volume type ..."); // array.cpp:348, same text
+  if (mem_kind != OVR_HIP_MEM_HOST && mem_kind != OVR_HIP_MEM_DEVICE) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_volume: bad mem_kind");
+  if (int e = set_device(r)) return e;
+  if (int e = finish_frame(r)) return e;
+  HIP_TRY(hipDeviceSynchronize());
+
+  VolumeDesc vd{};
+  vd.type = vt;
+  vd.nx = dims[0]; vd.ny = dims[1]; vd.nz = dims[2];
+  const size_t es = voxel_size(vt);
+  const size_t align_elems = 64 / es; // rows start on 64-byte boundaries
+  vd.row_stride = (int)((((size_t)vd.nx + 1 + align_elems - 1) / align_elems) * align_elems);
+  vd.tiles_y = (vd.ny + 7) / 8;
+  vd.tiles_z = (vd.nz + 7) / 8;
+  vd.value_scale = 1.f;
+  vd.value_min_clamp = -FLT_MAX;
+  if (vt == VOX_U8) vd.value_scale = 1.f / 255.f;
+  if (vt == VOX_I8) { vd.value_scale = 1.f / 127.f; vd.value_min_clamp = -127.f; }
+  const size_t rows = (size_t)vd.tiles_y * vd.tiles_z * 64;
+  const size_t bytes = rows * (size_t)vd.row_stride * es + 64; // + slack for the pair load of the very last element
+
+  if (r->d_volume) { HIP_TRY(hipFree(r->d_volume)); r->d_volume = nullptr; }
+  HIP_TRY(hipMalloc(&r->d_volume, bytes));
+  HIP_TRY(hipMemset(r->d_volume, 0, bytes));
+  r->volume_bytes = bytes;
+  vd.data = r->d_volume;
+
+  const size_t in_es = value_type_size(value_type);
+  const size_t slice_bytes = (size_t)vd.nx * vd.ny * in_es;
+  hipStream_t st = r->own_stream[0];
+  if (mem_kind == OVR_HIP_MEM_DEVICE) {
+    // chunk over z only to keep grid.z within limits
+    for (int z0 = 0; z0 < vd.nz; z0 += 32768) {
+      const int nzc = std::min(32768, vd.nz - z0);
+      HIP_TRY(launch_relayout((const char*)data + (size_t)z0 * slice_bytes, value_type, r->d_volume, vd, z0, nzc, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  else {
+    // host input: staged through a bounded device buffer (<= 1 GiB), slab by slab
+    size_t slab = std::max<size_t>(1, ((size_t)1 << 30) / std::max<size_t>(1, slice_bytes));
+    slab = std::min<size_t>(slab, (size_t)vd.nz);
+    void* d_stage = nullptr;
+    HIP_TRY(hipMalloc(&d_stage, slab * slice_bytes));
+    for (int z0 = 0; z0 < vd.nz; z0 += (int)slab) {
+      const int nzc = (int)std::min<size_t>(slab, (size_t)(vd.nz - z0));
+      hipError_t e = hipMemcpyAsync(d_stage, (const char*)data + (size_t)z0 * slice_bytes, (size_t)nzc * slice_bytes, hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) e = launch_relayout(d_stage, value_type, r->d_volume, vd, z0, nzc, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) { (void)hipFree(d_stage); return fail(OVR_HIP_EDEVICE, std::string("[hip] volume upload failed: ") + hipGetErrorString(e)); }
+    }
+    HIP_TRY(hipFree(d_stage));
+  }
+  r->vd = vd;
+  r->value_type = value_type;
+  std::memcpy(r->origin, grid_origin, sizeof(r->origin));
+  std::memcpy(r->spacing, grid_spacing, sizeof(r->spacing));
+  r->have_volume = true;
+  update_volume_params(r);
+  update_tfn_range(r);
+  r->fb_reset = true;
+  return 0;
+}
+
+int ovr_hip_set_grid_convention(ovr_hip_renderer* r, int c)
+{
+  if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
+  if (c != OVR_HIP_GRID_CELL_CENTRED && c != OVR_HIP_GRID_VERTEX_CENTRED) return fail(OVR_HIP_EINVAL, "[hip] unknown grid convention");
+  std::lock_guard<std::mutex> lk(r->mtx);
+  r->grid_convention.set(c);
+  return 0;
+}
+
+int ovr_hip_set_transfer_function(ovr_hip_renderer* r, const float* colors, int32_t n_colors, const float* alphas, int32_t n_alphas,
+                                  float lo, float hi)
+{
+  if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
+  if (n_colors < 0 || n_alphas < 0 || (n_colors > 0 && !colors) || (n_alphas > 0 && !alphas))
+    return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_transfer_function: bad arguments");
+  std::lock_guard<std::mutex> lk(r->mtx);
+  TfnP t;
+  t.colors.assign(colors, colors + (size_t)n_colors * 3);
+  t.alphas.assign(alphas, alphas + (size_t)n_alphas * 2);
+  t.lo = lo;
+  t.hi = hi;
+  r->tfn.set(t);
+  return 0;
+}
+
+int ovr_hip_set_camera(ovr_hip_renderer* r, const float from[3], const float at[3], const float up[3], float fovy)
+{
+  if (!r || !from || !at || !up) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_camera: null argument");
+  std::lock_guard<std::mutex> lk(r->mtx);
+  CameraP c;
+  std::memcpy(c.from, from, sizeof(c.from));
+  std::memcpy(c.at, at, sizeof(c.at));
+  std::memcpy(c.up, up, sizeof(c.up));
+  c.fovy = fovy;
+  r->camera.set(c);
+  return 0;
+}
+
+int ovr_hip_set_fbsize(ovr_hip_renderer* r, int32_t w, int32_t h)
+{
+  if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
+  if (w < 0 || h < 0) return fail(OVR_HIP_EINVAL, "[hip] negative framebuffer size");
+  std::lock_guard<std::mutex> lk(r->mtx);
+  Size2 s; s.w = w; s.h = h;
+  r->fbsize.set(s);
+  return 0;
+}
+
+#define OVR_SIMPLE_SETTER(name, field, type, check, msg)                                                               \
+  int name(ovr_hip_renderer* r, type v)                                                                                \
+  {                                                                                                                    \
+    if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");                                                        \
+    if (!(check)) return fail(OVR_HIP_EINVAL, msg);                                                                    \
+    std::lock_guard<std::mutex> lk(r->mtx);                                                                            \
+    r->field.set(v);                                                                                                   \
+    return 0;                                                                                                          \
+  }
+OVR_SIMPLE_SETTER(ovr_hip_set_sample_per_pixel, spp, int32_t, v > 0, "'sample_per_pixel' should always be positive")
+OVR_SIMPLE_SETTER(ovr_hip_set_volume_sampling_rate, rate, float, v > 0.f, "[hip] sampling rate must be positive")
+OVR_SIMPLE_SETTER(ovr_hip_set_frame_accumulation, accumulate, int32_t, true, "")
+OVR_SIMPLE_SETTER(ovr_hip_set_sparse_sampling, sparse, int32_t, true, "")
+OVR_SIMPLE_SETTER(ovr_hip_set_shading, shading, int32_t, v >= 0 && v <= 2, "[hip] unknown shading mode")
+
+int ovr_hip_set_focus(ovr_hip_renderer* r, float cx, float cy, float scale, float base_noise)
+{
+  if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
+  std::lock_guard<std::mutex> lk(r->mtx);
+  FocusP f; f.cx = cx; f.cy = cy; f.scale = scale; f.base_noise = base_noise;
+  r->focus.set(f);
+  return 0;
+}
+
+int ovr_hip_set_noise_tile(ovr_hip_renderer* r, const float* tile, int32_t xy)
+{
+  if (!r || !tile || xy <= 0) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_noise_tile: bad arguments");
+  if (int e = set_device(r)) return e;
+  if (int e = finish_frame(r)) return e;
+  HIP_TRY(hipDeviceSynchronize());
+  if (r->d_noise) HIP_TRY(hipFree(r->d_noise));
+  const size_t bytes = (size_t)xy * xy * 64 * sizeof(float);
+  HIP_TRY(hipMalloc((void**)&r->d_noise, bytes));
+  HIP_TRY(hipMemcpy(r->d_noise, tile, bytes, hipMemcpyHostToDevice));
+  r->noise_xy = xy;
+  r->fb_reset = true;
+  return 0;
+}
+
+int ovr_hip_set_image_shard(ovr_hip_renderer* r, int32_t rank, int32_t world, int32_t tw, int32_t th)
+{
+  if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
+  if (world < 1 || rank < 0 || rank >= world || tw < 1 || th < 1) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_image_shard: bad arguments");
+  std::lock_guard<std::mutex> lk(r->mtx);
+  ShardP s; s.rank = rank; s.world = world; s.tw = tw; s.th = th;
+  r->shard.set(s);
+  return 0;
+}
+
+int ovr_hip_commit(ovr_hip_renderer* r)
+{
+  if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
+  if (int e = set_device(r)) return e;
+  if (int e = finish_frame(r)) return e;
+  std::lock_guard<std::mutex> lk(r->mtx);
+  bool fb_size_updated = false;
+  if (r->fbsize.update()) { // device_impl.cpp:116-122
+    if (int e = resize_framebuffers(r, r->fbsize.current.w, r->fbsize.current.h)) return e;
+    fb_size_updated = true;
+    r->fb_reset = true;
+  }
+  if (r->camera.update() || fb_size_updated || r->camera_dirty) { // :125-144
+    if (r->fbsize.current.w > 0 && r->fbsize.current.h > 0) {
+      update_camera(r);
+      r->camera_dirty = false;
+    }
+    r->fb_reset = true;
+  }
+  if (r->tfn.update()) { // :146-153
+    if (int e = upload_tfn(r)) return e;
+    update_tfn_range(r);
+    r->fb_reset = true;
+  }
+  if (r->grid_convention.update()) {
+    if (r->have_volume) update_volume_params(r);
+    r->fb_reset = true;
+  }
+  if (r->focus.update()) r->fb_reset = true;      // :155-168
+  if (r->spp.update()) r->fb_reset = true;        // :170-173
+  if (r->sparse.update()) r->fb_reset = true;     // :180-183
+  if (r->accumulate.update()) r->fb_reset = true; // :185-188
+  if (r->rate.update()) r->fb_reset = true;       // :190-196
+  if (r->shading.update()) r->fb_reset = true;
+  if (r->shard.update()) r->fb_reset = true;
+  return 0;
+}
+
+int ovr_hip_render_async(ovr_hip_renderer* r)
+{
+  if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
+  if (int e = set_device(r)) return e;
+  if (int e = finish_frame(r)) return e;
+  return enqueue_frame(r);
+}
+
+int ovr_hip_sync(ovr_hip_renderer* r)
+{
+  if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
+  if (int e = set_device(r)) return e;
+  return finish_frame(r);
+}
+
+int ovr_hip_render(ovr_hip_renderer* r)
+{
+  if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
+  const auto t0 = std::chrono::high_resolution_clock::now(); // optix7/device.cpp:37-42
+  if (int e = ovr_hip_render_async(r)) return e;
+  if (int e = finish_frame(r)) return e;
+  const auto t1 = std::chrono::high_resolution_clock::now();
+  const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  r->stats.render_ms = ms;
+  r->render_time_ms += ms;
+  return 0;
+}
+
+int ovr_hip_mapframe(ovr_hip_renderer* r, int mem_kind, const float** rgba, size_t* rgba_bytes, const float** grad, size_t* grad_bytes)
+{
+  if (!r || !rgba || !rgba_bytes) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_mapframe: null argument");
+  if (int e = set_device(r)) return e;
+  if (int e = finish_frame(r)) return e;
+  const size_t n = r->fb_pixels;
+  const int c = r->cur;
+  if (mem_kind == OVR_HIP_MEM_DEVICE) {
+    *rgba = r->d_rgba[c];
+    *rgba_bytes = n * 4 * sizeof(float);
+    if (grad) *grad = r->d_grad[c];
+    if (grad_bytes) *grad_bytes = n * 3 * sizeof(float);
+    return 0;
+  }
+  if (mem_kind != OVR_HIP_MEM_HOST) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_mapframe: bad mem_kind");
+  if (n == 0) { *rgba = nullptr; *rgba_bytes = 0; if (grad) *grad = nullptr; if (grad_bytes) *grad_bytes = 0; return 0; }
+  hipStream_t st = r->stream();
+  if (!r->h_rgba[c]) HIP_TRY(hipHostMalloc((void**)&r->h_rgba[c], n * 4 * sizeof(float), hipHostMallocDefault));
+  HIP_TRY(hipMemcpyAsync(r->h_rgba[c], r->d_rgba[c], n * 4 * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (grad) {
+    if (!r->h_grad[c]) HIP_TRY(hipHostMalloc((void**)&r->h_grad[c], n * 3 * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(r->h_grad[c], r->d_grad[c], n * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  *rgba = r->h_rgba[c];
+  *rgba_bytes = n * 4 * sizeof(float);
+  if (grad) *grad = r->h_grad[c];
+  if (grad_bytes) *grad_bytes = n * 3 * sizeof(float);
+  return 0;
+}
+
+int ovr_hip_swap(ovr_hip_renderer* r)
+{
+  if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
+  if (int e = set_device(r)) return e;
+  if (int e = finish_frame(r)) return e;
+  HIP_TRY(hipStreamSynchronize(r->stream())); // device_impl.cpp:105
+  r->cur = (r->cur + 1) % 2;                  // safe_swap, optix7_common.h:366-370
+  return 0;
+}
+
+double ovr_hip_render_time_ms(const ovr_hip_renderer* r) { return r ? r->render_time_ms : 0.0; }
+
+int ovr_hip_get_stats(const ovr_hip_renderer* r, ovr_hip_stats* out)
+{
+  if (!r || !out) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_get_stats: null argument");
+  if (r->async_pending) return fail(OVR_HIP_ESTATE, "[hip] ovr_hip_get_stats: a frame is still in flight (call ovr_hip_sync)");
+  *out = r->stats;
+  return 0;
+}
+
+int ovr_hip_owned_tiles(const ovr_hip_renderer* r, int32_t rank, int32_t* n_tiles)
+{
+  if (!r || !n_tiles) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_owned_tiles: null argument");
+  const ShardP& s = r->shard.current;
+  if (rank < 0 || rank >= s.world) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_owned_tiles: rank out of range");
+  *n_tiles = count_owned_tiles(r->fbsize.current.w, r->fbsize.current.h, s.tw, s.th, rank, s.world);
+  return 0;
+}
+
+int ovr_hip_pack_tiles(ovr_hip_renderer* r, float* dst, size_t dst_bytes)
+{
+  if (!r || !dst) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_pack_tiles: null argument");
+  if (int e = set_device(r)) return e;
+  const ShardP& s = r->shard.current;
+  const int W = r->fbsize.current.w, H = r->fbsize.current.h;
+  const size_t need = (size_t)count_owned_tiles(W, H, s.tw, s.th, s.rank, s.world) * s.tw * s.th * 4 * sizeof(float);
+  if (dst_bytes < need) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_pack_tiles: destination too small");
+  HIP_TRY(launch_pack_tiles(r->d_rgba[r->cur], dst, W, H, s.tw, s.th, s.rank, s.world, r->stream()));
+  return 0;
+}
+
+int ovr_hip_unpack_tiles(ovr_hip_renderer* r, int32_t src_rank, const float* src, size_t src_bytes, float* frame, size_t frame_bytes)
+{
+  if (!r || !src || !frame) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_unpack_tiles: null argument");
+  if (int e = set_device(r)) return e;
+  const ShardP& s = r->shard.current;
+  const int W = r->fbsize.current.w, H = r->fbsize.current.h;
+  if (src_rank < 0 || src_rank >= s.world) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_unpack_tiles: rank out of range");
+  const size_t need = (size_t)count_owned_tiles(W, H, s.tw, s.th, src_rank, s.world) * s.tw * s.th * 4 * sizeof(float);
+  if (src_bytes < need) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_unpack_tiles: source too small");
+  if (frame_bytes < (size_t)W * H * 4 * sizeof(float)) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_unpack_tiles: frame too small");
+  HIP_TRY(launch_unpack_tiles(src, frame, W, H, s.tw, s.th, src_rank, s.world, r->stream()));
+  return 0;
+}
+
+int ovr_hip_sparse_mask(ovr_hip_renderer* r, int32_t frame_index, int32_t* out_xy, size_t out_bytes, int64_t* n_out)
+{
+  if (!r || !out_xy || !n_out) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_sparse_mask: null argument");
+  if (int e = set_device(r)) return e;
+  if (int e = finish_frame(r)) return e;
+  if (!r->d_noise) return fail(OVR_HIP_ESTATE, "[hip] ovr_hip_sparse_mask: no noise tile was set");
+  const int W = r->fbsize.current.w, H = r->fbsize.current.h;
+  if (W <= 0 || H <= 0) return fail(OVR_HIP_ESTATE, "[hip] ovr_hip_sparse_mask: framebuffer size not committed");
+  if (out_bytes < (size_t)W * H * 2 * sizeof(int32_t)) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_sparse_mask: output too small");
+  if (int e = ensure_sparse_buffers(r)) return e;
+  hipStream_t st = r->stream();
+  HIP_TRY(launch_sparse_mask(make_mask_params(r, frame_index, out_xy), st));
+  unsigned long long cnt = 0;
+  HIP_TRY(hipMemcpyAsync(&cnt, r->d_sparse_count, sizeof(cnt), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  *n_out = (int64_t)cnt;
+  return 0;
+}
+
+int ovr_hip_tea_floats(ovr_hip_renderer* r, uint32_t* v0v1, float* out, int64_t n)
+{
+  if (!r || !v0v1 || !out || n < 0) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_tea_floats: bad arguments");
+  if (int e = set_device(r)) return e;
+  HIP_TRY(launch_tea(v0v1, out, n, r->stream()));
+  HIP_TRY(hipStreamSynchronize(r->stream()));
+  return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,332 @@
+"""Host-side mirror of the reference's renderer interface for the HIP device.
+
+`DeviceHIP` has the same method names, argument meaning, call protocol and error behaviour as
+`ovr::MainRenderer` (reference ovr/renderer.h:82-341) as implemented by its GPU device
+(ovr/devices/optix7/device.cpp:16-49): queued thread-safe setters, `init(scene, camera)`, then per frame
+`commit()`, `render()`, `mapframe()`, `swap()`.  Everything is forwarded to the C ABI in include/ovr_hip.h;
+torch is only used to hand device memory across (volumes living in HBM, frames mapped as tensors)."""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+
+_NP_TO_TYPE = {
+    np.dtype(np.uint8): L.TYPE_UINT8, np.dtype(np.int8): L.TYPE_INT8,
+    np.dtype(np.uint16): L.TYPE_UINT16, np.dtype(np.int16): L.TYPE_INT16,
+    np.dtype(np.uint32): L.TYPE_UINT32, np.dtype(np.int32): L.TYPE_INT32,
+    np.dtype(np.float32): L.TYPE_FLOAT, np.dtype(np.float64): L.TYPE_DOUBLE,
+}
+
+
+@dataclass
+class Camera:
+    """ovr::scene::Camera (reference ovr/scene.h:201-231); fovy defaults to 60 like PerspectiveCamera."""
+    eye: Sequence[float] = (0.0, 0.0, -1000.0)   # `from` in the reference (a Python keyword)
+    at: Sequence[float] = (0.0, 0.0, 0.0)
+    up: Sequence[float] = (0.0, 1.0, 0.0)
+    fovy: float = 60.0
+
+
+@dataclass
+class TransferFunction:
+    """ovr::scene::TransferFunction (scene.h:233-237): color = N x 4 float (rgb + unused w), opacity = M float."""
+    color: np.ndarray = None
+    opacity: np.ndarray = None
+    value_range: Sequence[float] = (1.0, -1.0)
+
+
+@dataclass
+class Scene:
+    """The subset of ovr::scene::Scene the path consumes: one structured-regular volume + its transfer function
+    (what parse_single_volume_scene accepts, scene.h:413-426) and the render settings main_batch forwards."""
+    volume: object = None                      # numpy array or torch tensor, shape (nz, ny, nx), x fastest
+    grid_origin: Sequence[float] = (0.0, 0.0, 0.0)
+    grid_spacing: Sequence[float] = (1.0, 1.0, 1.0)
+    transfer_function: TransferFunction = field(default_factory=TransferFunction)
+    camera: Camera = field(default_factory=Camera)
+    volume_sampling_rate: float = 1.0
+    spp: int = 1
+
+
+class _DevicePtr:
+    """Exposes a raw device pointer through __cuda_array_interface__ so torch.as_tensor can view it without a copy."""
+
+    def __init__(self, ptr, shape, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 3}
+
+
+class CrossDeviceBuffer:
+    """Mirror of the reference's CrossDeviceBuffer (ovr/common/cross_device_buffer.h:19-208): a non-owning view of the
+    frame, either on the host or on the device; to_cpu() returns host data."""
+    DEVICE_CPU, DEVICE_HIP = 0, 1
+
+    def __init__(self):
+        self._data = None
+        self.device = self.DEVICE_CPU
+        self.nbytes = 0
+
+    def set_data(self, data, nbytes, device):
+        self._data, self.nbytes, self.device = data, nbytes, device
+
+    def data(self):
+        return self._data
+
+    def to_cpu(self):
+        if self.device == self.DEVICE_CPU:
+            return self
+        out = CrossDeviceBuffer()
+        out.set_data(self._data.cpu().numpy(), self.nbytes, self.DEVICE_CPU)
+        return out
+
+
+class FrameBufferData:
+    """MainRenderer::FrameBufferData (renderer.h:89-97)."""
+
+    def __init__(self):
+        self.rgba = CrossDeviceBuffer()
+        self.grad = CrossDeviceBuffer()
+
+
+def _f3(v):
+    a = (C.c_float * 3)(*[float(x) for x in v])
+    return a
+
+
+class DeviceHIP:
+    """The "hip" device.  Method-for-method mirror of ovr::MainRenderer + DeviceOptix7."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = L.load()
+        self._h = C.c_void_p()
+        L.check(self._lib.ovr_hip_create(C.byref(self._h), int(device_id)))
+        self.device_id = int(device_id)
+        self.current_scene: Optional[Scene] = None
+        self.variance = float("inf")          # renderer.h:287
+        self._fbsize = (0, 0)
+        self._keep = []                        # keeps ctypes buffers alive across calls
+
+    # ---- lifetime -------------------------------------------------------------------------------------------
+    def close(self):
+        if self._h:
+            self._lib.ovr_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- thread-safe setters (renderer.h:135-248) ------------------------------------------------------------
+    def set_fbsize(self, fbsize):
+        self._fbsize = (int(fbsize[0]), int(fbsize[1]))
+        L.check(self._lib.ovr_hip_set_fbsize(self._h, *self._fbsize))
+
+    def set_camera(self, camera_or_from, at=None, up=None):
+        """set_camera(Camera) or set_camera(from, at, up).  The three-vector form builds Camera{from, at, up} whose fovy
+        is the default 60 degrees - exactly what renderer.h:149-152 does (it discards a scene's fovy)."""
+        cam = camera_or_from if isinstance(camera_or_from, Camera) else Camera(camera_or_from, at, up)
+        L.check(self._lib.ovr_hip_set_camera(self._h, _f3(cam.eye), _f3(cam.at), _f3(cam.up), float(cam.fovy)))
+
+    def set_transfer_function(self, c, o, r):
+        """c: flat RGB triples, o: flat (position, alpha) pairs, r: (lo, hi) in raw data units (renderer.h:154-161)."""
+        c = np.ascontiguousarray(c, dtype=np.float32).ravel()
+        o = np.ascontiguousarray(o, dtype=np.float32).ravel()
+        if c.size % 3 or o.size % 2:
+            raise RuntimeError("transfer function arrays must hold RGB triples and (position, alpha) pairs")
+        L.check(self._lib.ovr_hip_set_transfer_function(
+            self._h, c.ctypes.data_as(C.POINTER(C.c_float)), c.size // 3, o.ctypes.data_as(C.POINTER(C.c_float)), o.size // 2,
+            float(r[0]), float(r[1])))
+
+    def set_focus(self, center, scale, base_noise):
+        L.check(self._lib.ovr_hip_set_focus(self._h, float(center[0]), float(center[1]), float(scale), float(base_noise)))
+
+    def set_sample_per_pixel(self, spp):
+        L.check(self._lib.ovr_hip_set_sample_per_pixel(self._h, int(spp)))
+
+    def set_sparse_sampling(self, on):
+        L.check(self._lib.ovr_hip_set_sparse_sampling(self._h, int(bool(on))))
+
+    def set_frame_accumulation(self, on):
+        L.check(self._lib.ovr_hip_set_frame_accumulation(self._h, int(bool(on))))
+
+    def set_volume_sampling_rate(self, rate):
+        self._rate_set_by_app = True
+        L.check(self._lib.ovr_hip_set_volume_sampling_rate(self._h, float(rate)))
+
+    def set_path_tracing(self, on):
+        if on:  # the path tracer is outside this backend's scope
+            raise RuntimeError("[hip] path tracing is not part of the ray-marching backend")
+
+    # accepted and ignored exactly as the reference's ray marcher ignores them (device_impl.cpp:113-197 never reads them)
+    def set_add_lights(self, v): pass
+    def set_photonmapping(self, v): pass
+    def set_volume_density_scale(self, v): pass
+    def set_mat_ambient(self, v): pass
+    def set_mat_diffuse(self, v): pass
+    def set_mat_specular(self, v): pass
+    def set_mat_shininess(self, v): pass
+    def set_light_phi(self, v): pass
+    def set_light_theta(self, v): pass
+    def set_light_radius(self, v): pass
+    def set_light_intensity(self, v): pass
+
+    # ---- extensions of this backend ----------------------------------------------------------------------------
+    def set_shading(self, mode):
+        L.check(self._lib.ovr_hip_set_shading(self._h, int(mode)))
+
+    def set_grid_convention(self, convention):
+        L.check(self._lib.ovr_hip_set_grid_convention(self._h, int(convention)))
+
+    def set_noise_tile(self, tile):
+        tile = np.ascontiguousarray(tile, dtype=np.float32)
+        xy = int(round((tile.size // 64) ** 0.5))
+        if xy * xy * 64 != tile.size:
+            raise RuntimeError("noise tile must hold xy*xy*64 floats, layout [y][x][t]")
+        L.check(self._lib.ovr_hip_set_noise_tile(self._h, tile.ctypes.data_as(C.POINTER(C.c_float)), xy))
+
+    def set_image_shard(self, rank, world, tile_w=64, tile_h=64):
+        L.check(self._lib.ovr_hip_set_image_shard(self._h, int(rank), int(world), int(tile_w), int(tile_h)))
+
+    def set_stream(self, stream_ptr):
+        L.check(self._lib.ovr_hip_set_stream(self._h, C.c_void_p(int(stream_ptr) if stream_ptr else None)))
+
+    # ---- init / per-frame protocol (renderer.h:107-116,290-341) ----------------------------------------------
+    def set_scene(self, scene: Scene):
+        """MainRenderer::set_scene (renderer.h:299-341): flatten the scene TF into the app-side format and queue it."""
+        tfn = scene.transfer_function
+        if tfn is not None and tfn.color is not None and tfn.opacity is not None:
+            color = np.asarray(tfn.color, dtype=np.float32).reshape(-1, 4)
+            opacity = np.asarray(tfn.opacity, dtype=np.float32).ravel()
+            tfn_colors = color[:, :3].ravel()
+            pos = np.arange(opacity.size, dtype=np.float32) / np.float32(max(opacity.size - 1, 1))
+            tfn_alphas = np.stack([pos, opacity], axis=1).ravel()
+            self.set_transfer_function(tfn_colors, tfn_alphas, tfn.value_range)
+        self.current_scene = scene
+
+    def init(self, scene: Scene, camera: Camera):
+        """MainRenderer::init(argc, argv, scene, camera) (renderer.h:290-297) followed by DeviceOptix7::init ->
+        Impl::buildScene (device_impl.cpp:283-302): upload the volume, take the scene's sampling rate, first commit."""
+        self.set_scene(scene)
+        self.set_camera(camera)
+        self._upload_volume(scene)
+        # buildScene applies the scene's rate directly; an earlier set_volume_sampling_rate() stays queued and wins at commit
+        # (device_impl.cpp:298 then :190-196) - reproduced by not queuing the scene's rate when the app already set one.
+        if not getattr(self, "_rate_set_by_app", False):
+            L.check(self._lib.ovr_hip_set_volume_sampling_rate(self._h, float(scene.volume_sampling_rate)))
+        self.commit()
+
+    def _upload_volume(self, scene: Scene):
+        vol = scene.volume
+        if vol is None:
+            raise RuntimeError("expect only one instance")  # parse_single_volume_scene, scene.h:416
+        origin, spacing = _f3(scene.grid_origin), _f3(scene.grid_spacing)
+        if isinstance(vol, np.ndarray):
+            if vol.ndim != 3:
+                raise RuntimeError("volume must have shape (nz, ny, nx)")
+            vol = np.ascontiguousarray(vol)
+            vt = _NP_TO_TYPE.get(vol.dtype)
+            if vt is None:
+                raise RuntimeError("[Optix7] unexpected volume type ...")
+            dims = (C.c_int32 * 3)(vol.shape[2], vol.shape[1], vol.shape[0])
+            L.check(self._lib.ovr_hip_set_volume(self._h, C.c_void_p(vol.ctypes.data), L.MEM_HOST, vt, dims, origin, spacing))
+            return
+        import torch
+        if not isinstance(vol, torch.Tensor) or vol.dim() != 3:
+            raise RuntimeError("volume must be a numpy array or torch tensor of shape (nz, ny, nx)")
+        vol = vol.contiguous()
+        tmap = {torch.uint8: L.TYPE_UINT8, torch.int8: L.TYPE_INT8, torch.int16: L.TYPE_INT16, torch.int32: L.TYPE_INT32,
+                torch.float32: L.TYPE_FLOAT, torch.float64: L.TYPE_DOUBLE}
+        if hasattr(torch, "uint16"):
+            tmap[torch.uint16] = L.TYPE_UINT16
+        vt = tmap.get(vol.dtype)
+        if vt is None:
+            raise RuntimeError("[Optix7] unexpected volume type ...")
+        dims = (C.c_int32 * 3)(vol.shape[2], vol.shape[1], vol.shape[0])
+        kind = L.MEM_DEVICE if vol.is_cuda else L.MEM_HOST
+        if vol.is_cuda:
+            torch.cuda.current_stream(vol.device).synchronize()
+        L.check(self._lib.ovr_hip_set_volume(self._h, C.c_void_p(vol.data_ptr()), kind, vt, dims, origin, spacing))
+
+    def commit(self):
+        L.check(self._lib.ovr_hip_commit(self._h))
+
+    def render(self):
+        L.check(self._lib.ovr_hip_render(self._h))
+        self.variance = 0.0  # device_impl.cpp:266
+
+    def render_async(self):
+        L.check(self._lib.ovr_hip_render_async(self._h))
+
+    def sync(self):
+        L.check(self._lib.ovr_hip_sync(self._h))
+
+    def swap(self):
+        L.check(self._lib.ovr_hip_swap(self._h))
+
+    def mapframe(self, fb: FrameBufferData, device: bool = False):
+        """Impl::mapframe (device_impl.cpp:271-281).  device=True hands out device memory as torch tensors (what the
+        reference does, DEVICE_CUDA); device=False returns host arrays (the caller's to_cpu())."""
+        rgba, grad = C.c_void_p(), C.c_void_p()
+        nb_rgba, nb_grad = C.c_size_t(), C.c_size_t()
+        kind = L.MEM_DEVICE if device else L.MEM_HOST
+        L.check(self._lib.ovr_hip_mapframe(self._h, kind, C.byref(rgba), C.byref(nb_rgba), C.byref(grad), C.byref(nb_grad)))
+        w, h = self._fbsize
+        if device:
+            import torch
+            dev = torch.device("cuda", self.device_id)
+            t_rgba = torch.as_tensor(_DevicePtr(rgba.value, (h, w, 4)), device=dev)
+            t_grad = torch.as_tensor(_DevicePtr(grad.value, (h, w, 3)), device=dev)
+            fb.rgba.set_data(t_rgba, nb_rgba.value, CrossDeviceBuffer.DEVICE_HIP)
+            fb.grad.set_data(t_grad, nb_grad.value, CrossDeviceBuffer.DEVICE_HIP)
+        else:
+            a_rgba = np.ctypeslib.as_array(C.cast(rgba, C.POINTER(C.c_float)), shape=(h, w, 4))
+            a_grad = np.ctypeslib.as_array(C.cast(grad, C.POINTER(C.c_float)), shape=(h, w, 3))
+            fb.rgba.set_data(a_rgba, nb_rgba.value, CrossDeviceBuffer.DEVICE_CPU)
+            fb.grad.set_data(a_grad, nb_grad.value, CrossDeviceBuffer.DEVICE_CPU)
+        return fb
+
+    # ---- getters ------------------------------------------------------------------------------------------------
+    @property
+    def render_time(self):
+        """MainRenderer::render_time (renderer.h:87): accumulated milliseconds inside render()."""
+        return float(self._lib.ovr_hip_render_time_ms(self._h))
+
+    def unsafe_get_fbsize(self):
+        return self._fbsize
+
+    def unsafe_get_variance(self):
+        return self.variance
+
+    def stats(self):
+        s = L.Stats()
+        L.check(self._lib.ovr_hip_get_stats(self._h, C.byref(s)))
+        return s
+
+    # ---- stand-alone pieces for known-answer tests ----------------------------------------------------------------
+    def sparse_mask(self, frame_index):
+        import torch
+        w, h = self._fbsize
+        out = torch.empty(w * h * 2, dtype=torch.int32, device=torch.device("cuda", self.device_id))
+        n = C.c_int64()
+        L.check(self._lib.ovr_hip_sparse_mask(self._h, int(frame_index), C.c_void_p(out.data_ptr()), out.numel() * 4, C.byref(n)))
+        return out[: n.value].cpu().numpy()
+
+    def tea_floats(self, v0v1):
+        import torch
+        dev = torch.device("cuda", self.device_id)
+        st = torch.as_tensor(np.ascontiguousarray(v0v1, dtype=np.uint32).view(np.int32)).to(dev)
+        out = torch.empty(st.numel(), dtype=torch.float32, device=dev)
+        L.check(self._lib.ovr_hip_tea_floats(self._h, C.c_void_p(st.data_ptr()), C.c_void_p(out.data_ptr()), st.numel() // 2))
+        return out.cpu().numpy(), st.cpu().numpy().view(np.uint32)
+
+
+def create_renderer(name: str, device_id: int = 0):
+    """create_renderer(name) (reference ovr/renderer.cpp:42-61).  Only "hip" exists here; anything else raises the
+    same way the reference's factory does for an unknown device."""
+    if name == "hip":
+        return DeviceHIP(device_id)
+    raise RuntimeError(f"OVR ERROR: Could not find device_{name} (only the 'hip' device is built)")

@@ -1,0 +1,62 @@
+"""Image-plane sharding across one-process-per-GPU ranks.
+
+Pixels are independent, so the path shards with no exchange during rendering: the image is cut into tiles, tile
+(tx, ty) belongs to rank (tx + ty) % world, every rank renders its tiles against a full replica of the volume and
+one gather per displayed frame brings the tiles to rank 0.  The only collective is that gather
+(torch.distributed: RCCL over xGMI on GPUs, gloo on CPU for tests)."""
+from typing import List, Optional
+
+import numpy as np
+
+
+def tile_owner(tx: int, ty: int, world: int) -> int:
+    return (tx + ty) % world
+
+
+def owned_tiles(width: int, height: int, tile_w: int, tile_h: int, rank: int, world: int) -> List[tuple]:
+    """tiles of `rank` in the row-major order the pack kernel uses for its payload slots"""
+    tiles_x = (width + tile_w - 1) // tile_w
+    tiles_y = (height + tile_h - 1) // tile_h
+    return [(tx, ty) for ty in range(tiles_y) for tx in range(tiles_x) if tile_owner(tx, ty, world) == rank]
+
+
+def max_owned_tiles(width, height, tile_w, tile_h, world) -> int:
+    return max(len(owned_tiles(width, height, tile_w, tile_h, r, world)) for r in range(world))
+
+
+def pack_tiles_host(frame: np.ndarray, tile_w: int, tile_h: int, rank: int, world: int, slots: Optional[int] = None) -> np.ndarray:
+    """host restatement of the pack kernel: frame (H, W, 4) -> payload (slots, tile_h, tile_w, 4)"""
+    h, w = frame.shape[:2]
+    tiles = owned_tiles(w, h, tile_w, tile_h, rank, world)
+    out = np.zeros((slots if slots is not None else len(tiles), tile_h, tile_w, 4), dtype=frame.dtype)
+    for k, (tx, ty) in enumerate(tiles):
+        blk = frame[ty * tile_h:(ty + 1) * tile_h, tx * tile_w:(tx + 1) * tile_w]
+        out[k, :blk.shape[0], :blk.shape[1]] = blk
+    return out
+
+
+def unpack_tiles_host(payload: np.ndarray, frame: np.ndarray, tile_w: int, tile_h: int, rank: int, world: int) -> None:
+    h, w = frame.shape[:2]
+    for k, (tx, ty) in enumerate(owned_tiles(w, h, tile_w, tile_h, rank, world)):
+        y0, x0 = ty * tile_h, tx * tile_w
+        hh, ww = min(tile_h, h - y0), min(tile_w, w - x0)
+        frame[y0:y0 + hh, x0:x0 + ww] = payload[k, :hh, :ww]
+
+
+def gather_frame(local_payload, width, height, tile_w, tile_h, rank, world, unpack, dst: int = 0):
+    """One gather to `dst` per displayed frame.  `local_payload` is this rank's (slots, th, tw, 4) tensor with the same
+    `slots` on every rank (max over ranks); `unpack(src_rank, payload)` scatters one rank's payload into the final frame
+    (ovr_hip_unpack_tiles on GPUs, unpack_tiles_host in the CPU tests).  Returns True on `dst`."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        unpack(0, local_payload)
+        return True
+    if rank == dst:
+        bufs = [torch.empty_like(local_payload) for _ in range(world)]
+        dist.gather(local_payload, gather_list=bufs, dst=dst)
+        for src in range(world):
+            unpack(src, bufs[src])
+        return True
+    dist.gather(local_payload, gather_list=None, dst=dst)
+    return False

@@ -1,0 +1,188 @@
+"""ctypes binding of the CPU oracle (oracle/libovr_oracle.so).  TEST INFRASTRUCTURE ONLY: imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg - never by the package in open-volume-renderer_amd/."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libovr_oracle.so")
+
+TYPE = {np.dtype(np.uint8): 100, np.dtype(np.int8): 101, np.dtype(np.uint16): 200, np.dtype(np.int16): 201,
+        np.dtype(np.uint32): 300, np.dtype(np.int32): 301, np.dtype(np.float32): 400, np.dtype(np.float64): 500}
+SHADE_NONE, SHADE_GRADIENT, SHADE_FULL = 0, 1, 2
+GRID_CELL, GRID_VERTEX = 0, 1
+
+
+class Scene(C.Structure):
+    _fields_ = [
+        ("volume", C.c_void_p), ("value_type", C.c_int), ("dims", C.c_int * 3),
+        ("grid_origin", C.c_float * 3), ("grid_spacing", C.c_float * 3), ("grid_convention", C.c_int),
+        ("tfn_colors", C.POINTER(C.c_float)), ("n_colors", C.c_int),
+        ("tfn_alphas", C.POINTER(C.c_float)), ("n_alphas", C.c_int), ("tfn_range", C.c_float * 2),
+        ("cam_from", C.c_float * 3), ("cam_at", C.c_float * 3), ("cam_up", C.c_float * 3), ("fovy", C.c_float),
+        ("width", C.c_int), ("height", C.c_int), ("spp", C.c_int), ("sampling_rate", C.c_float), ("shading", C.c_int),
+        ("sparse_sampling", C.c_int), ("focus_center", C.c_float * 2), ("focus_scale", C.c_float), ("base_noise", C.c_float),
+        ("noise_tile", C.POINTER(C.c_float)), ("noise_xy", C.c_int),
+        ("tile_w", C.c_int), ("tile_h", C.c_int), ("rank", C.c_int), ("world", C.c_int),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("shaded_samples", C.c_uint64),
+                ("shadow_samples", C.c_uint64), ("shadow_samples_visible", C.c_uint64)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "libovr_oracle.so"], stdout=subprocess.DEVNULL)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(LIB_PATH)
+    fp = C.POINTER(C.c_float)
+    lib.ovr_oracle_tea_floats.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), fp]
+    lib.ovr_oracle_camera_basis.argtypes = [fp, fp, fp, C.c_float, C.c_int, C.c_int, fp]
+    lib.ovr_oracle_intersect_box.argtypes = [fp, fp, fp, fp]
+    lib.ovr_oracle_intersect_box.restype = C.c_int
+    lib.ovr_oracle_integer_normalize.argtypes = [C.c_float, C.c_int]
+    lib.ovr_oracle_integer_normalize.restype = C.c_float
+    lib.ovr_oracle_sample_volume.argtypes = [C.POINTER(Scene), fp]
+    lib.ovr_oracle_sample_volume.restype = C.c_float
+    lib.ovr_oracle_gradient.argtypes = [C.POINTER(Scene), fp, C.c_float, fp]
+    lib.ovr_oracle_sample_tfn.argtypes = [C.POINTER(Scene), C.c_float, fp]
+    lib.ovr_oracle_opacity_correction.argtypes = [C.c_float, C.c_float, C.c_float]
+    lib.ovr_oracle_opacity_correction.restype = C.c_float
+    lib.ovr_oracle_render_frame.argtypes = [C.POINTER(Scene), C.c_int, C.c_int, fp, fp, fp, C.POINTER(Counters), C.c_int]
+    lib.ovr_oracle_trace_ray.argtypes = [C.POINTER(Scene), fp, fp, fp, fp, C.POINTER(Counters)]
+    lib.ovr_oracle_rgba8.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+    lib.ovr_oracle_sparse_mask.argtypes = [C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, fp, C.c_float, C.c_float, fp, C.c_int]
+    lib.ovr_oracle_sparse_mask.restype = C.c_int64
+    lib.ovr_oracle_exp_det.argtypes = [C.c_float]
+    lib.ovr_oracle_exp_det.restype = C.c_float
+    lib.ovr_oracle_tile_owner.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.ovr_oracle_tile_owner.restype = C.c_int
+    lib.ovr_oracle_macrocell_value_range.argtypes = [C.POINTER(Scene), fp]
+    lib.ovr_oracle_macrocell_majorant.argtypes = [C.POINTER(Scene), fp, C.c_int, fp]
+    _lib = lib
+    return lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class OracleScene:
+    """Owns the numpy buffers a C `ovr_oracle_scene` points into."""
+
+    def __init__(self, volume, colors, alphas, value_range, camera, width, height, fovy=60.0, spp=1, rate=1.0,
+                 shading=SHADE_FULL, grid_origin=(0, 0, 0), grid_spacing=(1, 1, 1), convention=GRID_CELL,
+                 sparse=False, focus=((0.5, 0.5), 0.2, 0.1), noise=None, shard=None):
+        self.lib = load()
+        self.volume = np.ascontiguousarray(volume)
+        self.colors = np.ascontiguousarray(colors, dtype=np.float32).ravel()
+        self.alphas = np.ascontiguousarray(alphas, dtype=np.float32).ravel()
+        self.noise = None if noise is None else np.ascontiguousarray(noise, dtype=np.float32).ravel()
+        s = Scene()
+        s.volume = self.volume.ctypes.data
+        s.value_type = TYPE[self.volume.dtype]
+        nz, ny, nx = self.volume.shape
+        s.dims[:] = [nx, ny, nz]
+        s.grid_origin[:] = list(map(float, grid_origin))
+        s.grid_spacing[:] = list(map(float, grid_spacing))
+        s.grid_convention = convention
+        s.tfn_colors, s.n_colors = _fp(self.colors), self.colors.size // 3
+        s.tfn_alphas, s.n_alphas = _fp(self.alphas), self.alphas.size // 2
+        s.tfn_range[:] = [float(value_range[0]), float(value_range[1])]
+        eye, at, up = camera
+        s.cam_from[:] = list(map(float, eye))
+        s.cam_at[:] = list(map(float, at))
+        s.cam_up[:] = list(map(float, up))
+        s.fovy = float(fovy)
+        s.width, s.height, s.spp = int(width), int(height), int(spp)
+        s.sampling_rate = float(rate)
+        s.shading = int(shading)
+        s.sparse_sampling = int(bool(sparse))
+        s.focus_center[:] = [float(focus[0][0]), float(focus[0][1])]
+        s.focus_scale, s.base_noise = float(focus[1]), float(focus[2])
+        if self.noise is not None:
+            s.noise_tile = _fp(self.noise)
+            s.noise_xy = int(round((self.noise.size // 64) ** 0.5))
+        if shard is not None:
+            s.rank, s.world, s.tile_w, s.tile_h = shard
+        else:
+            s.rank, s.world, s.tile_w, s.tile_h = 0, 1, 0, 0
+        self.s = s
+
+    def render(self, frames=1, accumulate=False, nthreads=0, want_grad=True):
+        """renders `frames` consecutive frames (frame_index 1..frames); returns (rgba, grad, counters of the last frame)"""
+        w, h = self.s.width, self.s.height
+        rgba = np.zeros((h, w, 4), dtype=np.float32)
+        grad = np.zeros((h, w, 3), dtype=np.float32)
+        accum = np.zeros((h, w, 4), dtype=np.float32)
+        cnt = Counters()
+        for f in range(1, frames + 1):
+            if self.s.sparse_sampling and not accumulate:
+                rgba[:] = 0
+                grad[:] = 0
+            self.lib.ovr_oracle_render_frame(C.byref(self.s), f, int(bool(accumulate)), _fp(accum), _fp(rgba),
+                                             _fp(grad) if want_grad else None, C.byref(cnt), int(nthreads))
+        return rgba, grad, cnt
+
+    def sample(self, p):
+        a = (C.c_float * 3)(*map(float, p))
+        return float(self.lib.ovr_oracle_sample_volume(C.byref(self.s), a))
+
+    def gradient(self, p, v):
+        a = (C.c_float * 3)(*map(float, p))
+        o = (C.c_float * 3)()
+        self.lib.ovr_oracle_gradient(C.byref(self.s), a, float(v), o)
+        return np.array(o[:], dtype=np.float32)
+
+    def tfn(self, sample):
+        o = (C.c_float * 4)()
+        self.lib.ovr_oracle_sample_tfn(C.byref(self.s), float(sample), o)
+        return np.array(o[:], dtype=np.float32)
+
+    def trace(self, org, direction):
+        o = (C.c_float * 3)(*map(float, org))
+        d = (C.c_float * 3)(*map(float, direction))
+        rgba, grad, cnt = (C.c_float * 4)(), (C.c_float * 3)(), Counters()
+        self.lib.ovr_oracle_trace_ray(C.byref(self.s), o, d, rgba, grad, C.byref(cnt))
+        return np.array(rgba[:], dtype=np.float32), np.array(grad[:], dtype=np.float32), cnt
+
+
+def rgba8(rgba, flip=True):
+    lib = load()
+    rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+    h, w = rgba.shape[:2]
+    out = np.zeros((h, w, 4), dtype=np.uint8)
+    lib.ovr_oracle_rgba8(_fp(rgba), w, h, int(flip), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
+def tea_floats(v0, v1):
+    lib = load()
+    a, b = C.c_uint32(v0), C.c_uint32(v1)
+    o = (C.c_float * 2)()
+    lib.ovr_oracle_tea_floats(C.byref(a), C.byref(b), o)
+    return (o[0], o[1]), (a.value, b.value)
+
+
+def sparse_mask(frame_index, width, height, center, scale, base_noise, noise):
+    lib = load()
+    noise = np.ascontiguousarray(noise, dtype=np.float32).ravel()
+    xy = int(round((noise.size // 64) ** 0.5))
+    out = np.zeros(width * height * 2, dtype=np.int32)
+    c = (C.c_float * 2)(float(center[0]), float(center[1]))
+    n = lib.ovr_oracle_sparse_mask(out.ctypes.data_as(C.POINTER(C.c_int32)), int(frame_index), width, height, c,
+                                   float(scale), float(base_noise), _fp(noise), xy)
+    return out[:n].copy()

@@ -1,0 +1,41 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as O
+    O.load()
+    return O
+
+
+@pytest.fixture(scope="session")
+def ovr():
+    import ovr_amd
+    return ovr_amd
+
+
+@pytest.fixture(scope="session")
+def hip_renderer_factory(ovr):
+    """creates DeviceHIP instances; fails loudly (no skip, no fallback) when the library or the GPU is missing"""
+    made = []
+
+    def make():
+        r = ovr.create_renderer("hip")
+        made.append(r)
+        return r
+
+    yield make
+    for r in made:
+        r.close()
