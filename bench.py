@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the OVR ray-marching path on MI355X.
+
+Metric (BASELINE.json): Msamples/s (+ fps) on a 1024^3 float32 volume at 1920x1080, gradient shading + shadow march +
+early-ray termination (the reference's live ray marcher), frame accumulation on - the configuration the reference's own
+`renderbatch` loop measures (apps/main_batch.cpp:254-289: 5 warm-up + 25 timed blocking render() calls).
+
+A "step" is one blocking render() of one frame.  `value` counts primary marching-loop iterations ("samples")
+of all ranks per second of wall time, with the volume already resident in HBM.  With --gpus N > 1 the image plane is cut
+into tiles dealt over the ranks (one process per GPU, volume replicated) and every step ends with the gather of the
+tiles to rank 0 over RCCL - total work is fixed, so scaling is "strong".
+
+Prints ONE JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (n, dtype, width, height, shading, tf, camera, rate, spp)
+    "c2": dict(n=512, dtype="float32", width=1024, height=1024, shading=0, tf="sparse", cam="oblique", rate=1.0, spp=1,
+               workload="512^3 f32 volume, 1024x1024, absorption+emission (no shading), ERT"),
+    "c3": dict(n=1024, dtype="float32", width=1920, height=1080, shading=2, tf="sparse", cam="oblique", rate=1.0, spp=1,
+               workload="1024^3 f32 volume, 1920x1080, gradient shading + shadow march + ERT (reference ray marcher)"),
+    "c3g": dict(n=1024, dtype="float32", width=1920, height=1080, shading=1, tf="sparse", cam="oblique", rate=1.0, spp=1,
+                workload="1024^3 f32 volume, 1920x1080, gradient shading (no shadow march) + ERT"),
+    "c4": dict(n=2048, dtype="uint16", width=1920, height=1080, shading=2, tf="sparse", cam="oblique", rate=1.0, spp=1,
+               workload="2048^3 u16 volume (native u16 in HBM), 1920x1080, gradient shading + shadow march + ERT"),
+    "tiny": dict(n=64, dtype="float32", width=256, height=256, shading=2, tf="sparse", cam="oblique", rate=1.0, spp=1,
+                 workload="64^3 f32 volume, 256x256 (plumbing check, not a benchmark)"),
+}
+VOXEL_BYTES = {"float32": 4, "uint16": 2, "uint8": 1}
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def algorithmic_bytes(cfg, st, pixels, accumulate=True, grad=True):
+    """bytes the algorithm asks for, before any cache.  Every primary sample reads one trilinear tap
+    (8 voxels); a sample with non-zero opacity reads 3 more taps in the shaded modes; every shadow-march iteration reads
+    one tap; every pixel writes 16 B RGBA (+32 B accumulation read+write, +12 B gradient layer)."""
+    vb = VOXEL_BYTES[cfg["dtype"]]
+    tap = 8 * vb
+    b = st["samples"] * tap + st["shadow_samples"] * tap
+    if cfg["shading"] != 0:
+        b += st["shaded_samples"] * 3 * tap
+    b += pixels * (16 + (32 if accumulate else 0) + (12 if grad else 0))
+    return b
+
+
+def nominal_bytes(cfg, st, pixels, accumulate=True, grad=True):
+    """the same with SURVEY 8(d)'s nominal F (4 taps for EVERY primary sample in the shaded modes)"""
+    vb = VOXEL_BYTES[cfg["dtype"]]
+    tap = 8 * vb
+    f = 1 if cfg["shading"] == 0 else 4
+    return st["samples"] * f * tap + st["shadow_samples"] * tap + pixels * (16 + (32 if accumulate else 0) + (12 if grad else 0))
+
+
+def cpu_baseline(cfg, vol_host, colors, alphas, vr, cam, budget_s=20.0):
+    """The oracle (kind "port": this repo's CPU restatement of the reference's ray marcher - the reference's own CPU
+    device is OSPRay, which is not installed) timed on the host cores, on a bounded sample of the same workload:
+    the same scene rendered at 1/8 x 1/8 of the resolution (same camera and aspect: 1/64 of the rays)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    w, h = max(cfg["width"] // 8, 8), max(cfg["height"] // 8, 8)
+    sc = O.OracleScene(vol_host, colors, alphas, vr, cam, w, h, fovy=60.0, spp=cfg["spp"], rate=cfg["rate"], shading=cfg["shading"])
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    frames = 0
+    cnt = None
+    while True:
+        _, _, cnt = sc.render(frames=1, accumulate=False, nthreads=cores, want_grad=True)
+        frames += 1
+        if time.perf_counter() - t0 > budget_s * 0.5 or frames >= 3:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": cnt.samples * frames / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "fps_equivalent_full_frame": frames / dt / 64.0,
+            "sample": f"{frames} frame(s) of the same scene at {w}x{h} (1/64 of the {cfg['width']}x{cfg['height']} rays), "
+                      f"{cores} host threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=25)   # the reference's renderbatch times 25 frames ...
+    ap.add_argument("--warmup", type=int, default=5)   # ... after 5 warm-up frames (apps/main_batch.cpp:278-289)
+    ap.add_argument("--config", default=os.environ.get("OVR_BENCH_CONFIG", "c3"), choices=sorted(CONFIGS))
+    ap.add_argument("--camera", default=None, choices=["front", "oblique", "inside"])
+    ap.add_argument("--tf", default=None, choices=["sparse", "dense", "bumps"])
+    ap.add_argument("--shading", type=int, default=None, choices=[0, 1, 2])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tile", type=int, default=64)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import ovr_amd as ovr
+
+    cfg = dict(CONFIGS[args.config])
+    if args.camera:
+        cfg["cam"] = args.camera
+    if args.tf:
+        cfg["tf"] = args.tf
+    if args.shading is not None:
+        cfg["shading"] = args.shading
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    n, W, H = cfg["n"], cfg["width"], cfg["height"]
+    np_dtype = {"float32": np.float32, "uint16": np.uint16, "uint8": np.uint8}[cfg["dtype"]]
+    vol = ovr.synth.make_volume_torch(n, dev, cfg["dtype"])
+    colors, alphas, vr = ovr.synth.make_tfn(cfg["tf"], 1024, np_dtype)
+    cam = ovr.synth.make_camera(cfg["cam"], n)
+
+    ren = ovr.create_renderer("hip", local_rank)
+    # the call sequence of the reference's renderbatch (apps/main_batch.cpp:254-276)
+    ren.set_fbsize((W, H))
+    ren.set_frame_accumulation(True)
+    ren.set_sample_per_pixel(cfg["spp"])
+    ren.set_volume_sampling_rate(cfg["rate"])
+    ren.set_shading(cfg["shading"])
+    ren.set_transfer_function(colors, alphas, vr)
+    if world > 1:
+        ren.set_image_shard(rank, world, args.tile, args.tile)
+    scene = ovr.Scene(volume=vol, transfer_function=None, volume_sampling_rate=cfg["rate"])
+    ren.init(scene, ovr.Camera(*cam))
+    ren.set_camera(*cam)  # fovy 60, as renderbatch ends up with (renderer.h:149-152)
+    ren.set_sparse_sampling(False)
+    ren.commit()
+    vol_host = None
+    if rank == 0 and not args.no_cpu_baseline:
+        vol_host = vol.cpu().numpy() if cfg["dtype"] != "uint16" or hasattr(torch, "uint16") else vol.cpu().numpy().view(np.uint16)
+    del vol
+    torch.cuda.empty_cache()
+
+    payload = frame = None
+    if world > 1:
+        slots = ovr.tiles.max_owned_tiles(W, H, args.tile, args.tile, world)
+        payload = torch.zeros((slots, args.tile, args.tile, 4), dtype=torch.float32, device=dev)
+        frame = torch.zeros((H, W, 4), dtype=torch.float32, device=dev) if rank == 0 else None
+        import ctypes as C
+
+        def unpack(src, buf):
+            ovr._lib.check(ren._lib.ovr_hip_unpack_tiles(ren._h, src, C.c_void_p(buf.data_ptr()), buf.numel() * 4,
+                                                         C.c_void_p(frame.data_ptr()), frame.numel() * 4))
+
+    def step():
+        ren.render()
+        if world > 1:
+            import ctypes as C
+            ovr._lib.check(ren._lib.ovr_hip_pack_tiles(ren._h, C.c_void_p(payload.data_ptr()), payload.numel() * 4))
+            ren.sync()
+            torch.cuda.synchronize()
+            ovr.tiles.gather_frame(payload, W, H, args.tile, args.tile, rank, world, unpack if rank == 0 else None)
+            if rank == 0:
+                ren.sync()
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    tot = dict(samples=0, shaded_samples=0, shadow_samples=0, rays=0, active_pixels=0)
+    kernel_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        st = ren.stats()
+        for k in tot:
+            tot[k] += getattr(st, k)
+        kernel_ms += st.kernel_ms
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+
+    # max over ranks of the elapsed time, sum over ranks of the work
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        w = torch.tensor([tot[k] for k in sorted(tot)] + [kernel_ms], dtype=torch.float64, device=dev)
+        wmax = w.clone()
+        dist.all_reduce(w, op=dist.ReduceOp.SUM)
+        dist.all_reduce(wmax, op=dist.ReduceOp.MAX)
+        for i, k in enumerate(sorted(tot)):
+            tot[k] = int(w[i].item())
+        kernel_ms_max = float(wmax[-1].item())
+    else:
+        kernel_ms_max = kernel_ms
+
+    if rank == 0:
+        steps = args.steps
+        per_step = {k: v / steps for k, v in tot.items()}
+        # roofline of the dominant kernel (raymarch_kernel): algorithmic bytes per launch / mean launch duration
+        # (HIP events recorded on the renderer's own stream around the launch, inside libovr_hip.so)
+        k_ms = kernel_ms_max / steps
+        pixels_per_launch = per_step["active_pixels"] / world
+        per_launch = {k: v / world for k, v in per_step.items()}
+        abytes = algorithmic_bytes(cfg, per_launch, pixels_per_launch)
+        nbytes = nominal_bytes(cfg, per_launch, pixels_per_launch)
+        achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "Msamples/s (primary ray-march samples after ERT); fps alongside",
+            "value": tot["samples"] / dt / 1e6,
+            "unit": "Msamples/s",
+            "fps": steps / dt,
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": cfg["workload"], "name": args.config, "volume": f"{n}^3 {cfg['dtype']}", "image": f"{W}x{H}",
+                       "transfer_function": cfg["tf"], "camera": cfg["cam"], "fovy": 60, "sampling_rate": cfg["rate"],
+                       "spp": cfg["spp"], "shading": ["none", "gradient", "gradient+shadow"][cfg["shading"]],
+                       "frame_accumulation": True, "parallelism": f"image tiles {args.tile}x{args.tile} over {world} rank(s)"},
+            "per_frame": {k: per_step[k] for k in sorted(per_step)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "raymarch_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes,
+                         "nominal_frac_survey_F4": (nbytes / (k_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if k_ms > 0 else 0.0},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, vol_host, colors, alphas, vr, cam)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ren.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -144,6 +144,7 @@ struct ovr_hip_renderer {
 
   // counters
   unsigned long long* d_counters = nullptr;
+  unsigned int* d_block_counters = nullptr; // per-workgroup partial counters
   unsigned long long* h_counters = nullptr; // pinned
 
   RayMarchParams P{};
@@ -169,6 +170,8 @@ int free_framebuffers(ovr_hip_renderer* r)
   }
   if (r->d_accum) HIP_TRY(hipFree(r->d_accum));
   r->d_accum = nullptr;
+  if (r->d_block_counters) HIP_TRY(hipFree(r->d_block_counters));
+  r->d_block_counters = nullptr;
   if (r->d_sparse_xy) HIP_TRY(hipFree(r->d_sparse_xy));
   if (r->d_block_counts) HIP_TRY(hipFree(r->d_block_counts));
   r->d_sparse_xy = nullptr;
@@ -191,6 +194,8 @@ int resize_framebuffers(ovr_hip_renderer* r, int w, int h)
   }
   HIP_TRY(hipMalloc((void**)&r->d_accum, n * 4 * sizeof(float)));
   HIP_TRY(hipMemset(r->d_accum, 0, n * 4 * sizeof(float)));
+  const size_t nblk = std::max<size_t>((size_t)((w + 15) / 16) * (size_t)((h + 15) / 16), (n + 255) / 256) + 1;
+  HIP_TRY(hipMalloc((void**)&r->d_block_counters, nblk * 5 * sizeof(unsigned int)));
   r->fb_pixels = n;
   return 0;
 }
@@ -328,6 +333,8 @@ int enqueue_frame(ovr_hip_renderer* r)
 {
   if (!r->have_volume) return fail(OVR_HIP_ESTATE, "[hip] render() called before a volume was set");
   if (!r->have_tfn) return fail(OVR_HIP_ESTATE, "[hip] render() called before a transfer function was set");
+  if (raymarch_lds_bytes(r->n_color, r->n_alpha) == 0)
+    return fail(OVR_HIP_EINVAL, "[hip] transfer function too large for LDS staging (colour + alpha tables must fit in 96 KiB)");
   const int W = r->fbsize.current.w, H = r->fbsize.current.h;
   if (W <= 0 || H <= 0) return 0; // device_impl.cpp:216-217
   hipStream_t st = r->stream();
@@ -377,9 +384,9 @@ int enqueue_frame(ovr_hip_renderer* r)
   P.tile_w = r->shard.current.tw;
   P.tile_h = r->shard.current.th;
   P.counters = r->d_counters;
+  P.block_counters = r->d_block_counters;
   P.sparse_xy = nullptr;
   P.sparse_count = nullptr;
-  HIP_TRY(hipMemsetAsync(r->d_counters, 0, 8 * sizeof(unsigned long long), st));
   if (sparse) { // createSparseSamples, device_impl.cpp:304-342
     if (!r->d_noise) return fail(OVR_HIP_ESTATE, "[hip] sparse sampling enabled but no noise tile was set (ovr_hip_set_noise_tile)");
     if (int e = ensure_sparse_buffers(r)) return e;
@@ -498,20 +505,19 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
   vd.type = vt;
   vd.nx = dims[0]; vd.ny = dims[1]; vd.nz = dims[2];
   const size_t es = voxel_size(vt);
-  const size_t align_elems = 64 / es; // rows start on 64-byte boundaries
-  vd.row_stride = (int)((((size_t)vd.nx + 1 + align_elems - 1) / align_elems) * align_elems);
-  vd.tiles_y = (vd.ny + 7) / 8;
-  vd.tiles_z = (vd.nz + 7) / 8;
+  vd.macros_x = (vd.nx + 31) / 32;
+  vd.macros_y = (vd.ny + 31) / 32;
+  vd.macros_z = (vd.nz + 31) / 32;
   vd.value_scale = 1.f;
   vd.value_min_clamp = -FLT_MAX;
   if (vt == VOX_U8) vd.value_scale = 1.f / 255.f;
   if (vt == VOX_I8) { vd.value_scale = 1.f / 127.f; vd.value_min_clamp = -127.f; }
-  const size_t rows = (size_t)vd.tiles_y * vd.tiles_z * 64;
-  const size_t bytes = rows * (size_t)vd.row_stride * es + 64; // + slack for the pair load of the very last element
+  const size_t bytes = (size_t)vd.macros_x * vd.macros_y * vd.macros_z * 32768 * es;
+  vd.bytes = bytes;
 
   if (r->d_volume) { HIP_TRY(hipFree(r->d_volume)); r->d_volume = nullptr; }
   HIP_TRY(hipMalloc(&r->d_volume, bytes));
-  HIP_TRY(hipMemset(r->d_volume, 0, bytes));
+  if (((vd.nx | vd.ny | vd.nz) & 31) != 0) HIP_TRY(hipMemset(r->d_volume, 0, bytes)); // padding voxels are never sampled
   r->volume_bytes = bytes;
   vd.data = r->d_volume;
 

@@ -11,12 +11,13 @@
 //
 // Kernel shape: one lane per pixel, one wave64 per 8x8 pixel tile, four waves (16x16 pixels) per workgroup.  The
 // transfer function (colour float4 table + alpha table, 20 KiB at the shipped resolution of 1024) is staged in LDS
-// once per workgroup; the volume is read from the yz-tiled row layout described in ovr_hip_kernels.h with one
-// 8-byte load per (y,z) row of a trilinear tap.  Built with -ffp-contract=off: every fused multiply-add below is
+// once per workgroup; the volume is read from the bricked layout described in ovr_hip_kernels.h (one 128-byte
+// line = one 3-D brick).  Built with -ffp-contract=off: every fused multiply-add below is
 // explicit so the operation order is the one the CPU oracle (oracle/ovr_oracle.c) restates.
 #include "ovr_hip_kernels.h"
 
 #include <float.h>
+#include <algorithm>
 
 namespace ovrhip {
 
@@ -53,66 +54,62 @@ __device__ __forceinline__ float opacity_correction(float a, float adj)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// voxel access: one load returns the two x-neighbours of a row
+// voxel access.  Volume layout in HBM: 128-byte bricks inside 32^3-voxel macro blocks (see ovr_hip_kernels.h).
+// One L1/L2 line is one brick (f32: 4x4x2 voxels, u16/i16: 4x4x4, u8/i8: 8x4x4), so the 2x2x2 footprint of a tap
+// touches ~2.3 lines whatever the ray direction, and the 16x16-voxel sheet a wave samples per step ~50.
+// The element offset is separable: off(x,y,z) = X(x) + Y(y) + Z(z).
 // ------------------------------------------------------------------------------------------------------------------
-typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
-typedef unsigned short u16x2_u __attribute__((ext_vector_type(2), aligned(2)));
-typedef short i16x2_u __attribute__((ext_vector_type(2), aligned(2)));
-typedef unsigned char u8x2_u __attribute__((ext_vector_type(2), aligned(1)));
-typedef signed char i8x2_u __attribute__((ext_vector_type(2), aligned(1)));
-
 template <int VT> struct Vox;
 template <> struct Vox<VOX_F32> {
-  static __device__ __forceinline__ void pair(const void* base, unsigned long long off, float& a, float& b)
-  {
-    const f32x2_u v = *reinterpret_cast<const f32x2_u*>(static_cast<const float*>(base) + off);
-    a = v.x; b = v.y;
-  }
-  static constexpr bool kScale = false;
-  static constexpr bool kClamp = false;
+  typedef float T;
+  static constexpr int bx = 2, by = 2, bz = 1;
+  static constexpr bool kScale = false, kClamp = false;
 };
 template <> struct Vox<VOX_U16> {
-  static __device__ __forceinline__ void pair(const void* base, unsigned long long off, float& a, float& b)
-  {
-    const u16x2_u v = *reinterpret_cast<const u16x2_u*>(static_cast<const unsigned short*>(base) + off);
-    a = (float)v.x; b = (float)v.y;
-  }
-  static constexpr bool kScale = false; // u16 is sampled as RAW float (array.cpp:335-338)
-  static constexpr bool kClamp = false;
+  typedef unsigned short T;
+  static constexpr int bx = 2, by = 2, bz = 2;
+  static constexpr bool kScale = false, kClamp = false; // u16 is sampled as RAW float (array.cpp:335-338)
 };
 template <> struct Vox<VOX_I16> {
-  static __device__ __forceinline__ void pair(const void* base, unsigned long long off, float& a, float& b)
-  {
-    const i16x2_u v = *reinterpret_cast<const i16x2_u*>(static_cast<const short*>(base) + off);
-    a = (float)v.x; b = (float)v.y;
-  }
-  static constexpr bool kScale = false;
-  static constexpr bool kClamp = false;
+  typedef short T;
+  static constexpr int bx = 2, by = 2, bz = 2;
+  static constexpr bool kScale = false, kClamp = false;
 };
 template <> struct Vox<VOX_U8> {
-  static __device__ __forceinline__ void pair(const void* base, unsigned long long off, float& a, float& b)
-  {
-    const u8x2_u v = *reinterpret_cast<const u8x2_u*>(static_cast<const unsigned char*>(base) + off);
-    a = (float)v.x; b = (float)v.y;
-  }
-  static constexpr bool kScale = true; // normalized read: v / 255 (array.cpp:304-306)
-  static constexpr bool kClamp = false;
+  typedef unsigned char T;
+  static constexpr int bx = 3, by = 2, bz = 2;
+  static constexpr bool kScale = true, kClamp = false; // normalized read: v / 255 (array.cpp:304-306)
 };
 template <> struct Vox<VOX_I8> {
-  static __device__ __forceinline__ void pair(const void* base, unsigned long long off, float& a, float& b)
+  typedef signed char T;
+  static constexpr int bx = 3, by = 2, bz = 2;
+  static constexpr bool kScale = true, kClamp = true; // max(v / 127, -1)
+};
+
+template <int VT> struct BrickMap {
+  typedef Vox<VT> V;
+  static constexpr unsigned BV = 1u << (V::bx + V::by + V::bz); // voxels per brick (128 bytes)
+  static constexpr unsigned MV = 32768u;                         // voxels per 32^3 macro block
+  static constexpr unsigned sbx = BV, sby = (32u >> V::bx) * BV, sbz = (32u >> V::bx) * (32u >> V::by) * BV;
+  static __host__ __device__ __forceinline__ unsigned X(unsigned x)
   {
-    const i8x2_u v = *reinterpret_cast<const i8x2_u*>(static_cast<const signed char*>(base) + off);
-    a = (float)v.x; b = (float)v.y;
+    return (x & ((1u << V::bx) - 1u)) + ((x >> V::bx) & ((32u >> V::bx) - 1u)) * sbx + (x >> 5) * MV;
   }
-  static constexpr bool kScale = true; // max(v / 127, -1)
-  static constexpr bool kClamp = true;
+  static __host__ __device__ __forceinline__ unsigned Y(unsigned y, unsigned macro_y_stride)
+  {
+    return ((y & ((1u << V::by) - 1u)) << V::bx) + ((y >> V::by) & ((32u >> V::by) - 1u)) * sby + (y >> 5) * macro_y_stride;
+  }
+  static __host__ __device__ __forceinline__ unsigned Zlo(unsigned z)
+  {
+    return ((z & ((1u << V::bz) - 1u)) << (V::bx + V::by)) + ((z >> V::bz) & ((32u >> V::bz) - 1u)) * sbz;
+  }
 };
 
 struct VolConsts {
   const void* data;
   int nx1, ny1, nz1; // n - 1
-  unsigned int row_stride;
-  int tile_row_z;    // tiles_y * 64
+  unsigned int macro_y;          // elements between macro rows: 32768 * macros_x
+  unsigned long long macro_z;    // elements between macro layers: 32768 * macros_x * macros_y
   float fx1, fy1, fz1;
   f3 cs, cb;
   float vscale, vmin;
@@ -122,46 +119,69 @@ __device__ __forceinline__ void axis_tap(float po, float cs, float cb, float fn1
 {
   const float p = clamp01(po);                       // sample_volume_object_space clamps p to [0,1]
   float x = fmaf(p, cs, cb);                         // cell-centred: p*N - 0.5
-  x = fminf(fmaxf(x, 0.f), fn1);                     // == clamp-to-edge addressing (row pad replicates the last voxel)
+  x = fminf(fmaxf(x, 0.f), fn1);                     // == clamp-to-edge addressing: taps (i0, min(i0+1, n-1))
   const float fl = floorf(x);
   f = x - fl;
   i0 = (int)fl;
   i1 = min(i0 + 1, n1);
 }
-__device__ __forceinline__ int row_y(int y) { return ((y >> 3) << 6) + (y & 7); }
-__device__ __forceinline__ int row_z(int z, int tile_row_z) { return (z >> 3) * tile_row_z + ((z & 7) << 3); }
 
-// trilinear tap at object-space p (shaders_common.h:186-193); returns what tex3D<float> returns
-template <int VT>
-__device__ __forceinline__ float sample_volume(const VolConsts& vc, f3 p)
-{
-  int x0, x1, y0, y1, z0, z1;
+// One trilinear tap, split in two so that several taps can be in flight before the first is consumed
+// (software pipelining: the march is latency-bound otherwise).  issue: 8 voxel loads; finish: 7 lerps.
+struct Tap {
+  float c000, c100, c010, c110, c001, c101, c011, c111;
   float fx, fy, fz;
-  axis_tap(p.x, vc.cs.x, vc.cb.x, vc.fx1, vc.nx1, x0, x1, fx);
-  axis_tap(p.y, vc.cs.y, vc.cb.y, vc.fy1, vc.ny1, y0, y1, fy);
-  axis_tap(p.z, vc.cs.z, vc.cb.z, vc.fz1, vc.nz1, z0, z1, fz);
-  (void)x1;
-  const int ry0 = row_y(y0), ry1 = row_y(y1);
-  const int rz0 = row_z(z0, vc.tile_row_z), rz1 = row_z(z1, vc.tile_row_z);
-  const unsigned long long o00 = (unsigned long long)(unsigned int)(ry0 + rz0) * vc.row_stride + (unsigned int)x0;
-  const unsigned long long o10 = (unsigned long long)(unsigned int)(ry1 + rz0) * vc.row_stride + (unsigned int)x0;
-  const unsigned long long o01 = (unsigned long long)(unsigned int)(ry0 + rz1) * vc.row_stride + (unsigned int)x0;
-  const unsigned long long o11 = (unsigned long long)(unsigned int)(ry1 + rz1) * vc.row_stride + (unsigned int)x0;
-  float a00, b00, a10, b10, a01, b01, a11, b11;
-  Vox<VT>::pair(vc.data, o00, a00, b00);
-  Vox<VT>::pair(vc.data, o10, a10, b10);
-  Vox<VT>::pair(vc.data, o01, a01, b01);
-  Vox<VT>::pair(vc.data, o11, a11, b11);
-  if (Vox<VT>::kClamp) {
-    a00 = fmaxf(a00, vc.vmin); b00 = fmaxf(b00, vc.vmin); a10 = fmaxf(a10, vc.vmin); b10 = fmaxf(b10, vc.vmin);
-    a01 = fmaxf(a01, vc.vmin); b01 = fmaxf(b01, vc.vmin); a11 = fmaxf(a11, vc.vmin); b11 = fmaxf(b11, vc.vmin);
+};
+
+template <int VT, bool BIG>
+__device__ __forceinline__ void tap_issue(const VolConsts& vc, f3 p, Tap& t)
+{
+  typedef BrickMap<VT> M;
+  typedef typename Vox<VT>::T T;
+  int x0, x1, y0, y1, z0, z1;
+  axis_tap(p.x, vc.cs.x, vc.cb.x, vc.fx1, vc.nx1, x0, x1, t.fx);
+  axis_tap(p.y, vc.cs.y, vc.cb.y, vc.fy1, vc.ny1, y0, y1, t.fy);
+  axis_tap(p.z, vc.cs.z, vc.cb.z, vc.fz1, vc.nz1, z0, z1, t.fz);
+  const unsigned ox0 = M::X((unsigned)x0), ox1 = M::X((unsigned)x1);
+  const unsigned oy0 = M::Y((unsigned)y0, vc.macro_y), oy1 = M::Y((unsigned)y1, vc.macro_y);
+  const unsigned o00 = ox0 + oy0, o10 = ox1 + oy0, o01 = ox0 + oy1, o11 = ox1 + oy1;
+  const T* base = static_cast<const T*>(vc.data);
+  if (BIG) {
+    const unsigned long long oz0 = (unsigned long long)M::Zlo((unsigned)z0) + (unsigned long long)((unsigned)z0 >> 5) * vc.macro_z;
+    const unsigned long long oz1 = (unsigned long long)M::Zlo((unsigned)z1) + (unsigned long long)((unsigned)z1 >> 5) * vc.macro_z;
+    t.c000 = (float)base[oz0 + o00]; t.c100 = (float)base[oz0 + o10]; t.c010 = (float)base[oz0 + o01]; t.c110 = (float)base[oz0 + o11];
+    t.c001 = (float)base[oz1 + o00]; t.c101 = (float)base[oz1 + o10]; t.c011 = (float)base[oz1 + o01]; t.c111 = (float)base[oz1 + o11];
   }
-  const float c00 = lerpf(a00, b00, fx), c10 = lerpf(a10, b10, fx);
-  const float c01 = lerpf(a01, b01, fx), c11 = lerpf(a11, b11, fx);
-  const float c0 = lerpf(c00, c10, fy), c1 = lerpf(c01, c11, fy);
-  float s = lerpf(c0, c1, fz);
+  else { // the whole volume is < 4 GiB: 32-bit offsets, loads use the SGPR-base + VGPR-offset form
+    const unsigned oz0 = M::Zlo((unsigned)z0) + ((unsigned)z0 >> 5) * (unsigned)vc.macro_z;
+    const unsigned oz1 = M::Zlo((unsigned)z1) + ((unsigned)z1 >> 5) * (unsigned)vc.macro_z;
+    t.c000 = (float)base[oz0 + o00]; t.c100 = (float)base[oz0 + o10]; t.c010 = (float)base[oz0 + o01]; t.c110 = (float)base[oz0 + o11];
+    t.c001 = (float)base[oz1 + o00]; t.c101 = (float)base[oz1 + o10]; t.c011 = (float)base[oz1 + o01]; t.c111 = (float)base[oz1 + o11];
+  }
+}
+
+template <int VT>
+__device__ __forceinline__ float tap_finish(const VolConsts& vc, Tap t)
+{
+  if (Vox<VT>::kClamp) {
+    t.c000 = fmaxf(t.c000, vc.vmin); t.c100 = fmaxf(t.c100, vc.vmin); t.c010 = fmaxf(t.c010, vc.vmin); t.c110 = fmaxf(t.c110, vc.vmin);
+    t.c001 = fmaxf(t.c001, vc.vmin); t.c101 = fmaxf(t.c101, vc.vmin); t.c011 = fmaxf(t.c011, vc.vmin); t.c111 = fmaxf(t.c111, vc.vmin);
+  }
+  const float c00 = lerpf(t.c000, t.c100, t.fx), c10 = lerpf(t.c010, t.c110, t.fx);
+  const float c01 = lerpf(t.c001, t.c101, t.fx), c11 = lerpf(t.c011, t.c111, t.fx);
+  const float c0 = lerpf(c00, c10, t.fy), c1 = lerpf(c01, c11, t.fy);
+  float s = lerpf(c0, c1, t.fz);
   if (Vox<VT>::kScale) s *= vc.vscale;
   return s;
+}
+
+// trilinear tap at object-space p (shaders_common.h:186-193); returns what tex3D<float> returns
+template <int VT, bool BIG>
+__device__ __forceinline__ float sample_volume(const VolConsts& vc, f3 p)
+{
+  Tap t;
+  tap_issue<VT, BIG>(vc, p, t);
+  return tap_finish<VT>(vc, t);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -240,8 +260,10 @@ __device__ __forceinline__ f3 to_object(const MarchConsts& mc, f3 p)
   return mk3(fmaf(p.x, mc.inv_scale.x, mc.wto_p.x), fmaf(p.y, mc.inv_scale.y, mc.wto_p.y), fmaf(p.z, mc.inv_scale.z, mc.wto_p.z));
 }
 
-// raymarching_shadow, shaders_raymarching.cu:44-85 (+ :205-229): alpha-only march toward the light
-template <int VT>
+// raymarching_shadow, shaders_raymarching.cu:44-85 (+ :205-229): alpha-only march toward the light.
+// KS taps are issued before the first one is consumed; taps past the end of the march or past the early-termination
+// point are speculative (their coordinates are clamped, so the loads are always in bounds) and simply dropped.
+template <int VT, bool BIG, int KS>
 __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConsts& tf, const MarchConsts& mc, f3 org, unsigned int& n_shadow)
 {
   const f3 oo = to_object(mc, org);
@@ -250,33 +272,91 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
   float alpha = 0.f;
   if (!intersect_unit_box(t0, t1, oo, od)) return alpha;
   float tx = t0, ty = fminf(t1, t0 + mc.shadow_stride);
-  while ((ty > tx) && (alpha < 0.9999f)) {
-    const float tm = 0.5f * (tx + ty);
-    const f3 pos = mk3(fmaf(tm, mc.light.x, org.x), fmaf(tm, mc.light.y, org.y), fmaf(tm, mc.light.z, org.z));
-    const float s = sample_volume<VT>(vc, to_object(mc, pos));
-    float a = tf_alpha(tf, tf_coord(tf, s));
-    a = opacity_correction(a, mc.base * (ty - tx));
-    alpha = fmaf(1.f - alpha, a, alpha);
-    ++n_shadow;
-    tx = ty;
-    ty = fminf(tx + mc.shadow_stride, t1);
+  bool live = true;
+  while (live) {
+    Tap taps[KS];
+    float dts[KS];
+    bool valid[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      valid[k] = ty > tx;
+      dts[k] = ty - tx;
+      const float tm = 0.5f * (tx + ty);
+      const f3 pos = mk3(fmaf(tm, mc.light.x, org.x), fmaf(tm, mc.light.y, org.y), fmaf(tm, mc.light.z, org.z));
+      tap_issue<VT, BIG>(vc, to_object(mc, pos), taps[k]);
+      tx = ty;
+      ty = fminf(tx + mc.shadow_stride, t1);
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      if (live && valid[k] && (alpha < 0.9999f)) {
+        const float s = tap_finish<VT>(vc, taps[k]);
+        float a = tf_alpha(tf, tf_coord(tf, s));
+        a = opacity_correction(a, mc.base * dts[k]);
+        alpha = fmaf(1.f - alpha, a, alpha);
+        ++n_shadow;
+      }
+      else {
+        live = false;
+      }
+    }
   }
   return alpha;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // the ray-march kernel
+//
+// Work decomposition: one lane per pixel, one wave64 per 8x8 pixel tile, four waves per workgroup.
+//  * primary march: K samples per round, all their row loads in flight before the first is consumed.
+//  * deferred, compacted shading (SHADE != 0): a sample whose opacity is > 0 is not shaded by its own lane; the lane
+//    pushes a 32-byte request into its wave's queue in LDS (slot = tail + prefix-of-ballot, v_mbcnt) and keeps
+//    marching - alpha does not depend on shading, so early termination is unaffected.  Whenever 64 requests are
+//    queued the whole wave shades them, one request per lane (gradient taps, normals, shadow march toward the
+//    light - the expensive, otherwise badly divergent part), and hands the colour contributions back to the owning
+//    lanes with ds_bpermute.  Each owner applies its contributions in sample order (requests of one lane form a
+//    linked list through the queue), so the result is bit-identical to shading in place.
+//  * counters: per-workgroup partial sums, reduced by a second tiny kernel (no same-address atomics).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
 
-template <int VT, int SHADE, bool TF_LDS>
+template <int SHADE> struct MarchCfg;
+template <> struct MarchCfg<0> { static constexpr int K = 4, QCAP = 0, KS = 1; };
+template <> struct MarchCfg<1> { static constexpr int K = 3, QCAP = 256, KS = 1; };
+template <> struct MarchCfg<2> { static constexpr int K = 3, QCAP = 256, KS = 4; };
+
+struct ShadeReq { // 32 bytes
+  float px, py, pz; // world-space sample position
+  float s;          // sample value
+  float v;          // transfer-function coordinate
+  float tr;         // transmittance before the sample
+  float a;          // corrected opacity
+  int next;         // absolute queue position of the owner's next request (valid once that request exists)
+};
+
+__device__ __forceinline__ float bperm(int src_lane, float x)
+{
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(x)));
+}
+__device__ __forceinline__ int bperm_i(int src_lane, int x) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, x); }
+
+template <int VT, int SHADE, bool BIG>
 __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P)
 {
+  using Cfg = MarchCfg<SHADE>;
+  constexpr int K = Cfg::K;
+  constexpr int QCAP = Cfg::QCAP;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  // ---- LDS carve: [request queues][TF colour][TF alpha]
+  ShadeReq* const queue = reinterpret_cast<ShadeReq*>(lds_raw) + (size_t)wave * (QCAP > 0 ? QCAP : 1);
+  unsigned char* const tf_base = lds_raw + (size_t)kWaves * QCAP * sizeof(ShadeReq);
   TfConsts tf;
-  if (TF_LDS) {
-    float4* lc = reinterpret_cast<float4*>(lds_raw);
-    float* la = reinterpret_cast<float*>(lds_raw + (size_t)P.n_color * sizeof(float4));
+  {
+    float4* lc = reinterpret_cast<float4*>(tf_base);
+    float* la = reinterpret_cast<float*>(tf_base + (size_t)P.n_color * sizeof(float4));
     const float4* gc = reinterpret_cast<const float4*>(P.tf_color);
     for (int i = threadIdx.x; i < P.n_color; i += kBlock) lc[i] = gc[i];
     for (int i = threadIdx.x; i < P.n_alpha; i += kBlock) la[i] = P.tf_alpha[i];
@@ -284,16 +364,11 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
     tf.color = lc;
     tf.alpha = la;
   }
-  else {
-    tf.color = reinterpret_cast<const float4*>(P.tf_color);
-    tf.alpha = P.tf_alpha;
-  }
   tf.nc1 = P.n_color - 1; tf.na1 = P.n_alpha - 1;
   tf.fnc1 = (float)tf.nc1; tf.fna1 = (float)tf.na1;
   tf.lower = P.tf_lower; tf.upper = P.tf_upper; tf.scale = P.tf_scale;
 
   // ---- which pixel does this lane own? (compute_screen_position, shaders_common.h:394-451)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int ix, iy;
   bool active;
   if (P.sparse_xy) {
@@ -303,125 +378,210 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
     iy = active ? P.sparse_xy[2 * i + 1] : 0;
   }
   else {
-    const int bx = blockIdx.x, by = blockIdx.y;
-    ix = bx * 16 + (wave & 1) * 8 + (lane & 7);
-    iy = by * 16 + (wave >> 1) * 8 + (lane >> 3);
+    ix = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    iy = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
     active = ix < P.width && iy < P.height;
   }
   if (P.world > 1 && active) active = ((ix / P.tile_w + iy / P.tile_h) % P.world) == P.rank;
 
   unsigned int n_rays = 0, n_samples = 0, n_shaded = 0, n_shadow = 0;
 
-  if (active) {
-    VolConsts vc;
-    vc.data = P.vol.data;
-    vc.nx1 = P.vol.nx - 1; vc.ny1 = P.vol.ny - 1; vc.nz1 = P.vol.nz - 1;
-    vc.fx1 = (float)vc.nx1; vc.fy1 = (float)vc.ny1; vc.fz1 = (float)vc.nz1;
-    vc.row_stride = (unsigned int)P.vol.row_stride;
-    vc.tile_row_z = P.vol.tiles_y * 64;
-    vc.cs = ld3(P.coord_scale); vc.cb = ld3(P.coord_bias);
-    vc.vscale = P.vol.value_scale; vc.vmin = P.vol.value_min_clamp;
-    MarchConsts mc;
-    mc.inv_scale = ld3(P.inv_scale); mc.wto_p = ld3(P.wto_p); mc.otw_it = ld3(P.otw_it); mc.light = ld3(P.light);
-    mc.gstep = ld3(P.grad_step);
-    mc.ginv = mk3(1.f / mc.gstep.x, 1.f / mc.gstep.y, 1.f / mc.gstep.z);
-    mc.step = P.step; mc.base = P.base; mc.shadow_stride = P.shadow_stride;
+  VolConsts vc;
+  vc.data = P.vol.data;
+  vc.nx1 = P.vol.nx - 1; vc.ny1 = P.vol.ny - 1; vc.nz1 = P.vol.nz - 1;
+  vc.fx1 = (float)vc.nx1; vc.fy1 = (float)vc.ny1; vc.fz1 = (float)vc.nz1;
+  vc.macro_y = 32768u * (unsigned int)P.vol.macros_x;
+  vc.macro_z = 32768ull * (unsigned long long)P.vol.macros_x * (unsigned long long)P.vol.macros_y;
+  vc.cs = ld3(P.coord_scale); vc.cb = ld3(P.coord_bias);
+  vc.vscale = P.vol.value_scale; vc.vmin = P.vol.value_min_clamp;
+  MarchConsts mc;
+  mc.inv_scale = ld3(P.inv_scale); mc.wto_p = ld3(P.wto_p); mc.otw_it = ld3(P.otw_it); mc.light = ld3(P.light);
+  mc.gstep = ld3(P.grad_step);
+  mc.ginv = mk3(1.f / mc.gstep.x, 1.f / mc.gstep.y, 1.f / mc.gstep.z);
+  mc.step = P.step; mc.base = P.base; mc.shadow_stride = P.shadow_stride;
 
-    const float rsx = 1.f / (float)P.width, rsy = 1.f / (float)P.height;
-    const float scx = ((float)ix + .5f) * rsx, scy = ((float)iy + .5f) * rsy;
-    const unsigned int pixel_index = (unsigned int)ix + (unsigned int)iy * (unsigned int)P.width;
-    unsigned int v0 = (unsigned int)P.frame_index, v1 = pixel_index; // RandomTEA(frame_index, pixel_index)
-    const f3 org = ld3(P.cam_pos), cdir = ld3(P.cam_dir), chor = ld3(P.cam_hor), cver = ld3(P.cam_ver);
+  const float rsx = 1.f / (float)P.width, rsy = 1.f / (float)P.height;
+  const float scx = ((float)ix + .5f) * rsx, scy = ((float)iy + .5f) * rsy;
+  const unsigned int pixel_index = (unsigned int)ix + (unsigned int)iy * (unsigned int)P.width;
+  unsigned int v0 = (unsigned int)P.frame_index, v1 = pixel_index; // RandomTEA(frame_index, pixel_index)
+  const f3 org = ld3(P.cam_pos), cdir = ld3(P.cam_dir), chor = ld3(P.cam_hor), cver = ld3(P.cam_ver);
+  const f3 oo = to_object(mc, org);
 
-    float o_a = 0.f;
-    f3 o_c = mk3(0, 0, 0), o_g = mk3(0, 0, 0);
-    const int spp = P.spp;
-    for (int k = 0; k < spp; ++k) {
-      float sx = scx, sy = scy;
-      if (spp > 1) {
-        tea16(v0, v1);
-        sx += ((float)v0 * OVR_TEA_TOFLOAT - 0.5f) * rsx;
-        sy += ((float)v1 * OVR_TEA_TOFLOAT - 0.5f) * rsy;
+  float o_a = 0.f;
+  f3 o_c = mk3(0, 0, 0), o_g = mk3(0, 0, 0);
+  const int spp = P.spp;
+  // wave-uniform queue cursors (absolute positions; slot = position & (QCAP - 1))
+  unsigned int q_head = 0, q_tail = 0;
+
+  for (int k_spp = 0; k_spp < spp; ++k_spp) { // uniform trip count: every lane of the wave runs every round
+    float sx = scx, sy = scy;
+    if (spp > 1) {
+      tea16(v0, v1);
+      sx += ((float)v0 * OVR_TEA_TOFLOAT - 0.5f) * rsx;
+      sy += ((float)v1 * OVR_TEA_TOFLOAT - 0.5f) * rsy;
+    }
+    const float ux = sx - 0.5f, uy = sy - 0.5f;
+    const f3 dir = normalize3_exact(mk3(cdir.x + ux * chor.x + uy * cver.x, cdir.y + ux * chor.y + uy * cver.y,
+                                        cdir.z + ux * chor.z + uy * cver.z));
+    // ---- __intersection__volume: object-space ray, direction not renormalised so t is shared
+    const f3 od = mk3(dir.x * mc.inv_scale.x, dir.y * mc.inv_scale.y, dir.z * mc.inv_scale.z);
+    float t0 = 0.f, t1 = FLT_MAX;
+    float alpha = 0.f;
+    f3 color = mk3(0, 0, 0), gradient = mk3(0, 0, 0);
+    bool live = active && intersect_unit_box(t0, t1, oo, od);
+    if (active) ++n_rays;
+    float tx = t0, ty = fminf(t1, t0 + mc.step);
+    int pend = 0;                 // this lane's requests not yet applied
+    unsigned int first = 0, last = 0; // absolute queue positions of its oldest unapplied / newest request
+
+    for (;;) {
+      // ---- (1) shade queued requests: a full batch whenever 64 are queued, the remainder once no ray is live
+      if (SHADE != 0) {
+        const bool any_live = __ballot(live) != 0ull;
+        while ((q_tail - q_head) >= 64u || (!any_live && q_tail != q_head)) {
+          const unsigned int n = min(q_tail - q_head, 64u);
+          const bool worker = (unsigned int)lane < n;
+          float cx = 0.f, cy = 0.f, cz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, ra = 0.f;
+          int rnext = 0;
+          __builtin_amdgcn_wave_barrier(); // requests were written by other lanes of this wave (LDS ops are in order)
+          if (worker) {
+            const ShadeReq r = queue[(q_head + lane) & (QCAP - 1)];
+            ra = r.a;
+            rnext = r.next;
+            const f3 pos = mk3(r.px, r.py, r.pz);
+            const f3 po = to_object(mc, pos);
+            // compute_volume_gradient_object_space, shaders_common.h:195-215 (one-sided, flipped at the upper bound);
+            // the three taps are issued together
+            const bool flx = (po.x + mc.gstep.x) > 1.f, fly = (po.y + mc.gstep.y) > 1.f, flz = (po.z + mc.gstep.z) > 1.f;
+            Tap tgx, tgy, tgz;
+            tap_issue<VT, BIG>(vc, mk3(po.x + (flx ? -mc.gstep.x : mc.gstep.x), po.y, po.z), tgx);
+            tap_issue<VT, BIG>(vc, mk3(po.x, po.y + (fly ? -mc.gstep.y : mc.gstep.y), po.z), tgy);
+            tap_issue<VT, BIG>(vc, mk3(po.x, po.y, po.z + (flz ? -mc.gstep.z : mc.gstep.z)), tgz);
+            f3 rgb = tf_color(tf, r.v);
+            f3 g;
+            g.x = (tap_finish<VT>(vc, tgx) - r.s) * (flx ? -mc.ginv.x : mc.ginv.x);
+            g.y = (tap_finish<VT>(vc, tgy) - r.s) * (fly ? -mc.ginv.y : mc.ginv.y);
+            g.z = (tap_finish<VT>(vc, tgz) - r.s) * (flz ? -mc.ginv.z : mc.ginv.z);
+            const f3 gn = normalize3(g);
+            const f3 n_o = mk3(-gn.x, -gn.y, -gn.z);
+            const f3 n_w = normalize3(mk3(n_o.x * mc.otw_it.x, n_o.y * mc.otw_it.y, n_o.z * mc.otw_it.z));
+            f3 n_c = mk3(0, 0, 0);
+            if (P.grad) {
+              const float* m = P.wtc_it;
+              n_c = normalize3(mk3(fmaf(n_w.x, m[0], fmaf(n_w.y, m[3], n_w.z * m[6])), fmaf(n_w.x, m[1], fmaf(n_w.y, m[4], n_w.z * m[7])),
+                                   fmaf(n_w.x, m[2], fmaf(n_w.y, m[5], n_w.z * m[8]))));
+            }
+            float shadow = 0.f;
+            if (SHADE == 2) shadow = march_shadow<VT, BIG, Cfg::KS>(vc, tf, mc, pos, n_shadow);
+            const float cosNL = fabsf(dot3(mc.light, n_w));
+            const float shade = 0.5f + 0.5f * cosNL * 2.f * (1.f - shadow); // shaders_raymarching.cu:156-157
+            cx = r.tr * clamp01(rgb.x * shade);
+            cy = r.tr * clamp01(rgb.y * shade);
+            cz = r.tr * clamp01(rgb.z * shade);
+            gx = r.tr * clamp01(n_c.x);
+            gy = r.tr * clamp01(n_c.y);
+            gz = r.tr * clamp01(n_c.z);
+          }
+          // hand the contributions back: every owner walks its own requests of this batch in sample order
+          for (;;) {
+            const bool has = (pend > 0) && ((first - q_head) < n);
+            if (__ballot(has) == 0ull) break;
+            const int j = has ? (int)(first - q_head) : lane;
+            const float tcx = bperm(j, cx), tcy = bperm(j, cy), tcz = bperm(j, cz);
+            const float tgx2 = bperm(j, gx), tgy2 = bperm(j, gy), tgz2 = bperm(j, gz);
+            const float ta = bperm(j, ra);
+            const int tn = bperm_i(j, rnext);
+            if (has) {
+              color.x = fmaf(tcx, ta, color.x);
+              color.y = fmaf(tcy, ta, color.y);
+              color.z = fmaf(tcz, ta, color.z);
+              gradient.x = fmaf(tgx2, ta, gradient.x);
+              gradient.y = fmaf(tgy2, ta, gradient.y);
+              gradient.z = fmaf(tgz2, ta, gradient.z);
+              first = (unsigned int)tn;
+              --pend;
+            }
+          }
+          q_head += n;
+        }
+        if (!any_live) break;
       }
-      const float ux = sx - 0.5f, uy = sy - 0.5f;
-      const f3 dir = normalize3_exact(mk3(cdir.x + ux * chor.x + uy * cver.x, cdir.y + ux * chor.y + uy * cver.y,
-                                          cdir.z + ux * chor.z + uy * cver.z));
-      ++n_rays;
-      // ---- __intersection__volume: object-space ray, direction not renormalised so t is shared
-      const f3 oo = to_object(mc, org);
-      const f3 od = mk3(dir.x * mc.inv_scale.x, dir.y * mc.inv_scale.y, dir.z * mc.inv_scale.z);
-      float t0 = 0.f, t1 = FLT_MAX;
-      float alpha = 0.f;
-      f3 color = mk3(0, 0, 0), gradient = mk3(0, 0, 0);
-      if (intersect_unit_box(t0, t1, oo, od)) {
-        float tx = t0, ty = fminf(t1, t0 + mc.step);
-        while ((ty > tx) && (alpha < 0.9999f)) {
-          const float tm = 0.5f * (tx + ty);
-          const f3 pos = mk3(fmaf(tm, dir.x, org.x), fmaf(tm, dir.y, org.y), fmaf(tm, dir.z, org.z));
-          const f3 po = to_object(mc, pos);
-          const float s = sample_volume<VT>(vc, po);
-          const float v = tf_coord(tf, s);
-          float a = tf_alpha(tf, v);
-          a = opacity_correction(a, mc.base * (ty - tx));
+      else {
+        if (__ballot(live) == 0ull) break;
+      }
+
+      // ---- (2) primary march: K samples, loads first
+      Tap taps[K];
+      f3 poss[K];
+      float dts[K];
+      bool valid[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        valid[k] = ty > tx;
+        dts[k] = ty - tx;
+        const float tm = 0.5f * (tx + ty);
+        poss[k] = mk3(fmaf(tm, dir.x, org.x), fmaf(tm, dir.y, org.y), fmaf(tm, dir.z, org.z));
+        tap_issue<VT, BIG>(vc, to_object(mc, poss[k]), taps[k]);
+        tx = ty;
+        ty = fminf(tx + mc.step, t1);
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        bool push = false;
+        float s = 0.f, v = 0.f, a = 0.f, tr = 0.f;
+        if (live && valid[k] && (alpha < 0.9999f)) { // the reference's loop condition, shaders_raymarching.cu:110
+          s = tap_finish<VT>(vc, taps[k]);
+          v = tf_coord(tf, s);
+          a = opacity_correction(tf_alpha(tf, v), mc.base * dts[k]);
           ++n_samples;
           // A sample whose corrected opacity is exactly 0 adds exactly 0 to colour, gradient and alpha (its colour
-          // passes through clamp01 first, so it is finite): the gradient taps and the shadow march are skipped.
+          // passes through clamp01 first, so it is finite): nothing is shaded for it.
           if (a > 0.f) {
             ++n_shaded;
-            f3 rgb = tf_color(tf, v);
-            f3 n_c = mk3(0, 0, 0);
-            if (SHADE != 0) {
-              // compute_volume_gradient_object_space, shaders_common.h:195-215 (one-sided, flipped at the upper bound)
-              f3 g;
-              {
-                const bool fl = (po.x + mc.gstep.x) > 1.f;
-                const float h = fl ? -mc.gstep.x : mc.gstep.x;
-                g.x = (sample_volume<VT>(vc, mk3(po.x + h, po.y, po.z)) - s) * (fl ? -mc.ginv.x : mc.ginv.x);
-              }
-              {
-                const bool fl = (po.y + mc.gstep.y) > 1.f;
-                const float h = fl ? -mc.gstep.y : mc.gstep.y;
-                g.y = (sample_volume<VT>(vc, mk3(po.x, po.y + h, po.z)) - s) * (fl ? -mc.ginv.y : mc.ginv.y);
-              }
-              {
-                const bool fl = (po.z + mc.gstep.z) > 1.f;
-                const float h = fl ? -mc.gstep.z : mc.gstep.z;
-                g.z = (sample_volume<VT>(vc, mk3(po.x, po.y, po.z + h)) - s) * (fl ? -mc.ginv.z : mc.ginv.z);
-              }
-              const f3 gn = normalize3(g);
-              const f3 n_o = mk3(-gn.x, -gn.y, -gn.z);
-              const f3 n_w = normalize3(mk3(n_o.x * mc.otw_it.x, n_o.y * mc.otw_it.y, n_o.z * mc.otw_it.z));
-              if (P.grad) {
-                const float* m = P.wtc_it;
-                n_c = normalize3(mk3(fmaf(n_w.x, m[0], fmaf(n_w.y, m[3], n_w.z * m[6])), fmaf(n_w.x, m[1], fmaf(n_w.y, m[4], n_w.z * m[7])),
-                                     fmaf(n_w.x, m[2], fmaf(n_w.y, m[5], n_w.z * m[8]))));
-              }
-              float shadow = 0.f;
-              if (SHADE == 2) shadow = march_shadow<VT>(vc, tf, mc, pos, n_shadow);
-              const float cosNL = fabsf(dot3(mc.light, n_w));
-              const float shade = 0.5f + 0.5f * cosNL * 2.f * (1.f - shadow);
-              rgb.x *= shade; rgb.y *= shade; rgb.z *= shade;
+            tr = 1.f - alpha;
+            if (SHADE == 0) {
+              const f3 rgb = tf_color(tf, v);
+              color.x = fmaf(tr * clamp01(rgb.x), a, color.x);
+              color.y = fmaf(tr * clamp01(rgb.y), a, color.y);
+              color.z = fmaf(tr * clamp01(rgb.z), a, color.z);
             }
-            const float tr = 1.f - alpha;
-            color.x = fmaf(tr * clamp01(rgb.x), a, color.x);
-            color.y = fmaf(tr * clamp01(rgb.y), a, color.y);
-            color.z = fmaf(tr * clamp01(rgb.z), a, color.z);
-            gradient.x = fmaf(tr * clamp01(n_c.x), a, gradient.x);
-            gradient.y = fmaf(tr * clamp01(n_c.y), a, gradient.y);
-            gradient.z = fmaf(tr * clamp01(n_c.z), a, gradient.z);
+            else {
+              push = true;
+            }
             alpha = fmaf(tr, a, alpha);
           }
-          tx = ty;
-          ty = fminf(tx + mc.step, t1);
+        }
+        else {
+          live = false;
+        }
+        if (SHADE != 0) {
+          const unsigned long long m = __ballot(push);
+          if (m != 0ull) {
+            if (push) {
+              const unsigned int pos_q = q_tail + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+              ShadeReq r;
+              r.px = poss[k].x; r.py = poss[k].y; r.pz = poss[k].z;
+              r.s = s; r.v = v; r.tr = tr; r.a = a; r.next = 0;
+              queue[pos_q & (QCAP - 1)] = r;
+              if (pend > 0) queue[last & (QCAP - 1)].next = (int)pos_q; else first = pos_q;
+              last = pos_q;
+              ++pend;
+            }
+            q_tail += (unsigned int)__popcll(m);
+          }
         }
       }
-      // render_raymarching / alpha_blend with an always-missing background (shaders_raymarching.cu:260-321)
-      o_a += alpha;
-      if (alpha > 0.f) {
-        o_c.x += color.x / alpha; o_c.y += color.y / alpha; o_c.z += color.z / alpha;
-        o_g.x += gradient.x / alpha; o_g.y += gradient.y / alpha; o_g.z += gradient.z / alpha;
-      }
     }
+
+    // render_raymarching / alpha_blend with an always-missing background (shaders_raymarching.cu:260-321)
+    o_a += alpha;
+    if (alpha > 0.f) {
+      o_c.x += color.x / alpha; o_c.y += color.y / alpha; o_c.z += color.z / alpha;
+      o_g.x += gradient.x / alpha; o_g.y += gradient.y / alpha; o_g.z += gradient.z / alpha;
+    }
+  }
+
+  if (active) {
     const float rspp = 1.f / (float)spp;
     o_a *= rspp;
     o_c.x *= rspp; o_c.y *= rspp; o_c.z *= rspp;
@@ -450,7 +610,7 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
     }
   }
 
-  // ---- counters: wave reduction, one atomic per wave and counter
+  // ---- counters: wave reduction -> LDS -> one plain store of the workgroup's partial sums
   unsigned int n_active = active ? 1u : 0u;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -460,25 +620,66 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
     n_shadow += __shfl_down(n_shadow, off);
     n_active += __shfl_down(n_active, off);
   }
-  if (lane == 0 && P.counters && n_active) {
-    atomicAdd(&P.counters[0], (unsigned long long)n_rays);
-    atomicAdd(&P.counters[1], (unsigned long long)n_samples);
-    atomicAdd(&P.counters[2], (unsigned long long)n_shaded);
-    atomicAdd(&P.counters[3], (unsigned long long)n_shadow);
-    atomicAdd(&P.counters[4], (unsigned long long)n_active);
+  if (P.block_counters) {
+    __syncthreads(); // the queues are dead: reuse the front of LDS
+    unsigned int* red = reinterpret_cast<unsigned int*>(lds_raw);
+    if (lane == 0) {
+      red[wave * 5 + 0] = n_rays; red[wave * 5 + 1] = n_samples; red[wave * 5 + 2] = n_shaded;
+      red[wave * 5 + 3] = n_shadow; red[wave * 5 + 4] = n_active;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+      const unsigned int bid = blockIdx.x + blockIdx.y * gridDim.x;
+      unsigned int sum = 0;
+      for (int w = 0; w < kWaves; ++w) sum += red[w * 5 + threadIdx.x];
+      P.block_counters[(size_t)bid * 5 + threadIdx.x] = sum;
+    }
   }
 }
 
-size_t raymarch_lds_bytes(int n_color, int n_alpha)
+// sums the per-workgroup partials into counters[0..4] (one workgroup; deterministic)
+__global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned int* __restrict__ partials, int n_blocks, unsigned long long* counters)
 {
-  const size_t need = (size_t)n_color * sizeof(float4) + (size_t)n_alpha * sizeof(float);
-  return need <= 60 * 1024 ? need : 0;
+  __shared__ unsigned long long red[4][5];
+  unsigned long long acc[5] = { 0, 0, 0, 0, 0 };
+  for (int b = threadIdx.x; b < n_blocks; b += 256) {
+#pragma unroll
+    for (int c = 0; c < 5; ++c) acc[c] += partials[(size_t)b * 5 + c];
+  }
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    for (int off = 32; off > 0; off >>= 1) acc[c] += __shfl_down(acc[c], off);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < 5; ++c) red[wave][c] = acc[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) counters[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-template <int VT, int SHADE>
-static hipError_t launch_vs(const RayMarchParams& p, hipStream_t stream)
+template <int SHADE> static size_t queue_lds_bytes() { return (size_t)kWaves * MarchCfg<SHADE>::QCAP * sizeof(ShadeReq); }
+
+size_t raymarch_lds_bytes(int n_color, int n_alpha)
 {
-  const size_t lds = raymarch_lds_bytes(p.n_color, p.n_alpha);
+  // the transfer function always lives in LDS; 0 = does not fit next to the request queues (caller reports an error)
+  const size_t need = (size_t)n_color * sizeof(float4) + (size_t)n_alpha * sizeof(float);
+  return need <= 96 * 1024 ? need : 0;
+}
+
+size_t raymarch_grid_blocks(const RayMarchParams& p)
+{
+  if (p.sparse_xy) return ((size_t)p.width * p.height + kBlock - 1) / kBlock;
+  return (size_t)((p.width + 15) / 16) * (size_t)((p.height + 15) / 16);
+}
+
+template <int VT, int SHADE, bool BIG>
+static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream)
+{
+  const size_t tf_lds = raymarch_lds_bytes(p.n_color, p.n_alpha);
+  if (tf_lds == 0) return hipErrorInvalidValue;
+  const size_t lds = std::max<size_t>(tf_lds + queue_lds_bytes<SHADE>(), 64); // >= 64 B: the counter reduction reuses it
   dim3 grid, block(kBlock);
   if (p.sparse_xy) {
     grid = dim3((unsigned)(((size_t)p.width * p.height + kBlock - 1) / kBlock));
@@ -486,11 +687,27 @@ static hipError_t launch_vs(const RayMarchParams& p, hipStream_t stream)
   else {
     grid = dim3((unsigned)((p.width + 15) / 16), (unsigned)((p.height + 15) / 16));
   }
-  if (lds)
-    hipLaunchKernelGGL((raymarch_kernel<VT, SHADE, true>), grid, block, lds, stream, p);
-  else
-    hipLaunchKernelGGL((raymarch_kernel<VT, SHADE, false>), grid, block, 0, stream, p);
-  return hipGetLastError();
+  auto kern = raymarch_kernel<VT, SHADE, BIG>;
+  if (lds > 64 * 1024) {
+    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return ea;
+  }
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (p.block_counters && p.counters) {
+    hipLaunchKernelGGL(reduce_counters_kernel, dim3(1), dim3(256), 0, stream, p.block_counters, (int)raymarch_grid_blocks(p), p.counters);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+template <int VT, int SHADE>
+static hipError_t launch_vs(const RayMarchParams& p, hipStream_t stream)
+{
+  // 32-bit byte offsets (SGPR base + VGPR offset loads) whenever the bricked volume is smaller than 4 GiB
+  if (p.vol.bytes <= 0xffffffffull) return launch_vsb<VT, SHADE, false>(p, stream);
+  return launch_vsb<VT, SHADE, true>(p, stream);
 }
 
 template <int VT>
@@ -516,7 +733,7 @@ hipError_t launch_raymarch(const RayMarchParams& p, hipStream_t stream)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// volume relayout: linear (x fastest) -> yz-tiled rows with a replicated pad element
+// volume relayout: linear (x fastest) -> 128-byte bricks in 32^3 macro blocks
 // ------------------------------------------------------------------------------------------------------------------
 int device_voxel_type(int t)
 {
@@ -546,41 +763,41 @@ template <> struct Conv<int, float> { // array.h:78-90
   static __device__ __forceinline__ float cv(int v) { const float n = (float)v / (float)0x7fffffff; return n < -1.f ? -1.f : n; }
 };
 
-template <typename TI, typename TO>
-__global__ __launch_bounds__(256) void relayout_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int nx, int ny, int row_stride,
-                                                      int tiles_y, int z0, int nz_chunk)
+template <typename TI, typename TO, int VT>
+__global__ __launch_bounds__(256) void relayout_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int nx, int ny, unsigned int macro_y,
+                                                      unsigned long long macro_z, int z0, int nz_chunk)
 {
-  // grid: x = ceil(row_stride / 256), y = ny, z = nz_chunk ; src holds slices [z0, z0 + nz_chunk)
+  // grid: x = ceil(nx / 256), y = ny, z = nz_chunk ; src holds slices [z0, z0 + nz_chunk), x fastest
+  typedef BrickMap<VT> M;
   const int x = blockIdx.x * 256 + threadIdx.x;
   const int y = blockIdx.y, zl = blockIdx.z;
-  if (x >= row_stride || zl >= nz_chunk) return;
-  const int z = z0 + zl;
-  const int xs = min(x, nx - 1);
-  const TI v = src[(size_t)xs + (size_t)nx * ((size_t)y + (size_t)ny * (size_t)zl)];
-  const size_t row = (size_t)(((z >> 3) * tiles_y + (y >> 3)) * 64 + (z & 7) * 8 + (y & 7));
-  dst[row * (size_t)row_stride + (size_t)x] = Conv<TI, TO>::cv(v);
+  if (x >= nx || zl >= nz_chunk) return;
+  const unsigned z = (unsigned)(z0 + zl);
+  const TI v = src[(size_t)x + (size_t)nx * ((size_t)y + (size_t)ny * (size_t)zl)];
+  const unsigned long long off = (unsigned long long)(M::X((unsigned)x) + M::Y((unsigned)y, macro_y)) + M::Zlo(z) + (unsigned long long)(z >> 5) * macro_z;
+  dst[off] = Conv<TI, TO>::cv(v);
 }
 
-template <typename TI, typename TO>
+template <typename TI, typename TO, int VT>
 static hipError_t relayout_t(const void* src, void* dst, const VolumeDesc& vd, int z0, int nzc, hipStream_t stream)
 {
-  dim3 grid((unsigned)((vd.row_stride + 255) / 256), (unsigned)vd.ny, (unsigned)nzc);
-  hipLaunchKernelGGL((relayout_kernel<TI, TO>), grid, dim3(256), 0, stream, (const TI*)src, (TO*)dst, vd.nx, vd.ny, vd.row_stride,
-                     vd.tiles_y, z0, nzc);
+  dim3 grid((unsigned)((vd.nx + 255) / 256), (unsigned)vd.ny, (unsigned)nzc);
+  hipLaunchKernelGGL((relayout_kernel<TI, TO, VT>), grid, dim3(256), 0, stream, (const TI*)src, (TO*)dst, vd.nx, vd.ny,
+                     32768u * (unsigned)vd.macros_x, 32768ull * (unsigned long long)vd.macros_x * (unsigned long long)vd.macros_y, z0, nzc);
   return hipGetLastError();
 }
 
 hipError_t launch_relayout(const void* src, int vt, void* dst, const VolumeDesc& vd, int z0, int nzc, hipStream_t stream)
 {
   switch (vt) {
-  case 100: return relayout_t<unsigned char, unsigned char>(src, dst, vd, z0, nzc, stream);
-  case 101: return relayout_t<signed char, signed char>(src, dst, vd, z0, nzc, stream);
-  case 200: return relayout_t<unsigned short, unsigned short>(src, dst, vd, z0, nzc, stream);
-  case 201: return relayout_t<short, short>(src, dst, vd, z0, nzc, stream);
-  case 300: return relayout_t<unsigned int, float>(src, dst, vd, z0, nzc, stream);
-  case 301: return relayout_t<int, float>(src, dst, vd, z0, nzc, stream);
-  case 400: return relayout_t<float, float>(src, dst, vd, z0, nzc, stream);
-  case 500: return relayout_t<double, float>(src, dst, vd, z0, nzc, stream);
+  case 100: return relayout_t<unsigned char, unsigned char, VOX_U8>(src, dst, vd, z0, nzc, stream);
+  case 101: return relayout_t<signed char, signed char, VOX_I8>(src, dst, vd, z0, nzc, stream);
+  case 200: return relayout_t<unsigned short, unsigned short, VOX_U16>(src, dst, vd, z0, nzc, stream);
+  case 201: return relayout_t<short, short, VOX_I16>(src, dst, vd, z0, nzc, stream);
+  case 300: return relayout_t<unsigned int, float, VOX_F32>(src, dst, vd, z0, nzc, stream);
+  case 301: return relayout_t<int, float, VOX_F32>(src, dst, vd, z0, nzc, stream);
+  case 400: return relayout_t<float, float, VOX_F32>(src, dst, vd, z0, nzc, stream);
+  case 500: return relayout_t<double, float, VOX_F32>(src, dst, vd, z0, nzc, stream);
   default: return hipErrorInvalidValue;
   }
 }
