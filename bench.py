@@ -180,6 +180,7 @@ def main():
     torch.cuda.synchronize()
     tot = dict(samples=0, shaded_samples=0, shadow_samples=0, rays=0, active_pixels=0)
     kernel_ms = 0.0
+    phase_ms = [0.0, 0.0, 0.0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -187,6 +188,10 @@ def main():
         for k in tot:
             tot[k] += getattr(st, k)
         kernel_ms += st.kernel_ms
+        phase_ms[0] += st.march_ms
+        phase_ms[1] += st.shade_ms
+        phase_ms[2] += st.composite_ms
+        last_stats = st
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -239,7 +244,9 @@ def main():
             "per_frame": {k: per_step[k] for k in sorted(per_step)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "raymarch_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes,
+                         "kernel": "raymarch pipeline (march + shade + composite)" if last_stats.pipeline == 2 else "raymarch_kernel",
+                         "kernel_ms": k_ms, "phase_ms_rank0": {"march": phase_ms[0] / steps, "shade": phase_ms[1] / steps, "composite": phase_ms[2] / steps},
+                         "pool_chunks": int(last_stats.pool_chunks), "algorithmic_bytes_per_launch": abytes,
                          "nominal_frac_survey_F4": (nbytes / (k_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if k_ms > 0 else 0.0},
         }
         if not args.no_cpu_baseline:

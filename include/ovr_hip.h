@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OVR_HIP_ABI_VERSION 1
+#define OVR_HIP_ABI_VERSION 2
 
 /* error codes */
 #define OVR_HIP_OK 0
@@ -67,7 +67,11 @@ typedef struct ovr_hip_stats {
   double kernel_ms;         /* hipEvent time of the ray-march kernel of the last render()                     */
   double render_ms;         /* wall time of the last render() call, as DeviceOptix7::render measures it       */
   int32_t frame_index;      /* accumulation frame counter after the last render (device_impl.cpp:241)         */
-  int32_t reserved;
+  int32_t pipeline;         /* 1 = shaded in place, 2 = pooled (march -> shade -> composite kernels)          */
+  double march_ms;          /* hipEvent time of the primary-march kernel (== kernel_ms when shading in place)  */
+  double shade_ms;          /* pooled pipeline: the persistent shading kernel                                  */
+  double composite_ms;      /* pooled pipeline: composite + counter reduction                                  */
+  uint64_t pool_chunks;     /* pooled pipeline: 2 KiB request chunks used by the frame                         */
 } ovr_hip_stats;
 
 const char* ovr_hip_last_error(void);
@@ -114,6 +118,10 @@ int ovr_hip_set_focus(ovr_hip_renderer* r, float center_x, float center_y, float
 int ovr_hip_set_noise_tile(ovr_hip_renderer* r, const float* tile, int32_t xy);
 /* extension: select the sub-mode BASELINE.json's configs name; default OVR_HIP_SHADE_FULL (= reference) */
 int ovr_hip_set_shading(ovr_hip_renderer* r, int32_t mode);
+/* extension: how shaded samples are processed.  0 = automatic (pooled when spp == 1, else in place), 1 = in place
+ * (the tile's own wave shades its request batches), 2 = pooled (request chunks go through a global pool and are shaded
+ * by a separate, load-balanced kernel).  Both produce bit-identical frames. */
+int ovr_hip_set_shading_pipeline(ovr_hip_renderer* r, int32_t mode);
 /* extension (multi-GPU): this renderer draws only the image tiles owned by `rank` of `world`;
  * owner(tile_x, tile_y) = (tile_x + tile_y) % world.  world = 1 restores the single-GPU behaviour. */
 int ovr_hip_set_image_shard(ovr_hip_renderer* r, int32_t rank, int32_t world, int32_t tile_w, int32_t tile_h);

@@ -16,6 +16,7 @@ TYPE_FLOAT, TYPE_DOUBLE = 400, 500
 MEM_HOST, MEM_DEVICE = 0, 1
 SHADE_NONE, SHADE_GRADIENT, SHADE_FULL = 0, 1, 2
 GRID_CELL_CENTRED, GRID_VERTEX_CENTRED = 0, 1
+PIPELINE_AUTO, PIPELINE_IN_PLACE, PIPELINE_POOLED = 0, 1, 2
 
 
 class Stats(C.Structure):
@@ -28,7 +29,11 @@ class Stats(C.Structure):
         ("kernel_ms", C.c_double),
         ("render_ms", C.c_double),
         ("frame_index", C.c_int32),
-        ("reserved", C.c_int32),
+        ("pipeline", C.c_int32),
+        ("march_ms", C.c_double),
+        ("shade_ms", C.c_double),
+        ("composite_ms", C.c_double),
+        ("pool_chunks", C.c_uint64),
     ]
 
 
@@ -53,6 +58,7 @@ SYMBOLS = {
     "ovr_hip_set_focus": (C.c_int, [_H, C.c_float, C.c_float, C.c_float, C.c_float]),
     "ovr_hip_set_noise_tile": (C.c_int, [_H, _F3, C.c_int32]),
     "ovr_hip_set_shading": (C.c_int, [_H, C.c_int32]),
+    "ovr_hip_set_shading_pipeline": (C.c_int, [_H, C.c_int32]),
     "ovr_hip_set_image_shard": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "ovr_hip_commit": (C.c_int, [_H]),
     "ovr_hip_render": (C.c_int, [_H]),

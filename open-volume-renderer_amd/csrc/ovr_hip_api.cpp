@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -98,13 +99,13 @@ struct ovr_hip_renderer {
   hipStream_t own_stream[2] = { nullptr, nullptr };
   hipStream_t user_stream = nullptr;
   bool use_user_stream = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
 
   Queued<Size2> fbsize;
   Queued<CameraP> camera;
   Queued<TfnP> tfn;
   Queued<FocusP> focus;
-  Queued<int> spp, sparse, accumulate, shading, grid_convention;
+  Queued<int> spp, sparse, accumulate, shading, grid_convention, pipeline;
   Queued<float> rate;
   Queued<ShardP> shard;
 
@@ -145,7 +146,14 @@ struct ovr_hip_renderer {
   // counters
   unsigned long long* d_counters = nullptr;
   unsigned int* d_block_counters = nullptr; // per-workgroup partial counters
+  unsigned long long* d_trace = nullptr;    // OVR_HIP_TRACE=1 diagnostic buffer
+  size_t trace_words = 0;
   unsigned long long* h_counters = nullptr; // pinned
+
+  // request pool of the pooled shading pipeline
+  PoolDesc pool{};
+  size_t pool_tiles = 0;
+  unsigned int* h_ctrl = nullptr; // pinned copy of pool.ctrl
 
   RayMarchParams P{};
   ovr_hip_stats stats{};
@@ -172,6 +180,10 @@ int free_framebuffers(ovr_hip_renderer* r)
   r->d_accum = nullptr;
   if (r->d_block_counters) HIP_TRY(hipFree(r->d_block_counters));
   r->d_block_counters = nullptr;
+  if (r->pool.tile_first) HIP_TRY(hipFree(r->pool.tile_first));
+  if (r->pool.tile_count) HIP_TRY(hipFree(r->pool.tile_count));
+  if (r->pool.pix_state) HIP_TRY(hipFree(r->pool.pix_state));
+  r->pool.tile_first = nullptr; r->pool.tile_count = nullptr; r->pool.pix_state = nullptr;
   if (r->d_sparse_xy) HIP_TRY(hipFree(r->d_sparse_xy));
   if (r->d_block_counts) HIP_TRY(hipFree(r->d_block_counts));
   r->d_sparse_xy = nullptr;
@@ -196,7 +208,33 @@ int resize_framebuffers(ovr_hip_renderer* r, int w, int h)
   HIP_TRY(hipMemset(r->d_accum, 0, n * 4 * sizeof(float)));
   const size_t nblk = std::max<size_t>((size_t)((w + 15) / 16) * (size_t)((h + 15) / 16), (n + 255) / 256) + 1;
   HIP_TRY(hipMalloc((void**)&r->d_block_counters, nblk * 5 * sizeof(unsigned int)));
+  HIP_TRY(hipMalloc((void**)&r->pool.tile_first, nblk * 4 * sizeof(int)));
+  HIP_TRY(hipMalloc((void**)&r->pool.tile_count, nblk * 4 * sizeof(unsigned int)));
+  HIP_TRY(hipMalloc((void**)&r->pool.pix_state, std::max<size_t>(n, 1) * sizeof(float4)));
+  r->pool_tiles = nblk * 4;
+  if (r->d_trace) { HIP_TRY(hipFree(r->d_trace)); r->d_trace = nullptr; }
+  if (const char* tr = getenv("OVR_HIP_TRACE")) {
+    if (tr[0] == '1') {
+      r->trace_words = nblk * 4 * 4;
+      HIP_TRY(hipMalloc((void**)&r->d_trace, r->trace_words * sizeof(unsigned long long)));
+    }
+  }
   r->fb_pixels = n;
+  return 0;
+}
+
+int ensure_pool(ovr_hip_renderer* r, size_t chunks)
+{
+  if (r->pool.reqs && r->pool.capacity >= chunks) return 0;
+  HIP_TRY(hipDeviceSynchronize());
+  if (r->pool.reqs) HIP_TRY(hipFree(r->pool.reqs));
+  if (r->pool.chunk_next) HIP_TRY(hipFree(r->pool.chunk_next));
+  if (r->pool.chunk_n) HIP_TRY(hipFree(r->pool.chunk_n));
+  r->pool.reqs = nullptr; r->pool.chunk_next = nullptr; r->pool.chunk_n = nullptr; r->pool.capacity = 0;
+  HIP_TRY(hipMalloc((void**)&r->pool.reqs, chunks * 64 * 32));
+  HIP_TRY(hipMalloc((void**)&r->pool.chunk_next, chunks * sizeof(int)));
+  HIP_TRY(hipMalloc((void**)&r->pool.chunk_n, chunks * sizeof(unsigned int)));
+  r->pool.capacity = (unsigned int)chunks;
   return 0;
 }
 
@@ -328,6 +366,8 @@ SparseMaskParams make_mask_params(ovr_hip_renderer* r, int frame_index, int32_t*
   return m;
 }
 
+int launch_frame(ovr_hip_renderer* r);
+
 // Impl::render up to and including the launch (device_impl.cpp:199-262); no host synchronisation
 int enqueue_frame(ovr_hip_renderer* r)
 {
@@ -385,6 +425,7 @@ int enqueue_frame(ovr_hip_renderer* r)
   P.tile_h = r->shard.current.th;
   P.counters = r->d_counters;
   P.block_counters = r->d_block_counters;
+  P.trace = r->d_trace;
   P.sparse_xy = nullptr;
   P.sparse_count = nullptr;
   if (sparse) { // createSparseSamples, device_impl.cpp:304-342
@@ -394,10 +435,31 @@ int enqueue_frame(ovr_hip_renderer* r)
     P.sparse_xy = r->d_sparse_xy;
     P.sparse_count = r->d_sparse_count;
   }
-  HIP_TRY(hipEventRecord(r->ev0, st));
-  HIP_TRY(launch_raymarch(P, st));
-  HIP_TRY(hipEventRecord(r->ev1, st));
+  // ---- shading pipeline: pooled (march -> shade -> composite) when it applies, else in place
+  const int pipe = r->pipeline.current;
+  const bool want_pool = P.shading != 0 && P.spp == 1 && pipe != 1;
+  P.pool = PoolDesc{};
+  if (want_pool) {
+    // first guess: room for 8 shaded samples per pixel; grown after an overflow (finish_frame)
+    const size_t guess = std::min<size_t>(std::max<size_t>(n * 8 / 64, 4096), (size_t)1 << 20);
+    if (int e = ensure_pool(r, std::max<size_t>(guess, r->pool.capacity))) return e;
+    if (!r->pool.ctrl) {
+      HIP_TRY(hipMalloc((void**)&r->pool.ctrl, 4 * sizeof(unsigned int)));
+      HIP_TRY(hipMalloc((void**)&r->pool.shade_counters, pool_shade_blocks() * sizeof(unsigned int)));
+      HIP_TRY(hipHostMalloc((void**)&r->h_ctrl, 4 * sizeof(unsigned int), hipHostMallocDefault));
+    }
+    P.pool = r->pool;
+  }
+  r->stats.pipeline = want_pool ? 2 : 1;
+  return launch_frame(r);
+}
+
+int launch_frame(ovr_hip_renderer* r)
+{
+  hipStream_t st = r->stream();
+  HIP_TRY(launch_raymarch(r->P, st, r->ev));
   HIP_TRY(hipMemcpyAsync(r->h_counters, r->d_counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  if (r->P.pool.reqs) HIP_TRY(hipMemcpyAsync(r->h_ctrl, r->pool.ctrl, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
   r->async_pending = true;
   return 0;
 }
@@ -406,15 +468,44 @@ int finish_frame(ovr_hip_renderer* r)
 {
   if (!r->async_pending) return 0;
   HIP_TRY(hipStreamSynchronize(r->stream()));
-  float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, r->ev0, r->ev1));
+  if (r->P.pool.reqs) {
+    // pool overflow: the march asked for more chunks than the pool holds; nothing was written to the framebuffer.
+    // Grow the pool to what the frame needs (+25 %) and render the same frame again.
+    for (int attempt = 0; attempt < 4 && r->h_ctrl[0] > r->pool.capacity; ++attempt) {
+      const size_t need = (size_t)r->h_ctrl[0] + (size_t)r->h_ctrl[0] / 4 + 64;
+      if (int e = ensure_pool(r, need)) return e;
+      r->P.pool = r->pool;
+      if (int e = launch_frame(r)) return e;
+      HIP_TRY(hipStreamSynchronize(r->stream()));
+    }
+    if (r->h_ctrl[0] > r->pool.capacity) return fail(OVR_HIP_EDEVICE, "[hip] request pool overflow persists after re-sizing");
+    r->stats.pool_chunks = r->h_ctrl[0];
+  }
+  else {
+    r->stats.pool_chunks = 0;
+  }
+  float ms = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, r->ev[0], r->ev[3]));
+  HIP_TRY(hipEventElapsedTime(&m1, r->ev[0], r->ev[1]));
+  HIP_TRY(hipEventElapsedTime(&m2, r->ev[1], r->ev[2]));
+  HIP_TRY(hipEventElapsedTime(&m3, r->ev[2], r->ev[3]));
   r->stats.kernel_ms = ms;
+  r->stats.march_ms = m1;
+  r->stats.shade_ms = m2;
+  r->stats.composite_ms = m3;
   r->stats.rays = r->h_counters[0];
   r->stats.samples = r->h_counters[1];
   r->stats.shaded_samples = r->h_counters[2];
   r->stats.shadow_samples = r->h_counters[3];
   r->stats.active_pixels = r->h_counters[4];
   r->stats.frame_index = r->frame_index;
+  if (r->d_trace) {
+    if (const char* path = getenv("OVR_HIP_TRACE_FILE")) {
+      std::vector<unsigned long long> h(r->trace_words);
+      HIP_TRY(hipMemcpy(h.data(), r->d_trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+    }
+  }
   r->async_pending = false;
   return 0;
 }
@@ -443,8 +534,7 @@ int ovr_hip_create(ovr_hip_renderer** out, int device_id)
   r->device = device_id;
   HIP_TRY(hipStreamCreate(&r->own_stream[0]));
   HIP_TRY(hipStreamCreate(&r->own_stream[1]));
-  HIP_TRY(hipEventCreate(&r->ev0));
-  HIP_TRY(hipEventCreate(&r->ev1));
+  for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&r->ev[i]));
   HIP_TRY(hipMalloc((void**)&r->d_counters, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipMalloc((void**)&r->d_sparse_count, sizeof(unsigned long long)));
   HIP_TRY(hipHostMalloc((void**)&r->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
@@ -473,8 +563,15 @@ void ovr_hip_destroy(ovr_hip_renderer* r)
   if (r->d_counters) (void)hipFree(r->d_counters);
   if (r->d_sparse_count) (void)hipFree(r->d_sparse_count);
   if (r->h_counters) (void)hipHostFree(r->h_counters);
-  if (r->ev0) (void)hipEventDestroy(r->ev0);
-  if (r->ev1) (void)hipEventDestroy(r->ev1);
+  for (int i = 0; i < 4; ++i) if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
+  if (r->pool.reqs) (void)hipFree(r->pool.reqs);
+  if (r->pool.chunk_next) (void)hipFree(r->pool.chunk_next);
+  if (r->pool.chunk_n) (void)hipFree(r->pool.chunk_n);
+  if (r->pool.ctrl) (void)hipFree(r->pool.ctrl);
+  if (r->pool.shade_counters) (void)hipFree(r->pool.shade_counters);
+  if (r->h_ctrl) (void)hipHostFree(r->h_ctrl);
+  if (r->d_block_counters) (void)hipFree(r->d_block_counters);
+  if (r->d_trace) (void)hipFree(r->d_trace);
   for (int i = 0; i < 2; ++i)
     if (r->own_stream[i]) (void)hipStreamDestroy(r->own_stream[i]);
   delete r;
@@ -620,6 +717,7 @@ OVR_SIMPLE_SETTER(ovr_hip_set_volume_sampling_rate, rate, float, v > 0.f, "[hip]
 OVR_SIMPLE_SETTER(ovr_hip_set_frame_accumulation, accumulate, int32_t, true, "")
 OVR_SIMPLE_SETTER(ovr_hip_set_sparse_sampling, sparse, int32_t, true, "")
 OVR_SIMPLE_SETTER(ovr_hip_set_shading, shading, int32_t, v >= 0 && v <= 2, "[hip] unknown shading mode")
+OVR_SIMPLE_SETTER(ovr_hip_set_shading_pipeline, pipeline, int32_t, v >= 0 && v <= 2, "[hip] unknown shading pipeline")
 
 int ovr_hip_set_focus(ovr_hip_renderer* r, float cx, float cy, float scale, float base_noise)
 {
@@ -689,6 +787,7 @@ int ovr_hip_commit(ovr_hip_renderer* r)
   if (r->accumulate.update()) r->fb_reset = true; // :185-188
   if (r->rate.update()) r->fb_reset = true;       // :190-196
   if (r->shading.update()) r->fb_reset = true;
+  (void)r->pipeline.update(); // both pipelines produce the same frame: no accumulation reset
   if (r->shard.update()) r->fb_reset = true;
   return 0;
 }

@@ -29,6 +29,19 @@ struct VolumeDesc {
 
 struct float3_ { float x, y, z; };
 
+// global request pool of the pooled shading pipeline (see ovr_hip_kernels.hip): 2 KiB chunks of 64 requests
+struct PoolDesc {
+  struct ShadeReq* reqs;        // capacity * 64 requests of 32 bytes (null = pipeline disabled)
+  unsigned int capacity;        // chunks
+  unsigned int* ctrl;           // [0] chunks requested by the march  [1] shade cursor  [2..3] reserved; zeroed per frame
+  int* chunk_next;              // per chunk: next chunk of the same tile
+  unsigned int* chunk_n;        // per chunk: requests in it (64 except a tile's last)
+  int* tile_first;              // per tile (wave of the march grid): first chunk or -1
+  unsigned int* tile_count;     // per tile: requests pushed
+  float4* pix_state;            // per pixel: alpha, first request position, request count
+  unsigned int* shade_counters; // per shade workgroup: shadow-march iterations
+};
+
 struct RayMarchParams {
   // framebuffer (optix7/params.h:56-63)
   float* rgba;   // W*H*4
@@ -60,12 +73,15 @@ struct RayMarchParams {
   const unsigned long long* sparse_count;
   // counters: [0] rays [1] samples [2] shaded samples [3] shadow samples [4] active pixels
   unsigned long long* counters;
+  unsigned long long* trace;    // diagnostic (OVR_HIP_TRACE=1): 4 words per wave, null otherwise
   unsigned int* block_counters; // workspace: raymarch_grid_blocks() * 5 per-workgroup partial sums
+  PoolDesc pool;
   VolumeDesc vol;
 };
 
-// returns hipSuccess or the launch error
-hipError_t launch_raymarch(const RayMarchParams& p, hipStream_t stream);
+// returns hipSuccess or the launch error; ev = 4 events (start, after march, after shade, end) or null
+hipError_t launch_raymarch(const RayMarchParams& p, hipStream_t stream, const hipEvent_t* ev);
+size_t pool_shade_blocks();
 
 // dynamic LDS bytes the ray-march kernel needs for this TF (0 when the TF stays in global memory)
 size_t raymarch_lds_bytes(int n_color, int n_alpha);

@@ -152,11 +152,14 @@ __device__ __forceinline__ void tap_issue(const VolConsts& vc, f3 p, Tap& t)
     t.c000 = (float)base[oz0 + o00]; t.c100 = (float)base[oz0 + o10]; t.c010 = (float)base[oz0 + o01]; t.c110 = (float)base[oz0 + o11];
     t.c001 = (float)base[oz1 + o00]; t.c101 = (float)base[oz1 + o10]; t.c011 = (float)base[oz1 + o01]; t.c111 = (float)base[oz1 + o11];
   }
-  else { // the whole volume is < 4 GiB: 32-bit offsets, loads use the SGPR-base + VGPR-offset form
+  else { // the whole volume is < 4 GiB: 32-bit BYTE offsets, so the loads use the SGPR-base + 32-bit-VGPR-offset form
     const unsigned oz0 = M::Zlo((unsigned)z0) + ((unsigned)z0 >> 5) * (unsigned)vc.macro_z;
     const unsigned oz1 = M::Zlo((unsigned)z1) + ((unsigned)z1 >> 5) * (unsigned)vc.macro_z;
-    t.c000 = (float)base[oz0 + o00]; t.c100 = (float)base[oz0 + o10]; t.c010 = (float)base[oz0 + o01]; t.c110 = (float)base[oz0 + o11];
-    t.c001 = (float)base[oz1 + o00]; t.c101 = (float)base[oz1 + o10]; t.c011 = (float)base[oz1 + o01]; t.c111 = (float)base[oz1 + o11];
+    const char* cb = static_cast<const char*>(vc.data);
+#define OVR_LD(off) ((float)*reinterpret_cast<const T*>(cb + (unsigned)((off) * (unsigned)sizeof(T))))
+    t.c000 = OVR_LD(oz0 + o00); t.c100 = OVR_LD(oz0 + o10); t.c010 = OVR_LD(oz0 + o01); t.c110 = OVR_LD(oz0 + o11);
+    t.c001 = OVR_LD(oz1 + o00); t.c101 = OVR_LD(oz1 + o10); t.c011 = OVR_LD(oz1 + o01); t.c111 = OVR_LD(oz1 + o11);
+#undef OVR_LD
   }
 }
 
@@ -289,34 +292,39 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
     }
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
-      if (live && valid[k] && (alpha < 0.9999f)) {
-        const float s = tap_finish<VT>(vc, taps[k]);
-        float a = tf_alpha(tf, tf_coord(tf, s));
-        a = opacity_correction(a, mc.base * dts[k]);
-        alpha = fmaf(1.f - alpha, a, alpha);
-        ++n_shadow;
-      }
-      else {
-        live = false;
-      }
+      // branch-free on purpose: a conditional use would let the compiler sink this tap's loads into the branch and
+      // serialise the taps again (seen in the ISA); dead lanes just compute a value that is not used
+      const float s = tap_finish<VT>(vc, taps[k]);
+      float a = tf_alpha(tf, tf_coord(tf, s));
+      a = opacity_correction(a, mc.base * dts[k]);
+      live = live && valid[k] && (alpha < 0.9999f);
+      alpha = live ? fmaf(1.f - alpha, a, alpha) : alpha;
+      n_shadow += live ? 1u : 0u;
     }
   }
   return alpha;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// the ray-march kernel
+// the ray-march kernels
 //
 // Work decomposition: one lane per pixel, one wave64 per 8x8 pixel tile, four waves per workgroup.
-//  * primary march: K samples per round, all their row loads in flight before the first is consumed.
+//  * primary march: K samples per round, all their voxel loads in flight before the first is consumed.
 //  * deferred, compacted shading (SHADE != 0): a sample whose opacity is > 0 is not shaded by its own lane; the lane
 //    pushes a 32-byte request into its wave's queue in LDS (slot = tail + prefix-of-ballot, v_mbcnt) and keeps
-//    marching - alpha does not depend on shading, so early termination is unaffected.  Whenever 64 requests are
-//    queued the whole wave shades them, one request per lane (gradient taps, normals, shadow march toward the
-//    light - the expensive, otherwise badly divergent part), and hands the colour contributions back to the owning
-//    lanes with ds_bpermute.  Each owner applies its contributions in sample order (requests of one lane form a
-//    linked list through the queue), so the result is bit-identical to shading in place.
-//  * counters: per-workgroup partial sums, reduced by a second tiny kernel (no same-address atomics).
+//    marching - alpha does not depend on shading, so early termination is unaffected.  Requests are shaded 64 at a
+//    time, one request per lane (gradient taps, normals, shadow march toward the light - the expensive, otherwise
+//    badly divergent part); each owner applies its colour contributions in sample order (the requests of one lane
+//    form a linked list), so the result is bit-identical to shading in place.
+//  * two ways to shade a batch:
+//      in place   (raymarch_kernel)  the wave that owns the tile shades its own batches and gets the contributions
+//                                    back with ds_bpermute.  Used for spp > 1 and as the reference pipeline.
+//      pooled     (march_spill_kernel -> shade_pool_kernel -> composite_kernel)  the tile's wave spills each full
+//                                    batch as a 2 KiB chunk into a global pool; a second, persistent kernel shades
+//                                    chunks from ALL tiles with perfect load balance (the shadow work of a frame sits in
+//                                    a few hundred tiles: in place, their waves ran alone for 10 ms of a 13 ms kernel);
+//                                    a third kernel walks each tile's chunks in order and composites.
+//  * counters: per-workgroup partial sums, reduced by a tiny kernel (no same-address atomics).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
@@ -325,14 +333,15 @@ template <int SHADE> struct MarchCfg;
 template <> struct MarchCfg<0> { static constexpr int K = 4, QCAP = 0, KS = 1; };
 template <> struct MarchCfg<1> { static constexpr int K = 3, QCAP = 256, KS = 1; };
 template <> struct MarchCfg<2> { static constexpr int K = 3, QCAP = 256, KS = 4; };
+constexpr int kSpillK = 3, kSpillQCap = 256; // march_spill_kernel
 
-struct ShadeReq { // 32 bytes
-  float px, py, pz; // world-space sample position
-  float s;          // sample value
-  float v;          // transfer-function coordinate
-  float tr;         // transmittance before the sample
+struct ShadeReq { // 32 bytes; after shading the same slot holds the result (cx,cy,cz,gx,gy,gz,a,next)
+  float px, py, pz; // world-space sample position          | colour contribution  tr*clamp01(rgb*shade)
+  float s;          // sample value                           | gradient contribution tr*clamp01(n_c) .x
+  float v;          // transfer-function coordinate           | .y
+  float tr;         // transmittance before the sample        | .z
   float a;          // corrected opacity
-  int next;         // absolute queue position of the owner's next request (valid once that request exists)
+  int next;         // stream position of the owner's next request (valid once that request exists)
 };
 
 __device__ __forceinline__ float bperm(int src_lane, float x)
@@ -341,35 +350,42 @@ __device__ __forceinline__ float bperm(int src_lane, float x)
 }
 __device__ __forceinline__ int bperm_i(int src_lane, int x) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, x); }
 
-template <int VT, int SHADE, bool BIG>
-__global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P)
+__device__ __forceinline__ void setup_consts(const RayMarchParams& P, VolConsts& vc, MarchConsts& mc)
 {
-  using Cfg = MarchCfg<SHADE>;
-  constexpr int K = Cfg::K;
-  constexpr int QCAP = Cfg::QCAP;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  vc.data = P.vol.data;
+  vc.nx1 = P.vol.nx - 1; vc.ny1 = P.vol.ny - 1; vc.nz1 = P.vol.nz - 1;
+  vc.fx1 = (float)vc.nx1; vc.fy1 = (float)vc.ny1; vc.fz1 = (float)vc.nz1;
+  vc.macro_y = 32768u * (unsigned int)P.vol.macros_x;
+  vc.macro_z = 32768ull * (unsigned long long)P.vol.macros_x * (unsigned long long)P.vol.macros_y;
+  vc.cs = ld3(P.coord_scale); vc.cb = ld3(P.coord_bias);
+  vc.vscale = P.vol.value_scale; vc.vmin = P.vol.value_min_clamp;
+  mc.inv_scale = ld3(P.inv_scale); mc.wto_p = ld3(P.wto_p); mc.otw_it = ld3(P.otw_it); mc.light = ld3(P.light);
+  mc.gstep = ld3(P.grad_step);
+  mc.ginv = mk3(1.f / mc.gstep.x, 1.f / mc.gstep.y, 1.f / mc.gstep.z);
+  mc.step = P.step; mc.base = P.base; mc.shadow_stride = P.shadow_stride;
+}
 
-  // ---- LDS carve: [request queues][TF colour][TF alpha]
-  ShadeReq* const queue = reinterpret_cast<ShadeReq*>(lds_raw) + (size_t)wave * (QCAP > 0 ? QCAP : 1);
-  unsigned char* const tf_base = lds_raw + (size_t)kWaves * QCAP * sizeof(ShadeReq);
-  TfConsts tf;
-  {
-    float4* lc = reinterpret_cast<float4*>(tf_base);
-    float* la = reinterpret_cast<float*>(tf_base + (size_t)P.n_color * sizeof(float4));
+// stage the transfer function in LDS (all threads of the workgroup); color may be skipped by alpha-only kernels
+__device__ __forceinline__ void stage_tf(const RayMarchParams& P, unsigned char* tf_base, bool with_color, TfConsts& tf)
+{
+  float4* lc = reinterpret_cast<float4*>(tf_base);
+  float* la = reinterpret_cast<float*>(tf_base + (with_color ? (size_t)P.n_color * sizeof(float4) : 0));
+  if (with_color) {
     const float4* gc = reinterpret_cast<const float4*>(P.tf_color);
     for (int i = threadIdx.x; i < P.n_color; i += kBlock) lc[i] = gc[i];
-    for (int i = threadIdx.x; i < P.n_alpha; i += kBlock) la[i] = P.tf_alpha[i];
-    __syncthreads();
-    tf.color = lc;
-    tf.alpha = la;
   }
+  for (int i = threadIdx.x; i < P.n_alpha; i += kBlock) la[i] = P.tf_alpha[i];
+  __syncthreads();
+  tf.color = lc;
+  tf.alpha = la;
   tf.nc1 = P.n_color - 1; tf.na1 = P.n_alpha - 1;
   tf.fnc1 = (float)tf.nc1; tf.fna1 = (float)tf.na1;
   tf.lower = P.tf_lower; tf.upper = P.tf_upper; tf.scale = P.tf_scale;
+}
 
-  // ---- which pixel does this lane own? (compute_screen_position, shaders_common.h:394-451)
-  int ix, iy;
+// which pixel does this lane own? (compute_screen_position, shaders_common.h:394-451)
+__device__ __forceinline__ bool assign_pixel(const RayMarchParams& P, int lane, int wave, int& ix, int& iy)
+{
   bool active;
   if (P.sparse_xy) {
     const unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
@@ -383,22 +399,152 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
     active = ix < P.width && iy < P.height;
   }
   if (P.world > 1 && active) active = ((ix / P.tile_w + iy / P.tile_h) % P.world) == P.rank;
+  return active;
+}
 
+// accumulation + framebuffer write, shaders_raymarching.cu:389-409
+__device__ __forceinline__ void write_pixel(const RayMarchParams& P, unsigned int pixel_index, f3 o_c, float o_a, f3 o_g)
+{
+  float4 out = make_float4(o_c.x, o_c.y, o_c.z, o_a);
+  float4* fb = reinterpret_cast<float4*>(P.rgba) + pixel_index;
+  if (P.accumulate) {
+    float4* ac = reinterpret_cast<float4*>(P.accum) + pixel_index;
+    if (P.frame_index == 1) {
+      *ac = out;
+    }
+    else {
+      float4 acc = *ac;
+      acc.x += out.x; acc.y += out.y; acc.z += out.z; acc.w += out.w;
+      *ac = acc;
+      const float fi = (float)P.frame_index;
+      out = make_float4(acc.x / fi, acc.y / fi, acc.z / fi, acc.w / fi);
+    }
+  }
+  *fb = out;
+  if (P.grad) {
+    float* pg = P.grad + 3ull * pixel_index;
+    pg[0] = o_g.x; pg[1] = o_g.y; pg[2] = o_g.z;
+  }
+}
+
+// shade one request: gradient (shaders_common.h:195-215), normals, shadow march, Lambert-ish term
+// (shaders_raymarching.cu:124-158).  Writes the result over the request.
+template <int VT, int SHADE, bool BIG>
+__device__ __forceinline__ void shade_request(const RayMarchParams& P, const VolConsts& vc, const TfConsts& tf, const MarchConsts& mc, ShadeReq& r,
+                                              unsigned int& n_shadow)
+{
+  const f3 pos = mk3(r.px, r.py, r.pz);
+  const f3 po = to_object(mc, pos);
+  // one-sided differences, flipped at the upper bound; the three taps are issued together
+  const bool flx = (po.x + mc.gstep.x) > 1.f, fly = (po.y + mc.gstep.y) > 1.f, flz = (po.z + mc.gstep.z) > 1.f;
+  Tap tgx, tgy, tgz;
+  tap_issue<VT, BIG>(vc, mk3(po.x + (flx ? -mc.gstep.x : mc.gstep.x), po.y, po.z), tgx);
+  tap_issue<VT, BIG>(vc, mk3(po.x, po.y + (fly ? -mc.gstep.y : mc.gstep.y), po.z), tgy);
+  tap_issue<VT, BIG>(vc, mk3(po.x, po.y, po.z + (flz ? -mc.gstep.z : mc.gstep.z)), tgz);
+  const f3 rgb = tf_color(tf, r.v);
+  f3 g;
+  g.x = (tap_finish<VT>(vc, tgx) - r.s) * (flx ? -mc.ginv.x : mc.ginv.x);
+  g.y = (tap_finish<VT>(vc, tgy) - r.s) * (fly ? -mc.ginv.y : mc.ginv.y);
+  g.z = (tap_finish<VT>(vc, tgz) - r.s) * (flz ? -mc.ginv.z : mc.ginv.z);
+  const f3 gn = normalize3(g);
+  const f3 n_o = mk3(-gn.x, -gn.y, -gn.z);
+  const f3 n_w = normalize3(mk3(n_o.x * mc.otw_it.x, n_o.y * mc.otw_it.y, n_o.z * mc.otw_it.z));
+  f3 n_c = mk3(0, 0, 0);
+  if (P.grad) {
+    const float* m = P.wtc_it;
+    n_c = normalize3(mk3(fmaf(n_w.x, m[0], fmaf(n_w.y, m[3], n_w.z * m[6])), fmaf(n_w.x, m[1], fmaf(n_w.y, m[4], n_w.z * m[7])),
+                         fmaf(n_w.x, m[2], fmaf(n_w.y, m[5], n_w.z * m[8]))));
+  }
+  float shadow = 0.f;
+  if (SHADE == 2) shadow = march_shadow<VT, BIG, MarchCfg<2>::KS>(vc, tf, mc, pos, n_shadow);
+  const float cosNL = fabsf(dot3(mc.light, n_w));
+  const float shade = 0.5f + 0.5f * cosNL * 2.f * (1.f - shadow); // shaders_raymarching.cu:156-157
+  const float tr = r.tr;
+  r.px = tr * clamp01(rgb.x * shade);
+  r.py = tr * clamp01(rgb.y * shade);
+  r.pz = tr * clamp01(rgb.z * shade);
+  r.s = tr * clamp01(n_c.x);
+  r.v = tr * clamp01(n_c.y);
+  r.tr = tr * clamp01(n_c.z);
+}
+
+// hand the contributions of one shaded batch (stream positions [base, base + n), result of position base + j in lane j)
+// back to the owning lanes: every owner walks its own requests of this batch in sample order
+__device__ __forceinline__ void apply_batch(const ShadeReq& res, unsigned int base, unsigned int n, int lane, int& pend, unsigned int& first, f3& color,
+                                            f3& gradient)
+{
+  for (;;) {
+    const bool has = (pend > 0) && ((first - base) < n);
+    if (__ballot(has) == 0ull) break;
+    const int j = has ? (int)(first - base) : lane;
+    const float tcx = bperm(j, res.px), tcy = bperm(j, res.py), tcz = bperm(j, res.pz);
+    const float tgx = bperm(j, res.s), tgy = bperm(j, res.v), tgz = bperm(j, res.tr);
+    const float ta = bperm(j, res.a);
+    const int tn = bperm_i(j, res.next);
+    if (has) {
+      color.x = fmaf(tcx, ta, color.x);
+      color.y = fmaf(tcy, ta, color.y);
+      color.z = fmaf(tcz, ta, color.z);
+      gradient.x = fmaf(tgx, ta, gradient.x);
+      gradient.y = fmaf(tgy, ta, gradient.y);
+      gradient.z = fmaf(tgz, ta, gradient.z);
+      first = (unsigned int)tn;
+      --pend;
+    }
+  }
+}
+
+// per-wave counters -> LDS -> one plain store of the workgroup's partial sums (lds must hold kWaves*5 uints)
+__device__ __forceinline__ void store_block_counters(const RayMarchParams& P, unsigned int* red, int lane, int wave, unsigned int n_rays,
+                                                     unsigned int n_samples, unsigned int n_shaded, unsigned int n_shadow, unsigned int n_active)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n_rays += __shfl_down(n_rays, off);
+    n_samples += __shfl_down(n_samples, off);
+    n_shaded += __shfl_down(n_shaded, off);
+    n_shadow += __shfl_down(n_shadow, off);
+    n_active += __shfl_down(n_active, off);
+  }
+  if (!P.block_counters) return;
+  __syncthreads(); // LDS is dead at this point: reuse its front
+  if (lane == 0) {
+    red[wave * 5 + 0] = n_rays; red[wave * 5 + 1] = n_samples; red[wave * 5 + 2] = n_shaded;
+    red[wave * 5 + 3] = n_shadow; red[wave * 5 + 4] = n_active;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    const unsigned int bid = blockIdx.x + blockIdx.y * gridDim.x;
+    unsigned int sum = 0;
+    for (int w = 0; w < kWaves; ++w) sum += red[w * 5 + threadIdx.x];
+    P.block_counters[(size_t)bid * 5 + threadIdx.x] = sum;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// in-place pipeline: march + shade + composite in one kernel
+// ------------------------------------------------------------------------------------------------------------------
+template <int VT, int SHADE, bool BIG>
+__global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P)
+{
+  using Cfg = MarchCfg<SHADE>;
+  constexpr int K = Cfg::K;
+  constexpr int QCAP = Cfg::QCAP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long t_start = P.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+
+  // ---- LDS carve: [request queues][TF colour][TF alpha]
+  ShadeReq* const queue = reinterpret_cast<ShadeReq*>(lds_raw) + (size_t)wave * (QCAP > 0 ? QCAP : 1);
+  TfConsts tf;
+  stage_tf(P, lds_raw + (size_t)kWaves * QCAP * sizeof(ShadeReq), true, tf);
+
+  int ix, iy;
+  const bool active = assign_pixel(P, lane, wave, ix, iy);
   unsigned int n_rays = 0, n_samples = 0, n_shaded = 0, n_shadow = 0;
-
   VolConsts vc;
-  vc.data = P.vol.data;
-  vc.nx1 = P.vol.nx - 1; vc.ny1 = P.vol.ny - 1; vc.nz1 = P.vol.nz - 1;
-  vc.fx1 = (float)vc.nx1; vc.fy1 = (float)vc.ny1; vc.fz1 = (float)vc.nz1;
-  vc.macro_y = 32768u * (unsigned int)P.vol.macros_x;
-  vc.macro_z = 32768ull * (unsigned long long)P.vol.macros_x * (unsigned long long)P.vol.macros_y;
-  vc.cs = ld3(P.coord_scale); vc.cb = ld3(P.coord_bias);
-  vc.vscale = P.vol.value_scale; vc.vmin = P.vol.value_min_clamp;
   MarchConsts mc;
-  mc.inv_scale = ld3(P.inv_scale); mc.wto_p = ld3(P.wto_p); mc.otw_it = ld3(P.otw_it); mc.light = ld3(P.light);
-  mc.gstep = ld3(P.grad_step);
-  mc.ginv = mk3(1.f / mc.gstep.x, 1.f / mc.gstep.y, 1.f / mc.gstep.z);
-  mc.step = P.step; mc.base = P.base; mc.shadow_stride = P.shadow_stride;
+  setup_consts(P, vc, mc);
 
   const float rsx = 1.f / (float)P.width, rsy = 1.f / (float)P.height;
   const float scx = ((float)ix + .5f) * rsx, scy = ((float)iy + .5f) * rsy;
@@ -410,7 +556,7 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
   float o_a = 0.f;
   f3 o_c = mk3(0, 0, 0), o_g = mk3(0, 0, 0);
   const int spp = P.spp;
-  // wave-uniform queue cursors (absolute positions; slot = position & (QCAP - 1))
+  // wave-uniform queue cursors (stream positions; slot = position & (QCAP - 1))
   unsigned int q_head = 0, q_tail = 0;
 
   for (int k_spp = 0; k_spp < spp; ++k_spp) { // uniform trip count: every lane of the wave runs every round
@@ -432,7 +578,7 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
     if (active) ++n_rays;
     float tx = t0, ty = fminf(t1, t0 + mc.step);
     int pend = 0;                 // this lane's requests not yet applied
-    unsigned int first = 0, last = 0; // absolute queue positions of its oldest unapplied / newest request
+    unsigned int first = 0, last = 0; // stream positions of its oldest unapplied / newest request
 
     for (;;) {
       // ---- (1) shade queued requests: a full batch whenever 64 are queued, the remainder once no ray is live
@@ -440,68 +586,14 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
         const bool any_live = __ballot(live) != 0ull;
         while ((q_tail - q_head) >= 64u || (!any_live && q_tail != q_head)) {
           const unsigned int n = min(q_tail - q_head, 64u);
-          const bool worker = (unsigned int)lane < n;
-          float cx = 0.f, cy = 0.f, cz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, ra = 0.f;
-          int rnext = 0;
           __builtin_amdgcn_wave_barrier(); // requests were written by other lanes of this wave (LDS ops are in order)
-          if (worker) {
-            const ShadeReq r = queue[(q_head + lane) & (QCAP - 1)];
-            ra = r.a;
-            rnext = r.next;
-            const f3 pos = mk3(r.px, r.py, r.pz);
-            const f3 po = to_object(mc, pos);
-            // compute_volume_gradient_object_space, shaders_common.h:195-215 (one-sided, flipped at the upper bound);
-            // the three taps are issued together
-            const bool flx = (po.x + mc.gstep.x) > 1.f, fly = (po.y + mc.gstep.y) > 1.f, flz = (po.z + mc.gstep.z) > 1.f;
-            Tap tgx, tgy, tgz;
-            tap_issue<VT, BIG>(vc, mk3(po.x + (flx ? -mc.gstep.x : mc.gstep.x), po.y, po.z), tgx);
-            tap_issue<VT, BIG>(vc, mk3(po.x, po.y + (fly ? -mc.gstep.y : mc.gstep.y), po.z), tgy);
-            tap_issue<VT, BIG>(vc, mk3(po.x, po.y, po.z + (flz ? -mc.gstep.z : mc.gstep.z)), tgz);
-            f3 rgb = tf_color(tf, r.v);
-            f3 g;
-            g.x = (tap_finish<VT>(vc, tgx) - r.s) * (flx ? -mc.ginv.x : mc.ginv.x);
-            g.y = (tap_finish<VT>(vc, tgy) - r.s) * (fly ? -mc.ginv.y : mc.ginv.y);
-            g.z = (tap_finish<VT>(vc, tgz) - r.s) * (flz ? -mc.ginv.z : mc.ginv.z);
-            const f3 gn = normalize3(g);
-            const f3 n_o = mk3(-gn.x, -gn.y, -gn.z);
-            const f3 n_w = normalize3(mk3(n_o.x * mc.otw_it.x, n_o.y * mc.otw_it.y, n_o.z * mc.otw_it.z));
-            f3 n_c = mk3(0, 0, 0);
-            if (P.grad) {
-              const float* m = P.wtc_it;
-              n_c = normalize3(mk3(fmaf(n_w.x, m[0], fmaf(n_w.y, m[3], n_w.z * m[6])), fmaf(n_w.x, m[1], fmaf(n_w.y, m[4], n_w.z * m[7])),
-                                   fmaf(n_w.x, m[2], fmaf(n_w.y, m[5], n_w.z * m[8]))));
-            }
-            float shadow = 0.f;
-            if (SHADE == 2) shadow = march_shadow<VT, BIG, Cfg::KS>(vc, tf, mc, pos, n_shadow);
-            const float cosNL = fabsf(dot3(mc.light, n_w));
-            const float shade = 0.5f + 0.5f * cosNL * 2.f * (1.f - shadow); // shaders_raymarching.cu:156-157
-            cx = r.tr * clamp01(rgb.x * shade);
-            cy = r.tr * clamp01(rgb.y * shade);
-            cz = r.tr * clamp01(rgb.z * shade);
-            gx = r.tr * clamp01(n_c.x);
-            gy = r.tr * clamp01(n_c.y);
-            gz = r.tr * clamp01(n_c.z);
+          ShadeReq r;
+          r.px = r.py = r.pz = r.s = r.v = r.tr = r.a = 0.f; r.next = 0;
+          if ((unsigned int)lane < n) {
+            r = queue[(q_head + lane) & (QCAP - 1)];
+            shade_request<VT, SHADE, BIG>(P, vc, tf, mc, r, n_shadow);
           }
-          // hand the contributions back: every owner walks its own requests of this batch in sample order
-          for (;;) {
-            const bool has = (pend > 0) && ((first - q_head) < n);
-            if (__ballot(has) == 0ull) break;
-            const int j = has ? (int)(first - q_head) : lane;
-            const float tcx = bperm(j, cx), tcy = bperm(j, cy), tcz = bperm(j, cz);
-            const float tgx2 = bperm(j, gx), tgy2 = bperm(j, gy), tgz2 = bperm(j, gz);
-            const float ta = bperm(j, ra);
-            const int tn = bperm_i(j, rnext);
-            if (has) {
-              color.x = fmaf(tcx, ta, color.x);
-              color.y = fmaf(tcy, ta, color.y);
-              color.z = fmaf(tcz, ta, color.z);
-              gradient.x = fmaf(tgx2, ta, gradient.x);
-              gradient.y = fmaf(tgy2, ta, gradient.y);
-              gradient.z = fmaf(tgz2, ta, gradient.z);
-              first = (unsigned int)tn;
-              --pend;
-            }
-          }
+          apply_batch(r, q_head, n, lane, pend, first, color, gradient);
           q_head += n;
         }
         if (!any_live) break;
@@ -527,33 +619,27 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
       }
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        bool push = false;
-        float s = 0.f, v = 0.f, a = 0.f, tr = 0.f;
-        if (live && valid[k] && (alpha < 0.9999f)) { // the reference's loop condition, shaders_raymarching.cu:110
-          s = tap_finish<VT>(vc, taps[k]);
-          v = tf_coord(tf, s);
-          a = opacity_correction(tf_alpha(tf, v), mc.base * dts[k]);
-          ++n_samples;
-          // A sample whose corrected opacity is exactly 0 adds exactly 0 to colour, gradient and alpha (its colour
-          // passes through clamp01 first, so it is finite): nothing is shaded for it.
-          if (a > 0.f) {
-            ++n_shaded;
-            tr = 1.f - alpha;
-            if (SHADE == 0) {
-              const f3 rgb = tf_color(tf, v);
-              color.x = fmaf(tr * clamp01(rgb.x), a, color.x);
-              color.y = fmaf(tr * clamp01(rgb.y), a, color.y);
-              color.z = fmaf(tr * clamp01(rgb.z), a, color.z);
-            }
-            else {
-              push = true;
-            }
-            alpha = fmaf(tr, a, alpha);
+        // branch-free sample processing (see march_shadow): the tap's loads must stay where they were issued
+        const float s = tap_finish<VT>(vc, taps[k]);
+        const float v = tf_coord(tf, s);
+        float a = opacity_correction(tf_alpha(tf, v), mc.base * dts[k]);
+        live = live && valid[k] && (alpha < 0.9999f); // the reference's loop condition, shaders_raymarching.cu:110
+        a = live ? a : 0.f;
+        n_samples += live ? 1u : 0u;
+        // A sample whose corrected opacity is exactly 0 adds exactly 0 to colour, gradient and alpha (its colour
+        // passes through clamp01 first, so it is finite): nothing is shaded for it.
+        const bool push = a > 0.f;
+        n_shaded += push ? 1u : 0u;
+        const float tr = 1.f - alpha;
+        if (SHADE == 0) {
+          if (push) {
+            const f3 rgb = tf_color(tf, v);
+            color.x = fmaf(tr * clamp01(rgb.x), a, color.x);
+            color.y = fmaf(tr * clamp01(rgb.y), a, color.y);
+            color.z = fmaf(tr * clamp01(rgb.z), a, color.z);
           }
         }
-        else {
-          live = false;
-        }
+        alpha = push ? fmaf(tr, a, alpha) : alpha;
         if (SHADE != 0) {
           const unsigned long long m = __ballot(push);
           if (m != 0ull) {
@@ -586,59 +672,224 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
     o_a *= rspp;
     o_c.x *= rspp; o_c.y *= rspp; o_c.z *= rspp;
     o_g.x *= rspp; o_g.y *= rspp; o_g.z *= rspp;
-
-    // accumulation, shaders_raymarching.cu:389-403
-    float4 out = make_float4(o_c.x, o_c.y, o_c.z, o_a);
-    float4* fb = reinterpret_cast<float4*>(P.rgba) + pixel_index;
-    if (P.accumulate) {
-      float4* ac = reinterpret_cast<float4*>(P.accum) + pixel_index;
-      if (P.frame_index == 1) {
-        *ac = out;
-      }
-      else {
-        float4 acc = *ac;
-        acc.x += out.x; acc.y += out.y; acc.z += out.z; acc.w += out.w;
-        *ac = acc;
-        const float fi = (float)P.frame_index;
-        out = make_float4(acc.x / fi, acc.y / fi, acc.z / fi, acc.w / fi);
-      }
-    }
-    *fb = out;
-    if (P.grad) {
-      float* pg = P.grad + 3ull * pixel_index;
-      pg[0] = o_g.x; pg[1] = o_g.y; pg[2] = o_g.z;
-    }
+    write_pixel(P, pixel_index, o_c, o_a, o_g);
   }
 
-  // ---- counters: wave reduction -> LDS -> one plain store of the workgroup's partial sums
-  unsigned int n_active = active ? 1u : 0u;
+  if (P.trace && lane == 0) { // diagnostic only (OVR_HIP_TRACE): per-wave residency interval and work, never read by the kernel
+    const unsigned int bid = blockIdx.x + blockIdx.y * gridDim.x;
+    unsigned long long* t = P.trace + ((size_t)bid * kWaves + wave) * 4;
+    t[0] = t_start; t[1] = __builtin_amdgcn_s_memrealtime();
+    t[2] = ((unsigned long long)n_samples << 32) | n_shaded; t[3] = n_shadow;
+  }
+  store_block_counters(P, reinterpret_cast<unsigned int*>(lds_raw), lane, wave, n_rays, n_samples, n_shaded, n_shadow, active ? 1u : 0u);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// pooled pipeline, kernel A: primary march; full batches of 64 requests are spilled to the global pool as chunks
+// ------------------------------------------------------------------------------------------------------------------
+template <int VT, bool BIG>
+__global__ __launch_bounds__(kBlock) void march_spill_kernel(const RayMarchParams P)
+{
+  constexpr int K = kSpillK;
+  constexpr int QCAP = kSpillQCap;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  ShadeReq* const queue = reinterpret_cast<ShadeReq*>(lds_raw) + (size_t)wave * QCAP;
+  TfConsts tf;
+  stage_tf(P, lds_raw + (size_t)kWaves * QCAP * sizeof(ShadeReq), false, tf); // alpha table only
+
+  int ix, iy;
+  const bool active = assign_pixel(P, lane, wave, ix, iy);
+  unsigned int n_rays = 0, n_samples = 0, n_shaded = 0;
+  VolConsts vc;
+  MarchConsts mc;
+  setup_consts(P, vc, mc);
+  const PoolDesc& Q = P.pool;
+  const unsigned int tile = (blockIdx.x + blockIdx.y * gridDim.x) * kWaves + wave;
+
+  const float rsx = 1.f / (float)P.width, rsy = 1.f / (float)P.height;
+  const float scx = ((float)ix + .5f) * rsx, scy = ((float)iy + .5f) * rsy;
+  const unsigned int pixel_index = (unsigned int)ix + (unsigned int)iy * (unsigned int)P.width;
+  const f3 org = ld3(P.cam_pos), cdir = ld3(P.cam_dir), chor = ld3(P.cam_hor), cver = ld3(P.cam_ver);
+  const f3 oo = to_object(mc, org);
+  const float ux = scx - 0.5f, uy = scy - 0.5f; // spp == 1: no jitter (shaders_raymarching.cu:354)
+  const f3 dir = normalize3_exact(mk3(cdir.x + ux * chor.x + uy * cver.x, cdir.y + ux * chor.y + uy * cver.y,
+                                      cdir.z + ux * chor.z + uy * cver.z));
+  const f3 od = mk3(dir.x * mc.inv_scale.x, dir.y * mc.inv_scale.y, dir.z * mc.inv_scale.z);
+  float t0 = 0.f, t1 = FLT_MAX;
+  float alpha = 0.f;
+  bool live = active && intersect_unit_box(t0, t1, oo, od);
+  if (active) ++n_rays;
+  float tx = t0, ty = fminf(t1, t0 + mc.step);
+  int pend = 0;
+  unsigned int first = 0, last = 0;
+  unsigned int last_gidx = 0;  // pool index of this lane's newest request once it has been spilled
+  unsigned int q_head = 0, q_tail = 0;
+  int prev_chunk = -1;
+  if (lane == 0) Q.tile_first[tile] = -1;
+
+  for (;;) {
+    const bool any_live = __ballot(live) != 0ull;
+    // ---- (1) spill: a full chunk whenever 64 requests are queued, the remainder once no ray is live
+    while ((q_tail - q_head) >= 64u || (!any_live && q_tail != q_head)) {
+      const unsigned int n = min(q_tail - q_head, 64u);
+      unsigned int c = 0;
+      if (lane == 0) c = atomicAdd(&Q.ctrl[0], 1u);
+      c = (unsigned int)__builtin_amdgcn_readfirstlane((int)c);
+      if (c < Q.capacity) {
+        __builtin_amdgcn_wave_barrier();
+        if ((unsigned int)lane < n) Q.reqs[(size_t)c * 64 + lane] = queue[(q_head + lane) & (QCAP - 1)];
+        if (lane == 0) {
+          Q.chunk_n[c] = n;
+          if (prev_chunk >= 0) Q.chunk_next[prev_chunk] = (int)c; else Q.tile_first[tile] = (int)c;
+        }
+        if (pend > 0 && (last - q_head) < n) last_gidx = c * 64u + (last - q_head);
+        prev_chunk = (int)c;
+      }
+      // c >= capacity: the pool is exhausted; ctrl[0] keeps counting so the host knows how much was needed, re-sizes
+      // the pool and renders the frame again (ovr_hip_api.cpp) - nothing of this frame is used
+      q_head += n;
+    }
+    if (!any_live) break;
+
+    // ---- (2) primary march: K samples, loads first
+    Tap taps[K];
+    f3 poss[K];
+    float dts[K];
+    bool valid[K];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    n_rays += __shfl_down(n_rays, off);
-    n_samples += __shfl_down(n_samples, off);
-    n_shaded += __shfl_down(n_shaded, off);
-    n_shadow += __shfl_down(n_shadow, off);
-    n_active += __shfl_down(n_active, off);
+    for (int k = 0; k < K; ++k) {
+      valid[k] = ty > tx;
+      dts[k] = ty - tx;
+      const float tm = 0.5f * (tx + ty);
+      poss[k] = mk3(fmaf(tm, dir.x, org.x), fmaf(tm, dir.y, org.y), fmaf(tm, dir.z, org.z));
+      tap_issue<VT, BIG>(vc, to_object(mc, poss[k]), taps[k]);
+      tx = ty;
+      ty = fminf(tx + mc.step, t1);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      // branch-free sample processing (see march_shadow)
+      const float s = tap_finish<VT>(vc, taps[k]);
+      const float v = tf_coord(tf, s);
+      float a = opacity_correction(tf_alpha(tf, v), mc.base * dts[k]);
+      live = live && valid[k] && (alpha < 0.9999f);
+      a = live ? a : 0.f;
+      n_samples += live ? 1u : 0u;
+      const bool push = a > 0.f;
+      n_shaded += push ? 1u : 0u;
+      const float tr = 1.f - alpha;
+      alpha = push ? fmaf(tr, a, alpha) : alpha;
+      const unsigned long long m = __ballot(push);
+      if (m != 0ull) {
+        if (push) {
+          const unsigned int pos_q = q_tail + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+          ShadeReq r;
+          r.px = poss[k].x; r.py = poss[k].y; r.pz = poss[k].z;
+          r.s = s; r.v = v; r.tr = tr; r.a = a; r.next = 0;
+          queue[pos_q & (QCAP - 1)] = r;
+          if (pend > 0) {
+            if ((int)(last - q_head) >= 0) queue[last & (QCAP - 1)].next = (int)pos_q; // still in LDS
+            else Q.reqs[last_gidx].next = (int)pos_q;                                 // already spilled
+          }
+          else {
+            first = pos_q;
+          }
+          last = pos_q;
+          ++pend;
+        }
+        q_tail += (unsigned int)__popcll(m);
+      }
+    }
   }
-  if (P.block_counters) {
-    __syncthreads(); // the queues are dead: reuse the front of LDS
-    unsigned int* red = reinterpret_cast<unsigned int*>(lds_raw);
-    if (lane == 0) {
-      red[wave * 5 + 0] = n_rays; red[wave * 5 + 1] = n_samples; red[wave * 5 + 2] = n_shaded;
-      red[wave * 5 + 3] = n_shadow; red[wave * 5 + 4] = n_active;
+
+  if (lane == 0) Q.tile_count[tile] = q_tail;
+  if (active) Q.pix_state[pixel_index] = make_float4(alpha, __uint_as_float(first), __int_as_float(pend), 0.f);
+  store_block_counters(P, reinterpret_cast<unsigned int*>(lds_raw), lane, wave, n_rays, n_samples, n_shaded, 0u, active ? 1u : 0u);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// pooled pipeline, kernel B: persistent waves shade chunks from all tiles; one returning atomic per chunk
+// ------------------------------------------------------------------------------------------------------------------
+template <int VT, int SHADE, bool BIG>
+__global__ __launch_bounds__(kBlock) void shade_pool_kernel(const RayMarchParams P)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  TfConsts tf;
+  stage_tf(P, lds_raw, true, tf);
+  VolConsts vc;
+  MarchConsts mc;
+  setup_consts(P, vc, mc);
+  const PoolDesc& Q = P.pool;
+  const unsigned int n_chunks = Q.ctrl[0] > Q.capacity ? 0u : Q.ctrl[0]; // overflow: the frame is re-rendered, skip the work
+  unsigned int n_shadow = 0;
+  for (;;) {
+    unsigned int c = 0;
+    if (lane == 0) c = atomicAdd(&Q.ctrl[1], 1u);
+    c = (unsigned int)__builtin_amdgcn_readfirstlane((int)c);
+    if (c >= n_chunks) break; // every wave reaches this: the cursor only grows
+    const unsigned int n = Q.chunk_n[c];
+    if ((unsigned int)lane < n) {
+      ShadeReq r = Q.reqs[(size_t)c * 64 + lane];
+      shade_request<VT, SHADE, BIG>(P, vc, tf, mc, r, n_shadow);
+      Q.reqs[(size_t)c * 64 + lane] = r;
     }
-    __syncthreads();
-    if (threadIdx.x < 5) {
-      const unsigned int bid = blockIdx.x + blockIdx.y * gridDim.x;
-      unsigned int sum = 0;
-      for (int w = 0; w < kWaves; ++w) sum += red[w * 5 + threadIdx.x];
-      P.block_counters[(size_t)bid * 5 + threadIdx.x] = sum;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) n_shadow += __shfl_down(n_shadow, off);
+  __syncthreads();
+  unsigned int* red = reinterpret_cast<unsigned int*>(lds_raw);
+  if (lane == 0) red[wave] = n_shadow;
+  __syncthreads();
+  if (threadIdx.x == 0 && Q.shade_counters) Q.shade_counters[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// pooled pipeline, kernel C: every tile walks its chunks in order, composites and writes its pixels
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void composite_kernel(const RayMarchParams P)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int ix, iy;
+  const bool active = assign_pixel(P, lane, wave, ix, iy);
+  const PoolDesc& Q = P.pool;
+  if (Q.ctrl[0] > Q.capacity) return; // pool overflow: the host re-renders this frame with a larger pool, nothing may be written
+  const unsigned int tile = (blockIdx.x + blockIdx.y * gridDim.x) * kWaves + wave;
+  const unsigned int pixel_index = (unsigned int)ix + (unsigned int)iy * (unsigned int)P.width;
+  float alpha = 0.f;
+  unsigned int first = 0;
+  int pend = 0;
+  if (active) {
+    const float4 st = Q.pix_state[pixel_index];
+    alpha = st.x; first = __float_as_uint(st.y); pend = __float_as_int(st.z);
+  }
+  f3 color = mk3(0, 0, 0), gradient = mk3(0, 0, 0);
+  const unsigned int total = Q.tile_count[tile];
+  int c = Q.tile_first[tile];
+  for (unsigned int base = 0; base < total; base += 64u) {
+    const unsigned int n = min(total - base, 64u);
+    ShadeReq r;
+    r.px = r.py = r.pz = r.s = r.v = r.tr = r.a = 0.f; r.next = 0;
+    if ((unsigned int)lane < n) r = Q.reqs[(size_t)c * 64 + lane];
+    const int c_next = Q.chunk_next[c];
+    apply_batch(r, base, n, lane, pend, first, color, gradient);
+    c = c_next;
+  }
+  if (active) {
+    f3 o_c = mk3(0, 0, 0), o_g = mk3(0, 0, 0);
+    if (alpha > 0.f) {
+      o_c = mk3(color.x / alpha, color.y / alpha, color.z / alpha);
+      o_g = mk3(gradient.x / alpha, gradient.y / alpha, gradient.z / alpha);
     }
+    // spp == 1: (x + 0) * (1 / 1) is exact, so this equals the in-place kernel's o_c * rspp bit for bit
+    write_pixel(P, pixel_index, o_c, alpha, o_g);
   }
 }
 
 // sums the per-workgroup partials into counters[0..4] (one workgroup; deterministic)
-__global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned int* __restrict__ partials, int n_blocks, unsigned long long* counters)
+__global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned int* __restrict__ partials, int n_blocks, const unsigned int* __restrict__ shade_partials,
+                                                             int n_shade_blocks, unsigned long long* counters)
 {
   __shared__ unsigned long long red[4][5];
   unsigned long long acc[5] = { 0, 0, 0, 0, 0 };
@@ -646,6 +897,8 @@ __global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned int
 #pragma unroll
     for (int c = 0; c < 5; ++c) acc[c] += partials[(size_t)b * 5 + c];
   }
+  if (shade_partials)
+    for (int b = threadIdx.x; b < n_shade_blocks; b += 256) acc[3] += shade_partials[b];
 #pragma unroll
   for (int c = 0; c < 5; ++c) {
     for (int off = 32; off > 0; off >>= 1) acc[c] += __shfl_down(acc[c], off);
@@ -674,62 +927,101 @@ size_t raymarch_grid_blocks(const RayMarchParams& p)
   return (size_t)((p.width + 15) / 16) * (size_t)((p.height + 15) / 16);
 }
 
+static dim3 raymarch_grid(const RayMarchParams& p)
+{
+  if (p.sparse_xy) return dim3((unsigned)(((size_t)p.width * p.height + kBlock - 1) / kBlock));
+  return dim3((unsigned)((p.width + 15) / 16), (unsigned)((p.height + 15) / 16));
+}
+
+template <typename KernT>
+static hipError_t set_lds(KernT kern, size_t lds)
+{
+  if (lds > 64 * 1024) return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  return hipSuccess;
+}
+
+constexpr int kShadeBlocks = 1024; // persistent shade grid: 4 workgroups per CU
+
 template <int VT, int SHADE, bool BIG>
-static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream)
+static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const hipEvent_t* ev)
 {
   const size_t tf_lds = raymarch_lds_bytes(p.n_color, p.n_alpha);
   if (tf_lds == 0) return hipErrorInvalidValue;
-  const size_t lds = std::max<size_t>(tf_lds + queue_lds_bytes<SHADE>(), 64); // >= 64 B: the counter reduction reuses it
-  dim3 grid, block(kBlock);
-  if (p.sparse_xy) {
-    grid = dim3((unsigned)(((size_t)p.width * p.height + kBlock - 1) / kBlock));
+  const dim3 grid = raymarch_grid(p), block(kBlock);
+  hipError_t e;
+  const bool pooled = (SHADE != 0) && p.pool.reqs != nullptr && p.spp == 1;
+  if (!pooled) {
+    const size_t lds = std::max<size_t>(tf_lds + queue_lds_bytes<SHADE>(), 64); // >= 64 B: the counter reduction reuses it
+    auto kern = raymarch_kernel<VT, SHADE, BIG>;
+    if ((e = set_lds(kern, lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (ev) { (void)hipEventRecord(ev[1], stream); (void)hipEventRecord(ev[2], stream); }
+    if (p.block_counters && p.counters)
+      hipLaunchKernelGGL(reduce_counters_kernel, dim3(1), dim3(256), 0, stream, p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)nullptr, 0, p.counters);
+    return hipGetLastError();
   }
-  else {
-    grid = dim3((unsigned)((p.width + 15) / 16), (unsigned)((p.height + 15) / 16));
+  // ---- pooled pipeline
+  if ((e = hipMemsetAsync(p.pool.ctrl, 0, 4 * sizeof(unsigned int), stream)) != hipSuccess) return e;
+  {
+    const size_t lds = (size_t)kWaves * kSpillQCap * sizeof(ShadeReq) + (size_t)p.n_alpha * sizeof(float);
+    auto kern = march_spill_kernel<VT, BIG>;
+    if ((e = set_lds(kern, lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
   }
-  auto kern = raymarch_kernel<VT, SHADE, BIG>;
-  if (lds > 64 * 1024) {
-    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (ea != hipSuccess) return ea;
+  if (ev) (void)hipEventRecord(ev[1], stream);
+  {
+    const size_t lds = std::max<size_t>(tf_lds, 64);
+    auto kern = shade_pool_kernel<VT, SHADE, BIG>;
+    if ((e = set_lds(kern, lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(kShadeBlocks), block, lds, stream, p);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  if (p.block_counters && p.counters) {
-    hipLaunchKernelGGL(reduce_counters_kernel, dim3(1), dim3(256), 0, stream, p.block_counters, (int)raymarch_grid_blocks(p), p.counters);
-    e = hipGetLastError();
-  }
-  return e;
+  if (ev) (void)hipEventRecord(ev[2], stream);
+  hipLaunchKernelGGL(composite_kernel, grid, block, 0, stream, p);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if (p.block_counters && p.counters)
+    hipLaunchKernelGGL(reduce_counters_kernel, dim3(1), dim3(256), 0, stream, p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)p.pool.shade_counters,
+                       kShadeBlocks, p.counters);
+  return hipGetLastError();
 }
 
 template <int VT, int SHADE>
-static hipError_t launch_vs(const RayMarchParams& p, hipStream_t stream)
+static hipError_t launch_vs(const RayMarchParams& p, hipStream_t stream, const hipEvent_t* ev)
 {
   // 32-bit byte offsets (SGPR base + VGPR offset loads) whenever the bricked volume is smaller than 4 GiB
-  if (p.vol.bytes <= 0xffffffffull) return launch_vsb<VT, SHADE, false>(p, stream);
-  return launch_vsb<VT, SHADE, true>(p, stream);
+  if (p.vol.bytes <= 0xffffffffull) return launch_vsb<VT, SHADE, false>(p, stream, ev);
+  return launch_vsb<VT, SHADE, true>(p, stream, ev);
 }
 
 template <int VT>
-static hipError_t launch_v(const RayMarchParams& p, hipStream_t stream)
+static hipError_t launch_v(const RayMarchParams& p, hipStream_t stream, const hipEvent_t* ev)
 {
   switch (p.shading) {
-  case 0: return launch_vs<VT, 0>(p, stream);
-  case 1: return launch_vs<VT, 1>(p, stream);
-  default: return launch_vs<VT, 2>(p, stream);
+  case 0: return launch_vs<VT, 0>(p, stream, ev);
+  case 1: return launch_vs<VT, 1>(p, stream, ev);
+  default: return launch_vs<VT, 2>(p, stream, ev);
   }
 }
 
-hipError_t launch_raymarch(const RayMarchParams& p, hipStream_t stream)
+size_t pool_shade_blocks() { return kShadeBlocks; }
+
+hipError_t launch_raymarch(const RayMarchParams& p, hipStream_t stream, const hipEvent_t* ev)
 {
+  // ev (optional): ev[0] before the first kernel, ev[1] after the march, ev[2] after the shade kernel, ev[3] at the end
+  if (ev) (void)hipEventRecord(ev[0], stream);
+  hipError_t e;
   switch (p.vol.type) {
-  case VOX_U8: return launch_v<VOX_U8>(p, stream);
-  case VOX_I8: return launch_v<VOX_I8>(p, stream);
-  case VOX_U16: return launch_v<VOX_U16>(p, stream);
-  case VOX_I16: return launch_v<VOX_I16>(p, stream);
-  case VOX_F32: return launch_v<VOX_F32>(p, stream);
-  default: return hipErrorInvalidValue;
+  case VOX_U8: e = launch_v<VOX_U8>(p, stream, ev); break;
+  case VOX_I8: e = launch_v<VOX_I8>(p, stream, ev); break;
+  case VOX_U16: e = launch_v<VOX_U16>(p, stream, ev); break;
+  case VOX_I16: e = launch_v<VOX_I16>(p, stream, ev); break;
+  case VOX_F32: e = launch_v<VOX_F32>(p, stream, ev); break;
+  default: e = hipErrorInvalidValue;
   }
+  if (ev) (void)hipEventRecord(ev[3], stream);
+  return e;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -178,6 +178,10 @@ class DeviceHIP:
     def set_shading(self, mode):
         L.check(self._lib.ovr_hip_set_shading(self._h, int(mode)))
 
+    def set_shading_pipeline(self, mode):
+        """0 auto, 1 in place, 2 pooled (include/ovr_hip.h) - both produce bit-identical frames"""
+        L.check(self._lib.ovr_hip_set_shading_pipeline(self._h, int(mode)))
+
     def set_grid_convention(self, convention):
         L.check(self._lib.ovr_hip_set_grid_convention(self._h, int(convention)))
 

@@ -23,7 +23,7 @@ def oracle_scene(O, case, **kw):
                          grid_spacing=case["spacing"], convention=case["convention"], **kw)
 
 
-def hip_setup(ovr, ren, case, accumulate=False):
+def hip_setup(ovr, ren, case, accumulate=False, pipeline=0):
     """the call sequence of the reference's renderbatch (apps/main_batch.cpp:254-276)"""
     scene = ovr.Scene(volume=case["vol"], grid_origin=case["origin"], grid_spacing=case["spacing"],
                       transfer_function=None, volume_sampling_rate=case["rate"])
@@ -33,6 +33,7 @@ def hip_setup(ovr, ren, case, accumulate=False):
     ren.set_sample_per_pixel(case["spp"])
     ren.set_volume_sampling_rate(case["rate"])
     ren.set_shading(case["shading"])
+    ren.set_shading_pipeline(pipeline)
     ren.set_grid_convention(case["convention"])
     ren.set_transfer_function(case["colors"], case["alphas"], case["vr"])
     ren.init(scene, ovr.Camera(eye, at, up, case["fovy"]))
