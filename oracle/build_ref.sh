@@ -38,4 +38,5 @@ wait
 hostobjs=$(echo "$objs" | tr ' ' '\n' | grep -v main_batch | tr '\n' ' ')
 $CXX -shared -o "$OUT/libovr_refhost.so" $hostobjs -ldl -lpthread
 $CXX -o "$OUT/renderbatch" $objs -rdynamic -ldl -lpthread
-echo "[build_ref] built $OUT/renderbatch and $OUT/libovr_refhost.so"
+$CXX $FLAGS "$HERE/ref_probe.cpp" -o "$OUT/ref_probe" -L"$OUT" -lovr_refhost -Wl,-rpath,'$ORIGIN' -ldl -lpthread
+echo "[build_ref] built $OUT/renderbatch, $OUT/libovr_refhost.so and $OUT/ref_probe"

@@ -66,6 +66,7 @@ def load():
     lib.ovr_oracle_rgba8.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
     lib.ovr_oracle_sparse_mask.argtypes = [C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, fp, C.c_float, C.c_float, fp, C.c_int]
     lib.ovr_oracle_sparse_mask.restype = C.c_int64
+    lib.ovr_oracle_xfm_probe.argtypes = [fp, fp, fp, fp]
     lib.ovr_oracle_exp_det.argtypes = [C.c_float]
     lib.ovr_oracle_exp_det.restype = C.c_float
     lib.ovr_oracle_tile_owner.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
@@ -158,6 +159,28 @@ class OracleScene:
         rgba, grad, cnt = (C.c_float * 4)(), (C.c_float * 3)(), Counters()
         self.lib.ovr_oracle_trace_ray(C.byref(self.s), o, d, rgba, grad, C.byref(cnt))
         return np.array(rgba[:], dtype=np.float32), np.array(grad[:], dtype=np.float32), cnt
+
+
+def camera_basis(eye, at, up, fovy, w, h):
+    lib = load()
+    out = (C.c_float * 12)()
+    lib.ovr_oracle_camera_basis((C.c_float * 3)(*map(float, eye)), (C.c_float * 3)(*map(float, at)), (C.c_float * 3)(*map(float, up)),
+                                float(fovy), int(w), int(h), out)
+    return np.array(out[:], dtype=np.float32)
+
+
+def xfm_probe(origin, scale, p):
+    lib = load()
+    out = (C.c_float * 12)()
+    lib.ovr_oracle_xfm_probe((C.c_float * 3)(*map(float, origin)), (C.c_float * 3)(*map(float, scale)), (C.c_float * 3)(*map(float, p)), out)
+    return np.array(out[:], dtype=np.float32)
+
+
+def intersect_box(org, d, t0=0.0, t1=3.4028234663852886e38):
+    lib = load()
+    a, b = C.c_float(t0), C.c_float(t1)
+    hit = lib.ovr_oracle_intersect_box(C.byref(a), C.byref(b), (C.c_float * 3)(*map(float, org)), (C.c_float * 3)(*map(float, d)))
+    return bool(hit), a.value, b.value
 
 
 def rgba8(rgba, flip=True):

@@ -339,6 +339,27 @@ static inline v3 to_object(const frame_consts* fc, v3 p) /* xfmPoint(wto, p), di
                  fmaf(p.z, fc->inv_scale.z, fc->wto_p.z));
 }
 
+/* test access to the transform restatements (pinned against the reference's gdt math, tests/test_oracle_vs_ref.py):
+ * out = { xfmPoint(wto,p), xfmVector(wto,p), xfmNormal(otw,p), normalize(p) } for otw = translate(origin)*scale(scale) */
+void ovr_oracle_xfm_probe(const float origin[3], const float scale[3], const float p[3], float out[12])
+{
+  ovr_oracle_scene s;
+  memset(&s, 0, sizeof(s));
+  frame_consts fc;
+  memset(&fc, 0, sizeof(fc));
+  fc.scale = v3_make(scale[0], scale[1], scale[2]);
+  fc.inv_scale = v3_make(1.f / fc.scale.x, 1.f / fc.scale.y, 1.f / fc.scale.z);
+  fc.wto_p = v3_make(-(fc.inv_scale.x * origin[0]), -(fc.inv_scale.y * origin[1]), -(fc.inv_scale.z * origin[2]));
+  fc.otw_it = fc.inv_scale;
+  const v3 q = v3_make(p[0], p[1], p[2]);
+  const v3 a = to_object(&fc, q);
+  const v3 b = v3_make(q.x * fc.inv_scale.x, q.y * fc.inv_scale.y, q.z * fc.inv_scale.z);
+  const v3 c = v3_make(q.x * fc.otw_it.x, q.y * fc.otw_it.y, q.z * fc.otw_it.z);
+  const v3 d = v3_normalize(q);
+  out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = b.x; out[4] = b.y; out[5] = b.z;
+  out[6] = c.x; out[7] = c.y; out[8] = c.z; out[9] = d.x; out[10] = d.y; out[11] = d.z;
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* raymarching_shadow + __closesthit__volume_shadow - shaders_raymarching.cu:44-85,205-229          */
 /* ------------------------------------------------------------------------------------------------ */
@@ -632,7 +653,7 @@ void ovr_oracle_rgba8(const float* rgba, int width, int height, int flip_vertica
 /* ------------------------------------------------------------------------------------------------ */
 /* __expf restated as a fixed sequence of IEEE basic operations (range reduction to 2^n * 2^f, degree-6 polynomial in
  * Horner form with explicit fma) so that the keep/discard decision - an integer result - is bit-reproducible on any
- * IEEE machine; max relative error 2e-7, i.e. inside __expf's own error bound (2 ulp + range-reduction error). */
+ * IEEE machine; relative error 2e-7 near 0 growing to 2e-6 at x = -30 (the rounding of x*log2e), inside __expf's own bound of 2 + |1.16 x| ulp. */
 float ovr_oracle_exp_det(float x)
 {
   if (x < -87.f) return 0.f;

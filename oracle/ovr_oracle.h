@@ -141,6 +141,9 @@ void ovr_oracle_rgba8(const float* rgba, int width, int height, int flip_vertica
 int64_t ovr_oracle_sparse_mask(int32_t* out_xy, int frame_index, int width, int height, const float focus_center[2],
                                float focus_scale, float base_noise, const float* noise_tile, int noise_xy);
 
+/* test access: transform restatements, see ovr_oracle.c */
+void ovr_oracle_xfm_probe(const float origin[3], const float scale[3], const float p[3], float out[12]);
+
 /* deterministic restatement of __expf used by the mask (see ovr_oracle.c) */
 float ovr_oracle_exp_det(float x);
 
