@@ -6,7 +6,7 @@ one-process-per-GPU runs (tiles) and the synthetic inputs the reference does not
 from . import _lib
 from ._lib import (GRID_CELL_CENTRED, GRID_VERTEX_CENTRED, SHADE_FULL, SHADE_GRADIENT, SHADE_NONE)
 from .renderer import (Camera, CrossDeviceBuffer, DeviceHIP, FrameBufferData, Scene, TransferFunction, create_renderer)
-from . import synth, tiles
+from . import synth, tiles, vidi3d
 
 __all__ = ["Camera", "CrossDeviceBuffer", "DeviceHIP", "FrameBufferData", "Scene", "TransferFunction", "create_renderer",
-           "synth", "tiles", "SHADE_NONE", "SHADE_GRADIENT", "SHADE_FULL", "GRID_CELL_CENTRED", "GRID_VERTEX_CENTRED"]
+           "synth", "tiles", "vidi3d", "SHADE_NONE", "SHADE_GRADIENT", "SHADE_FULL", "GRID_CELL_CENTRED", "GRID_VERTEX_CENTRED"]

@@ -1,0 +1,107 @@
+// device_hip.cpp - the reference-side binding of the MI355X backend: `DeviceHIP : ovr::MainRenderer`.
+//
+// Compiled AGAINST THE REFERENCE'S OWN HEADERS (-I$OVR_ROOT ...; nothing of the reference is copied here) into
+// libdevice_hip.so, which exports the one symbol the reference's factory looks up for `--device hip`:
+//     extern "C" ovr::MainRenderer* ovr_create_renderer__hip();
+// (create_renderer -> LibraryRepository::add("device_hip") -> dlopen("libdevice_hip.so") -> objectFactory<MainRenderer>,
+//  reference ovr/renderer.cpp:55-58, ovr/common/dylink/ObjectFactory.h:35-85).  The reference's apps (renderbatch,
+// renderapp) run unmodified.  Everything below only forwards to the C ABI of include/ovr_hip.h - it plays the role
+// ovr/devices/optix7/device.cpp + device_impl.cpp play for the OptiX device.
+#include <ovr/renderer.h>
+
+#include "../include/ovr_hip.h"
+
+#include <chrono>
+#include <stdexcept>
+#include <string>
+
+namespace {
+
+void check(int code)
+{
+  if (code != 0) throw std::runtime_error(ovr_hip_last_error()); // the reference reports device errors as std::runtime_error
+}
+
+class DeviceHIP : public ovr::MainRenderer {
+public:
+  DeviceHIP() = default;
+  ~DeviceHIP() override { ovr_hip_destroy(h); }
+  DeviceHIP(const DeviceHIP&) = delete;
+  DeviceHIP& operator=(const DeviceHIP&) = delete;
+
+  // DeviceOptix7::init -> Impl::init -> buildScene (optix7/device.cpp:16-20, device_impl.cpp:283-302)
+  void init(int argc, const char** argv) override
+  {
+    if (h) throw std::runtime_error("[hip] device already initialized!");
+    int device_id = 0;
+    for (int i = 1; i + 1 < argc; ++i)
+      if (std::string(argv[i]) == "--hip-device") device_id = std::stoi(argv[i + 1]);
+    check(ovr_hip_create(&h, device_id));
+    const auto& v = ovr::parse_single_volume_scene(current_scene, ovr::scene::Volume::STRUCTURED_REGULAR_VOLUME).structured_regular;
+    const int32_t dims[3] = { v.data->dims.x, v.data->dims.y, v.data->dims.z };
+    const float origin[3] = { v.grid_origin.x, v.grid_origin.y, v.grid_origin.z };
+    const float spacing[3] = { v.grid_spacing.x, v.grid_spacing.y, v.grid_spacing.z };
+    check(ovr_hip_set_volume(h, v.data->data(), OVR_HIP_MEM_HOST, (int)v.data->type, dims, origin, spacing));
+    check(ovr_hip_set_volume_sampling_rate(h, current_scene.volume_sampling_rate)); // device_impl.cpp:298
+    check(ovr_hip_set_shading(h, OVR_HIP_SHADE_FULL));                             // what the reference's marcher does
+    commit();
+  }
+
+  void swap() override { check(ovr_hip_swap(h)); }
+
+  // DeviceOptix7::Impl::commit (device_impl.cpp:113-197): forward every changed TransactionalValue
+  void commit() override
+  {
+    if (params.fbsize.update()) check(ovr_hip_set_fbsize(h, params.fbsize.ref().x, params.fbsize.ref().y));
+    if (params.camera.update()) {
+      const ovr::scene::Camera& c = params.camera.ref();
+      const float from[3] = { c.from.x, c.from.y, c.from.z }, at[3] = { c.at.x, c.at.y, c.at.z }, up[3] = { c.up.x, c.up.y, c.up.z };
+      check(ovr_hip_set_camera(h, from, at, up, c.perspective.fovy));
+    }
+    if (params.tfn.update()) {
+      const auto& t = params.tfn.ref();
+      check(ovr_hip_set_transfer_function(h, t.tfn_colors.data(), (int32_t)(t.tfn_colors.size() / 3), t.tfn_alphas.data(),
+                                          (int32_t)(t.tfn_alphas.size() / 2), t.tfn_value_range.x, t.tfn_value_range.y));
+    }
+    const bool focus = params.focus_center.update() | params.focus_scale.update() | params.base_noise.update();
+    if (focus)
+      check(ovr_hip_set_focus(h, params.focus_center.ref().x, params.focus_center.ref().y, params.focus_scale.ref(), params.base_noise.ref()));
+    if (params.sample_per_pixel.update()) check(ovr_hip_set_sample_per_pixel(h, params.sample_per_pixel.ref()));
+    if (params.path_tracing.update() && params.path_tracing.ref())
+      throw std::runtime_error("[hip] path tracing is not part of the ray-marching backend");
+    if (params.sparse_sampling.update()) check(ovr_hip_set_sparse_sampling(h, params.sparse_sampling.ref()));
+    if (params.frame_accumulation.update()) check(ovr_hip_set_frame_accumulation(h, params.frame_accumulation.ref()));
+    if (params.volume_sampling_rate.update()) check(ovr_hip_set_volume_sampling_rate(h, params.volume_sampling_rate.get()));
+    check(ovr_hip_commit(h));
+  }
+
+  // DeviceOptix7::render (optix7/device.cpp:35-43): blocking; elapsed milliseconds are added to render_time
+  void render() override
+  {
+    const auto start = std::chrono::high_resolution_clock::now();
+    check(ovr_hip_render(h));
+    const auto end = std::chrono::high_resolution_clock::now();
+    render_time += std::chrono::duration_cast<std::chrono::milliseconds>(end - start).count();
+    variance = 0.f; // device_impl.cpp:266
+  }
+
+  // Impl::mapframe (device_impl.cpp:271-281).  The reference hands out device pointers (DEVICE_CUDA), which only exist
+  // in its CUDA build; an app built without OVR_BUILD_CUDA_DEVICES knows DEVICE_CPU only, so the frame is mapped to host
+  // memory owned by the backend - what the caller's to_cpu() (cross_device_buffer.h:130-159) would do next anyway.
+  void mapframe(FrameBufferData* fb) override
+  {
+    const float *rgba = nullptr, *grad = nullptr;
+    size_t nb_rgba = 0, nb_grad = 0;
+    check(ovr_hip_mapframe(h, OVR_HIP_MEM_HOST, &rgba, &nb_rgba, &grad, &nb_grad));
+    fb->rgba->set_data((void*)rgba, nb_rgba, ovr::CrossDeviceBuffer::DEVICE_CPU);
+    fb->grad->set_data((void*)grad, nb_grad, ovr::CrossDeviceBuffer::DEVICE_CPU);
+  }
+
+private:
+  ovr_hip_renderer* h = nullptr;
+};
+
+} // namespace
+
+// OVR_REGISTER_OBJECT(MainRenderer, renderer, DeviceHIP, hip) would expand to this (ObjectFactory.h:77-85)
+extern "C" ovr::MainRenderer* ovr_create_renderer__hip() { return new DeviceHIP; }

@@ -17,11 +17,11 @@ out="$out"
 for f in sorted(glob.glob(out+"/**/*counter_collection.csv", recursive=True)):
     agg=collections.defaultdict(lambda: [0,0.0])
     for r in csv.DictReader(open(f)):
-        k=(r["Kernel_Name"][:60], r["Counter_Name"])
+        k=(r["Kernel_Name"].split("(")[0][:70], r["Counter_Name"])
         agg[k][0]+=1; agg[k][1]+=float(r["Counter_Value"])
     with open(out+"/pmc_summary.txt","a") as o:
         for (k,c),(n,v) in sorted(agg.items()):
-            if "raymarch" in k: o.write(f"{k} {c} dispatches={n} mean={v/n:.6g}\n")
+            if any(t in k for t in ("raymarch", "march_spill", "shade_pool", "composite")): o.write(f"{k} {c} dispatches={n} mean={v/n:.6g}\n")
 for f in sorted(glob.glob(out+"/stats/**/*kernel_stats.csv", recursive=True)):
     os.system(f"cp {f} {out}/kernel_stats.csv")
 PY
