@@ -415,6 +415,10 @@ int enqueue_frame(ovr_hip_renderer* r)
   P.step = 1.f / r->rate.current; // volume.cpp:176
   P.base = 1.f;                   // volume.h:125
   P.shadow_stride = (P.step * 10.f) * P.step; // shaders_raymarching.cu:221 then :64
+  {
+    const float ex = r->spacing[0] * r->vd.nx, ey = r->spacing[1] * r->vd.ny, ez = r->spacing[2] * r->vd.nz;
+    P.long_ray_steps = std::sqrt(ex * ex + ey * ey + ez * ez) / P.step;
+  }
   P.tf_color = r->d_tf_color;
   P.tf_alpha = r->d_tf_alpha;
   P.n_color = r->n_color;
@@ -441,7 +445,8 @@ int enqueue_frame(ovr_hip_renderer* r)
   P.pool = PoolDesc{};
   if (want_pool) {
     // first guess: room for 8 shaded samples per pixel; grown after an overflow (finish_frame)
-    const size_t guess = std::min<size_t>(std::max<size_t>(n * 8 / 64, 4096), (size_t)1 << 20);
+    // (every tile reserves runs of 8 chunks, so add one run per tile)
+    const size_t guess = std::min<size_t>(std::max<size_t>(n * 8 / 64, 4096) + r->pool_tiles * 8, (size_t)1 << 21);
     if (int e = ensure_pool(r, std::max<size_t>(guess, r->pool.capacity))) return e;
     if (!r->pool.ctrl) {
       HIP_TRY(hipMalloc((void**)&r->pool.ctrl, 4 * sizeof(unsigned int)));
@@ -601,20 +606,16 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
   VolumeDesc vd{};
   vd.type = vt;
   vd.nx = dims[0]; vd.ny = dims[1]; vd.nz = dims[2];
-  const size_t es = voxel_size(vt);
-  vd.macros_x = (vd.nx + 31) / 32;
-  vd.macros_y = (vd.ny + 31) / 32;
-  vd.macros_z = (vd.nz + 31) / 32;
+  volume_layout(vt, vd.nx, vd.ny, vd.nz, vd);
   vd.value_scale = 1.f;
   vd.value_min_clamp = -FLT_MAX;
   if (vt == VOX_U8) vd.value_scale = 1.f / 255.f;
   if (vt == VOX_I8) { vd.value_scale = 1.f / 127.f; vd.value_min_clamp = -127.f; }
-  const size_t bytes = (size_t)vd.macros_x * vd.macros_y * vd.macros_z * 32768 * es;
-  vd.bytes = bytes;
+  const size_t bytes = (size_t)vd.bytes;
 
   if (r->d_volume) { HIP_TRY(hipFree(r->d_volume)); r->d_volume = nullptr; }
-  HIP_TRY(hipMalloc(&r->d_volume, bytes));
-  if (((vd.nx | vd.ny | vd.nz) & 31) != 0) HIP_TRY(hipMemset(r->d_volume, 0, bytes)); // padding voxels are never sampled
+  HIP_TRY(hipMalloc(&r->d_volume, bytes + 64)); // + slack: the pair load of the very last element
+  HIP_TRY(hipMemset(r->d_volume, 0, bytes + 64));  // padding voxels are never sampled, but must be finite
   r->volume_bytes = bytes;
   vd.data = r->d_volume;
 

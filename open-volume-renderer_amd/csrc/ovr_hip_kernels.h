@@ -10,19 +10,23 @@ namespace ovrhip {
 // device-resident scalar types of the bricked volume (u32/i32/f64 inputs are converted at upload, see relayout)
 enum VoxelType : int { VOX_U8 = 0, VOX_I8 = 1, VOX_U16 = 2, VOX_I16 = 3, VOX_F32 = 4 };
 
-// Volume layout in HBM ("bricks in macro blocks"):
-//   the grid is padded to whole 32^3-voxel macro blocks, macro blocks are stored x-fastest, and inside a macro block the
-//   voxels are grouped into 128-byte bricks (f32: 4x4x2 voxels, u16/i16: 4x4x4, u8/i8: 8x4x4), bricks x-fastest.
-//   The element offset is separable, off(x,y,z) = X(x) + Y(y) + Z(z) (BrickMap in ovr_hip_kernels.hip), so a trilinear
-//   tap costs six small bit-field computations and eight adds.  One 128-byte L1/L2 line holds one brick: the 2x2x2
-//   footprint of a tap touches ~2.3 lines for ANY ray direction (a row-major layout touches 4 and loses all reuse as
-//   soon as rays do not run along x: measured 81 % L1 / 52 % L2 miss rate on the oblique bench camera).
+// Volume layout in HBM ("x-apron bricks in macro blocks"):
+//   voxels are grouped into 128-byte bricks = one L1/L2 line.  A brick covers CX x 4 x (2|4) cells and stores CX+1 voxels
+//   along x - its last x-column duplicates the first column of its +x neighbour (or replicates the grid's last voxel) - so
+//   the x-pair of a trilinear tap is always two ADJACENT elements of one brick:
+//       f32: (3+1)x4x2     u16/i16: (3+1)x4x4     u8/i8: (7+1)x4x4          (memory x 4/3, x 8/7 for 8-bit)
+//   Bricks are x-fastest inside macro blocks of (10|4) x 8 x (16|8) bricks (30|28 x 32 x 32 cells), macro blocks x-fastest.
+//   The element offset is separable, off(x,y,z) = X(x) + Y(y) + Z(z) (BrickMap in ovr_hip_kernels.hip).
+//   One line holds one 3-D brick: the 2x2x2 footprint of a tap touches ~2.4 lines for ANY ray direction (a row-major
+//   layout touches 4 and loses all reuse as soon as rays do not run along x: measured 81 % L1 / 52 % L2 miss rate on the
+//   oblique bench camera), and a tap is 4 pair loads instead of 8 scalar loads.
 struct VolumeDesc {
   const void* data;
   int type;        // VoxelType
   int nx, ny, nz;
-  int macros_x, macros_y, macros_z; // ceil(n / 32)
-  unsigned long long bytes;         // macros_x * macros_y * macros_z * 32768 * sizeof(voxel)
+  int macros_x, macros_y, macros_z;
+  unsigned int macro_elems;         // stored voxels per macro block
+  unsigned long long bytes;         // macros_x * macros_y * macros_z * macro_elems * sizeof(voxel)
   float value_scale; // multiplier turning a filtered raw value into what the reference's texture read returns
   float value_min_clamp; // raw clamp applied per voxel before filtering (i8: -127) - see array.h:83-90
 };
@@ -61,6 +65,7 @@ struct RayMarchParams {
   float3_ coord_scale, coord_bias, grad_step;
   float step, base;           // volume.cpp:172-179
   float shadow_stride;        // 10 * step * step (shaders_raymarching.cu:221,64)
+  float long_ray_steps;       // samples along the volume's diagonal (scheduling hint only)
   float tf_lower, tf_upper, tf_scale; // volume.cpp:131-145
   const float* tf_color;      // n_color * 4 (rgb, 1)
   const float* tf_alpha;      // n_alpha
@@ -91,6 +96,7 @@ size_t raymarch_grid_blocks(const RayMarchParams& p);
 // linear (x fastest) -> bricked layout; src may be any reference ValueType, dst is the VoxelType chosen by
 // device_voxel_type().  z0/nz_chunk allow chunked uploads from host staging.
 int device_voxel_type(int ovr_value_type);
+void volume_layout(int voxel_type, int nx, int ny, int nz, VolumeDesc& vd); // fills macros_*, macro_elems, bytes
 size_t voxel_size(int voxel_type);
 hipError_t launch_relayout(const void* src_linear, int ovr_value_type, void* dst, const VolumeDesc& vd, int z0, int nz_chunk,
                            hipStream_t stream);

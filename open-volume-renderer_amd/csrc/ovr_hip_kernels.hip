@@ -54,62 +54,78 @@ __device__ __forceinline__ float opacity_correction(float a, float adj)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// voxel access.  Volume layout in HBM: 128-byte bricks inside 32^3-voxel macro blocks (see ovr_hip_kernels.h).
-// One L1/L2 line is one brick (f32: 4x4x2 voxels, u16/i16: 4x4x4, u8/i8: 8x4x4), so the 2x2x2 footprint of a tap
-// touches ~2.3 lines whatever the ray direction, and the 16x16-voxel sheet a wave samples per step ~50.
+// voxel access.  Volume layout in HBM: 128-byte bricks with an x-apron, inside macro blocks (see ovr_hip_kernels.h).
+// One L1/L2 line is one brick.  A brick stores CX+1 voxels along x (the last one duplicates the first of its +x neighbour),
+// so the two x-neighbours of a trilinear tap always sit next to each other in ONE brick and a tap is 4 pair loads
+// (f32: 4 x 8 bytes) instead of 8 scalar loads.  The texture addresser spends ~41 clocks on a 64-lane gather instruction
+// whatever its width (tools/ubench_gather.hip), so halving the instruction count halves the cost of the path's bottleneck;
+// the price is 4/3 (8/7 for 8-bit) of the memory.   f32: (3+1)x4x2   u16/i16: (3+1)x4x4   u8/i8: (7+1)x4x4
 // The element offset is separable: off(x,y,z) = X(x) + Y(y) + Z(z).
 // ------------------------------------------------------------------------------------------------------------------
+typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+typedef unsigned short u16x2_u __attribute__((ext_vector_type(2), aligned(2)));
+typedef short i16x2_u __attribute__((ext_vector_type(2), aligned(2)));
+typedef unsigned char u8x2_u __attribute__((ext_vector_type(2), aligned(1)));
+typedef signed char i8x2_u __attribute__((ext_vector_type(2), aligned(1)));
+
 template <int VT> struct Vox;
 template <> struct Vox<VOX_F32> {
-  typedef float T;
-  static constexpr int bx = 2, by = 2, bz = 1;
+  typedef float T; typedef f32x2_u P;
+  static constexpr int cx = 3, mbx = 10, by = 2, bz = 1; // cells per brick in x, bricks per macro block in x, log2 brick y/z
   static constexpr bool kScale = false, kClamp = false;
 };
 template <> struct Vox<VOX_U16> {
-  typedef unsigned short T;
-  static constexpr int bx = 2, by = 2, bz = 2;
+  typedef unsigned short T; typedef u16x2_u P;
+  static constexpr int cx = 3, mbx = 10, by = 2, bz = 2;
   static constexpr bool kScale = false, kClamp = false; // u16 is sampled as RAW float (array.cpp:335-338)
 };
 template <> struct Vox<VOX_I16> {
-  typedef short T;
-  static constexpr int bx = 2, by = 2, bz = 2;
+  typedef short T; typedef i16x2_u P;
+  static constexpr int cx = 3, mbx = 10, by = 2, bz = 2;
   static constexpr bool kScale = false, kClamp = false;
 };
 template <> struct Vox<VOX_U8> {
-  typedef unsigned char T;
-  static constexpr int bx = 3, by = 2, bz = 2;
+  typedef unsigned char T; typedef u8x2_u P;
+  static constexpr int cx = 7, mbx = 4, by = 2, bz = 2;
   static constexpr bool kScale = true, kClamp = false; // normalized read: v / 255 (array.cpp:304-306)
 };
 template <> struct Vox<VOX_I8> {
-  typedef signed char T;
-  static constexpr int bx = 3, by = 2, bz = 2;
+  typedef signed char T; typedef i8x2_u P;
+  static constexpr int cx = 7, mbx = 4, by = 2, bz = 2;
   static constexpr bool kScale = true, kClamp = true; // max(v / 127, -1)
 };
 
 template <int VT> struct BrickMap {
   typedef Vox<VT> V;
-  static constexpr unsigned BV = 1u << (V::bx + V::by + V::bz); // voxels per brick (128 bytes)
-  static constexpr unsigned MV = 32768u;                         // voxels per 32^3 macro block
-  static constexpr unsigned sbx = BV, sby = (32u >> V::bx) * BV, sbz = (32u >> V::bx) * (32u >> V::by) * BV;
-  static __host__ __device__ __forceinline__ unsigned X(unsigned x)
+  static constexpr unsigned SX = V::cx + 1;                           // stored voxels per brick row (4 or 8)
+  static constexpr unsigned BV = SX << (V::by + V::bz);               // stored voxels per brick (128 bytes)
+  static constexpr unsigned sby = V::mbx * BV, sbz = (32u >> V::by) * V::mbx * BV;
+  static constexpr unsigned MV = (32u >> V::bz) * sbz;                // stored voxels per macro block
+  static constexpr unsigned MCX = V::cx * V::mbx;                     // cells per macro block along x (30 or 28)
+  // exact for x < 65536: q = floor(x / d) = mulhi(x, ceil(2^32 / d))
+  static __host__ __device__ __forceinline__ unsigned div_cx(unsigned x) { return (unsigned)(((unsigned long long)x * ((0xffffffffull / V::cx) + 1ull)) >> 32); }
+  static __host__ __device__ __forceinline__ unsigned div_mbx(unsigned b) { return (unsigned)(((unsigned long long)b * ((0xffffffffull / V::mbx) + 1ull)) >> 32); }
+  static __host__ __device__ __forceinline__ unsigned X(unsigned x) // offset of voxel x as the LOWER member of a pair
   {
-    return (x & ((1u << V::bx) - 1u)) + ((x >> V::bx) & ((32u >> V::bx) - 1u)) * sbx + (x >> 5) * MV;
+    const unsigned b = div_cx(x), xr = x - b * V::cx;
+    const unsigned m = div_mbx(b), bm = b - m * V::mbx;
+    return xr + bm * BV + m * MV;
   }
   static __host__ __device__ __forceinline__ unsigned Y(unsigned y, unsigned macro_y_stride)
   {
-    return ((y & ((1u << V::by) - 1u)) << V::bx) + ((y >> V::by) & ((32u >> V::by) - 1u)) * sby + (y >> 5) * macro_y_stride;
+    return (y & ((1u << V::by) - 1u)) * SX + ((y >> V::by) & ((32u >> V::by) - 1u)) * sby + (y >> 5) * macro_y_stride;
   }
   static __host__ __device__ __forceinline__ unsigned Zlo(unsigned z)
   {
-    return ((z & ((1u << V::bz) - 1u)) << (V::bx + V::by)) + ((z >> V::bz) & ((32u >> V::bz) - 1u)) * sbz;
+    return ((z & ((1u << V::bz) - 1u)) << V::by) * SX + ((z >> V::bz) & ((32u >> V::bz) - 1u)) * sbz;
   }
 };
 
 struct VolConsts {
   const void* data;
   int nx1, ny1, nz1; // n - 1
-  unsigned int macro_y;          // elements between macro rows: 32768 * macros_x
-  unsigned long long macro_z;    // elements between macro layers: 32768 * macros_x * macros_y
+  unsigned int macro_y;          // stored elements between macro rows: MV * macros_x
+  unsigned long long macro_z;    // stored elements between macro layers: MV * macros_x * macros_y
   float fx1, fy1, fz1;
   f3 cs, cb;
   float vscale, vmin;
@@ -127,40 +143,50 @@ __device__ __forceinline__ void axis_tap(float po, float cs, float cb, float fn1
 }
 
 // One trilinear tap, split in two so that several taps can be in flight before the first is consumed
-// (software pipelining: the march is latency-bound otherwise).  issue: 8 voxel loads; finish: 7 lerps.
+// (software pipelining: the march is latency-bound otherwise).  issue: 4 pair loads; finish: 7 lerps.
 struct Tap {
   float c000, c100, c010, c110, c001, c101, c011, c111;
   float fx, fy, fz;
 };
 
-template <int VT, bool BIG>
+template <int VT, int AM>
 __device__ __forceinline__ void tap_issue(const VolConsts& vc, f3 p, Tap& t)
 {
   typedef BrickMap<VT> M;
   typedef typename Vox<VT>::T T;
+  typedef typename Vox<VT>::P P;
   int x0, x1, y0, y1, z0, z1;
   axis_tap(p.x, vc.cs.x, vc.cb.x, vc.fx1, vc.nx1, x0, x1, t.fx);
   axis_tap(p.y, vc.cs.y, vc.cb.y, vc.fy1, vc.ny1, y0, y1, t.fy);
   axis_tap(p.z, vc.cs.z, vc.cb.z, vc.fz1, vc.nz1, z0, z1, t.fz);
-  const unsigned ox0 = M::X((unsigned)x0), ox1 = M::X((unsigned)x1);
-  const unsigned oy0 = M::Y((unsigned)y0, vc.macro_y), oy1 = M::Y((unsigned)y1, vc.macro_y);
-  const unsigned o00 = ox0 + oy0, o10 = ox1 + oy0, o01 = ox0 + oy1, o11 = ox1 + oy1;
-  const T* base = static_cast<const T*>(vc.data);
-  if (BIG) {
+  (void)x1; // the pair's upper member is the brick's next element (apron / replicated edge)
+  const unsigned ox = M::X((unsigned)x0);
+  const unsigned o0 = ox + M::Y((unsigned)y0, vc.macro_y), o1 = ox + M::Y((unsigned)y1, vc.macro_y);
+  P p00, p10, p01, p11;
+  if (AM == 2) { // > 2^32 elements: 64-bit element offsets
+    const T* base = static_cast<const T*>(vc.data);
     const unsigned long long oz0 = (unsigned long long)M::Zlo((unsigned)z0) + (unsigned long long)((unsigned)z0 >> 5) * vc.macro_z;
     const unsigned long long oz1 = (unsigned long long)M::Zlo((unsigned)z1) + (unsigned long long)((unsigned)z1 >> 5) * vc.macro_z;
-    t.c000 = (float)base[oz0 + o00]; t.c100 = (float)base[oz0 + o10]; t.c010 = (float)base[oz0 + o01]; t.c110 = (float)base[oz0 + o11];
-    t.c001 = (float)base[oz1 + o00]; t.c101 = (float)base[oz1 + o10]; t.c011 = (float)base[oz1 + o01]; t.c111 = (float)base[oz1 + o11];
+    p00 = *reinterpret_cast<const P*>(base + (oz0 + o0)); p10 = *reinterpret_cast<const P*>(base + (oz0 + o1));
+    p01 = *reinterpret_cast<const P*>(base + (oz1 + o0)); p11 = *reinterpret_cast<const P*>(base + (oz1 + o1));
   }
-  else { // the whole volume is < 4 GiB: 32-bit BYTE offsets, so the loads use the SGPR-base + 32-bit-VGPR-offset form
+  else if (AM == 1) { // < 2^32 elements: 32-bit element offsets, one 64-bit shift-add per load
+    const T* base = static_cast<const T*>(vc.data);
+    const unsigned oz0 = M::Zlo((unsigned)z0) + ((unsigned)z0 >> 5) * (unsigned)vc.macro_z;
+    const unsigned oz1 = M::Zlo((unsigned)z1) + ((unsigned)z1 >> 5) * (unsigned)vc.macro_z;
+    p00 = *reinterpret_cast<const P*>(base + (oz0 + o0)); p10 = *reinterpret_cast<const P*>(base + (oz0 + o1));
+    p01 = *reinterpret_cast<const P*>(base + (oz1 + o0)); p11 = *reinterpret_cast<const P*>(base + (oz1 + o1));
+  }
+  else { // the whole volume is <= 4 GiB: 32-bit BYTE offsets, so the loads use the SGPR-base + 32-bit-VGPR-offset form
     const unsigned oz0 = M::Zlo((unsigned)z0) + ((unsigned)z0 >> 5) * (unsigned)vc.macro_z;
     const unsigned oz1 = M::Zlo((unsigned)z1) + ((unsigned)z1 >> 5) * (unsigned)vc.macro_z;
     const char* cb = static_cast<const char*>(vc.data);
-#define OVR_LD(off) ((float)*reinterpret_cast<const T*>(cb + (unsigned)((off) * (unsigned)sizeof(T))))
-    t.c000 = OVR_LD(oz0 + o00); t.c100 = OVR_LD(oz0 + o10); t.c010 = OVR_LD(oz0 + o01); t.c110 = OVR_LD(oz0 + o11);
-    t.c001 = OVR_LD(oz1 + o00); t.c101 = OVR_LD(oz1 + o10); t.c011 = OVR_LD(oz1 + o01); t.c111 = OVR_LD(oz1 + o11);
+#define OVR_LD(off) (*reinterpret_cast<const P*>(cb + (unsigned)((off) * (unsigned)sizeof(T))))
+    p00 = OVR_LD(oz0 + o0); p10 = OVR_LD(oz0 + o1); p01 = OVR_LD(oz1 + o0); p11 = OVR_LD(oz1 + o1);
 #undef OVR_LD
   }
+  t.c000 = (float)p00.x; t.c100 = (float)p00.y; t.c010 = (float)p10.x; t.c110 = (float)p10.y;
+  t.c001 = (float)p01.x; t.c101 = (float)p01.y; t.c011 = (float)p11.x; t.c111 = (float)p11.y;
 }
 
 template <int VT>
@@ -179,11 +205,11 @@ __device__ __forceinline__ float tap_finish(const VolConsts& vc, Tap t)
 }
 
 // trilinear tap at object-space p (shaders_common.h:186-193); returns what tex3D<float> returns
-template <int VT, bool BIG>
+template <int VT, int AM>
 __device__ __forceinline__ float sample_volume(const VolConsts& vc, f3 p)
 {
   Tap t;
-  tap_issue<VT, BIG>(vc, p, t);
+  tap_issue<VT, AM>(vc, p, t);
   return tap_finish<VT>(vc, t);
 }
 
@@ -266,7 +292,7 @@ __device__ __forceinline__ f3 to_object(const MarchConsts& mc, f3 p)
 // raymarching_shadow, shaders_raymarching.cu:44-85 (+ :205-229): alpha-only march toward the light.
 // KS taps are issued before the first one is consumed; taps past the end of the march or past the early-termination
 // point are speculative (their coordinates are clamped, so the loads are always in bounds) and simply dropped.
-template <int VT, bool BIG, int KS>
+template <int VT, int AM, int KS>
 __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConsts& tf, const MarchConsts& mc, f3 org, unsigned int& n_shadow)
 {
   const f3 oo = to_object(mc, org);
@@ -286,7 +312,7 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
       dts[k] = ty - tx;
       const float tm = 0.5f * (tx + ty);
       const f3 pos = mk3(fmaf(tm, mc.light.x, org.x), fmaf(tm, mc.light.y, org.y), fmaf(tm, mc.light.z, org.z));
-      tap_issue<VT, BIG>(vc, to_object(mc, pos), taps[k]);
+      tap_issue<VT, AM>(vc, to_object(mc, pos), taps[k]);
       tx = ty;
       ty = fminf(tx + mc.shadow_stride, t1);
     }
@@ -332,8 +358,15 @@ constexpr int kWaves = kBlock / 64;
 template <int SHADE> struct MarchCfg;
 template <> struct MarchCfg<0> { static constexpr int K = 4, QCAP = 0, KS = 1; };
 template <> struct MarchCfg<1> { static constexpr int K = 3, QCAP = 256, KS = 1; };
-template <> struct MarchCfg<2> { static constexpr int K = 3, QCAP = 256, KS = 4; };
-constexpr int kSpillK = 3, kSpillQCap = 256; // march_spill_kernel
+#ifndef OVR_SHADOW_K
+#define OVR_SHADOW_K 4
+#endif
+template <> struct MarchCfg<2> { static constexpr int K = 3, QCAP = 256, KS = OVR_SHADOW_K; };
+#ifndef OVR_SPILL_K
+#define OVR_SPILL_K 6
+#endif
+constexpr int kRun = 8; // chunks a tile reserves at a time: consecutive chunks of one tile are shaded by ONE workgroup (L1/L2 reuse)
+constexpr int kSpillK = OVR_SPILL_K, kSpillQCap = 128; // march_spill_kernel: spills after every sample, so 63 + 64 slots suffice
 
 struct ShadeReq { // 32 bytes; after shading the same slot holds the result (cx,cy,cz,gx,gy,gz,a,next)
   float px, py, pz; // world-space sample position          | colour contribution  tr*clamp01(rgb*shade)
@@ -355,8 +388,8 @@ __device__ __forceinline__ void setup_consts(const RayMarchParams& P, VolConsts&
   vc.data = P.vol.data;
   vc.nx1 = P.vol.nx - 1; vc.ny1 = P.vol.ny - 1; vc.nz1 = P.vol.nz - 1;
   vc.fx1 = (float)vc.nx1; vc.fy1 = (float)vc.ny1; vc.fz1 = (float)vc.nz1;
-  vc.macro_y = 32768u * (unsigned int)P.vol.macros_x;
-  vc.macro_z = 32768ull * (unsigned long long)P.vol.macros_x * (unsigned long long)P.vol.macros_y;
+  vc.macro_y = P.vol.macro_elems * (unsigned int)P.vol.macros_x;
+  vc.macro_z = (unsigned long long)P.vol.macro_elems * (unsigned long long)P.vol.macros_x * (unsigned long long)P.vol.macros_y;
   vc.cs = ld3(P.coord_scale); vc.cb = ld3(P.coord_bias);
   vc.vscale = P.vol.value_scale; vc.vmin = P.vol.value_min_clamp;
   mc.inv_scale = ld3(P.inv_scale); mc.wto_p = ld3(P.wto_p); mc.otw_it = ld3(P.otw_it); mc.light = ld3(P.light);
@@ -429,7 +462,7 @@ __device__ __forceinline__ void write_pixel(const RayMarchParams& P, unsigned in
 
 // shade one request: gradient (shaders_common.h:195-215), normals, shadow march, Lambert-ish term
 // (shaders_raymarching.cu:124-158).  Writes the result over the request.
-template <int VT, int SHADE, bool BIG>
+template <int VT, int SHADE, int AM>
 __device__ __forceinline__ void shade_request(const RayMarchParams& P, const VolConsts& vc, const TfConsts& tf, const MarchConsts& mc, ShadeReq& r,
                                               unsigned int& n_shadow)
 {
@@ -438,9 +471,9 @@ __device__ __forceinline__ void shade_request(const RayMarchParams& P, const Vol
   // one-sided differences, flipped at the upper bound; the three taps are issued together
   const bool flx = (po.x + mc.gstep.x) > 1.f, fly = (po.y + mc.gstep.y) > 1.f, flz = (po.z + mc.gstep.z) > 1.f;
   Tap tgx, tgy, tgz;
-  tap_issue<VT, BIG>(vc, mk3(po.x + (flx ? -mc.gstep.x : mc.gstep.x), po.y, po.z), tgx);
-  tap_issue<VT, BIG>(vc, mk3(po.x, po.y + (fly ? -mc.gstep.y : mc.gstep.y), po.z), tgy);
-  tap_issue<VT, BIG>(vc, mk3(po.x, po.y, po.z + (flz ? -mc.gstep.z : mc.gstep.z)), tgz);
+  tap_issue<VT, AM>(vc, mk3(po.x + (flx ? -mc.gstep.x : mc.gstep.x), po.y, po.z), tgx);
+  tap_issue<VT, AM>(vc, mk3(po.x, po.y + (fly ? -mc.gstep.y : mc.gstep.y), po.z), tgy);
+  tap_issue<VT, AM>(vc, mk3(po.x, po.y, po.z + (flz ? -mc.gstep.z : mc.gstep.z)), tgz);
   const f3 rgb = tf_color(tf, r.v);
   f3 g;
   g.x = (tap_finish<VT>(vc, tgx) - r.s) * (flx ? -mc.ginv.x : mc.ginv.x);
@@ -456,7 +489,7 @@ __device__ __forceinline__ void shade_request(const RayMarchParams& P, const Vol
                          fmaf(n_w.x, m[2], fmaf(n_w.y, m[5], n_w.z * m[8]))));
   }
   float shadow = 0.f;
-  if (SHADE == 2) shadow = march_shadow<VT, BIG, MarchCfg<2>::KS>(vc, tf, mc, pos, n_shadow);
+  if (SHADE == 2) shadow = march_shadow<VT, AM, MarchCfg<2>::KS>(vc, tf, mc, pos, n_shadow);
   const float cosNL = fabsf(dot3(mc.light, n_w));
   const float shade = 0.5f + 0.5f * cosNL * 2.f * (1.f - shadow); // shaders_raymarching.cu:156-157
   const float tr = r.tr;
@@ -524,7 +557,7 @@ __device__ __forceinline__ void store_block_counters(const RayMarchParams& P, un
 // ------------------------------------------------------------------------------------------------------------------
 // in-place pipeline: march + shade + composite in one kernel
 // ------------------------------------------------------------------------------------------------------------------
-template <int VT, int SHADE, bool BIG>
+template <int VT, int SHADE, int AM>
 __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P)
 {
   using Cfg = MarchCfg<SHADE>;
@@ -591,7 +624,7 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
           r.px = r.py = r.pz = r.s = r.v = r.tr = r.a = 0.f; r.next = 0;
           if ((unsigned int)lane < n) {
             r = queue[(q_head + lane) & (QCAP - 1)];
-            shade_request<VT, SHADE, BIG>(P, vc, tf, mc, r, n_shadow);
+            shade_request<VT, SHADE, AM>(P, vc, tf, mc, r, n_shadow);
           }
           apply_batch(r, q_head, n, lane, pend, first, color, gradient);
           q_head += n;
@@ -613,7 +646,7 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
         dts[k] = ty - tx;
         const float tm = 0.5f * (tx + ty);
         poss[k] = mk3(fmaf(tm, dir.x, org.x), fmaf(tm, dir.y, org.y), fmaf(tm, dir.z, org.z));
-        tap_issue<VT, BIG>(vc, to_object(mc, poss[k]), taps[k]);
+        tap_issue<VT, AM>(vc, to_object(mc, poss[k]), taps[k]);
         tx = ty;
         ty = fminf(tx + mc.step, t1);
       }
@@ -687,13 +720,14 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
 // ------------------------------------------------------------------------------------------------------------------
 // pooled pipeline, kernel A: primary march; full batches of 64 requests are spilled to the global pool as chunks
 // ------------------------------------------------------------------------------------------------------------------
-template <int VT, bool BIG>
+template <int VT, int AM>
 __global__ __launch_bounds__(kBlock) void march_spill_kernel(const RayMarchParams P)
 {
   constexpr int K = kSpillK;
   constexpr int QCAP = kSpillQCap;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long t_start = P.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
   ShadeReq* const queue = reinterpret_cast<ShadeReq*>(lds_raw) + (size_t)wave * QCAP;
   TfConsts tf;
   stage_tf(P, lds_raw + (size_t)kWaves * QCAP * sizeof(ShadeReq), false, tf); // alpha table only
@@ -728,29 +762,34 @@ __global__ __launch_bounds__(kBlock) void march_spill_kernel(const RayMarchParam
   int prev_chunk = -1;
   if (lane == 0) Q.tile_first[tile] = -1;
 
-  for (;;) {
-    const bool any_live = __ballot(live) != 0ull;
-    // ---- (1) spill: a full chunk whenever 64 requests are queued, the remainder once no ray is live
-    while ((q_tail - q_head) >= 64u || (!any_live && q_tail != q_head)) {
-      const unsigned int n = min(q_tail - q_head, 64u);
-      unsigned int c = 0;
-      if (lane == 0) c = atomicAdd(&Q.ctrl[0], 1u);
-      c = (unsigned int)__builtin_amdgcn_readfirstlane((int)c);
-      if (c < Q.capacity) {
-        __builtin_amdgcn_wave_barrier();
-        if ((unsigned int)lane < n) Q.reqs[(size_t)c * 64 + lane] = queue[(q_head + lane) & (QCAP - 1)];
-        if (lane == 0) {
-          Q.chunk_n[c] = n;
-          if (prev_chunk >= 0) Q.chunk_next[prev_chunk] = (int)c; else Q.tile_first[tile] = (int)c;
-        }
-        if (pend > 0 && (last - q_head) < n) last_gidx = c * 64u + (last - q_head);
-        prev_chunk = (int)c;
-      }
-      // c >= capacity: the pool is exhausted; ctrl[0] keeps counting so the host knows how much was needed, re-sizes
-      // the pool and renders the frame again (ovr_hip_api.cpp) - nothing of this frame is used
-      q_head += n;
+  // spill the n oldest queued requests as one chunk of the global pool (small: inlined after every sample)
+  unsigned int run_base = 0, run_left = 0; // the tile's current reservation of kRun consecutive chunks
+  auto spill = [&](unsigned int n) {
+    if (run_left == 0) {
+      unsigned int c0 = 0;
+      if (lane == 0) c0 = atomicAdd(&Q.ctrl[0], (unsigned int)kRun);
+      run_base = (unsigned int)__builtin_amdgcn_readfirstlane((int)c0);
+      run_left = kRun;
     }
-    if (!any_live) break;
+    const unsigned int c = run_base + (kRun - run_left);
+    --run_left;
+    if (run_base + kRun <= Q.capacity) {
+      __builtin_amdgcn_wave_barrier();
+      if ((unsigned int)lane < n) Q.reqs[(size_t)c * 64 + lane] = queue[(q_head + lane) & (QCAP - 1)];
+      if (lane == 0) {
+        Q.chunk_n[c] = n;
+        if (prev_chunk >= 0) Q.chunk_next[prev_chunk] = (int)c; else Q.tile_first[tile] = (int)c;
+      }
+      if (pend > 0 && (last - q_head) < n) last_gidx = c * 64u + (last - q_head);
+      prev_chunk = (int)c;
+    }
+    // beyond capacity: the pool is exhausted; ctrl[0] keeps counting so the host knows how much was needed, re-sizes
+    // the pool and renders the frame again (ovr_hip_api.cpp) - nothing of this frame is used
+    q_head += n;
+  };
+
+  for (;;) {
+    if (__ballot(live) == 0ull) break;
 
     // ---- (2) primary march: K samples, loads first
     Tap taps[K];
@@ -763,7 +802,7 @@ __global__ __launch_bounds__(kBlock) void march_spill_kernel(const RayMarchParam
       dts[k] = ty - tx;
       const float tm = 0.5f * (tx + ty);
       poss[k] = mk3(fmaf(tm, dir.x, org.x), fmaf(tm, dir.y, org.y), fmaf(tm, dir.z, org.z));
-      tap_issue<VT, BIG>(vc, to_object(mc, poss[k]), taps[k]);
+      tap_issue<VT, AM>(vc, to_object(mc, poss[k]), taps[k]);
       tx = ty;
       ty = fminf(tx + mc.step, t1);
     }
@@ -799,11 +838,20 @@ __global__ __launch_bounds__(kBlock) void march_spill_kernel(const RayMarchParam
           ++pend;
         }
         q_tail += (unsigned int)__popcll(m);
+        if ((q_tail - q_head) >= 64u) spill(64u);
       }
     }
   }
+  if (q_tail != q_head) spill(q_tail - q_head); // the tile's last, partial chunk
+  if (lane == 0 && run_base + kRun <= Q.capacity)
+    for (unsigned int i = kRun - run_left; i < (unsigned int)kRun && run_left != 0; ++i) Q.chunk_n[run_base + i] = 0; // unused tail of the reservation
 
   if (lane == 0) Q.tile_count[tile] = q_tail;
+  if (P.trace && lane == 0) { // diagnostic only (OVR_HIP_TRACE)
+    unsigned long long* t = P.trace + (size_t)tile * 4;
+    t[0] = t_start; t[1] = __builtin_amdgcn_s_memrealtime();
+    t[2] = ((unsigned long long)n_samples << 32) | n_shaded; t[3] = q_tail;
+  }
   if (active) Q.pix_state[pixel_index] = make_float4(alpha, __uint_as_float(first), __int_as_float(pend), 0.f);
   store_block_counters(P, reinterpret_cast<unsigned int*>(lds_raw), lane, wave, n_rays, n_samples, n_shaded, 0u, active ? 1u : 0u);
 }
@@ -811,7 +859,7 @@ __global__ __launch_bounds__(kBlock) void march_spill_kernel(const RayMarchParam
 // ------------------------------------------------------------------------------------------------------------------
 // pooled pipeline, kernel B: persistent waves shade chunks from all tiles; one returning atomic per chunk
 // ------------------------------------------------------------------------------------------------------------------
-template <int VT, int SHADE, bool BIG>
+template <int VT, int SHADE, int AM>
 __global__ __launch_bounds__(kBlock) void shade_pool_kernel(const RayMarchParams P)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -822,18 +870,25 @@ __global__ __launch_bounds__(kBlock) void shade_pool_kernel(const RayMarchParams
   MarchConsts mc;
   setup_consts(P, vc, mc);
   const PoolDesc& Q = P.pool;
-  const unsigned int n_chunks = Q.ctrl[0] > Q.capacity ? 0u : Q.ctrl[0]; // overflow: the frame is re-rendered, skip the work
+  const unsigned int n_runs = Q.ctrl[0] > Q.capacity ? 0u : Q.ctrl[0] / (unsigned int)kRun; // overflow: the frame is re-rendered
   unsigned int n_shadow = 0;
+  __shared__ unsigned int s_run;
   for (;;) {
-    unsigned int c = 0;
-    if (lane == 0) c = atomicAdd(&Q.ctrl[1], 1u);
-    c = (unsigned int)__builtin_amdgcn_readfirstlane((int)c);
-    if (c >= n_chunks) break; // every wave reaches this: the cursor only grows
-    const unsigned int n = Q.chunk_n[c];
-    if ((unsigned int)lane < n) {
-      ShadeReq r = Q.reqs[(size_t)c * 64 + lane];
-      shade_request<VT, SHADE, BIG>(P, vc, tf, mc, r, n_shadow);
-      Q.reqs[(size_t)c * 64 + lane] = r;
+    // one returning atomic per workgroup and run; the 4 waves shade the run's chunks (consecutive depth steps of ONE
+    // tile: their gradient and shadow taps fall into the same bricks, which the CU's L1 and the XCD's L2 now keep)
+    __syncthreads();
+    if (threadIdx.x == 0) s_run = atomicAdd(&Q.ctrl[1], 1u);
+    __syncthreads();
+    const unsigned int run = s_run;
+    if (run >= n_runs) break; // every workgroup reaches this: the cursor only grows
+    for (unsigned int i = (unsigned int)wave; i < (unsigned int)kRun; i += kWaves) {
+      const unsigned int c = run * kRun + i;
+      const unsigned int n = Q.chunk_n[c];
+      if ((unsigned int)lane < n) {
+        ShadeReq r = Q.reqs[(size_t)c * 64 + lane];
+        shade_request<VT, SHADE, AM>(P, vc, tf, mc, r, n_shadow);
+        Q.reqs[(size_t)c * 64 + lane] = r;
+      }
     }
   }
 #pragma unroll
@@ -942,7 +997,7 @@ static hipError_t set_lds(KernT kern, size_t lds)
 
 constexpr int kShadeBlocks = 1024; // persistent shade grid: 4 workgroups per CU
 
-template <int VT, int SHADE, bool BIG>
+template <int VT, int SHADE, int AM>
 static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const hipEvent_t* ev)
 {
   const size_t tf_lds = raymarch_lds_bytes(p.n_color, p.n_alpha);
@@ -952,7 +1007,7 @@ static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const 
   const bool pooled = (SHADE != 0) && p.pool.reqs != nullptr && p.spp == 1;
   if (!pooled) {
     const size_t lds = std::max<size_t>(tf_lds + queue_lds_bytes<SHADE>(), 64); // >= 64 B: the counter reduction reuses it
-    auto kern = raymarch_kernel<VT, SHADE, BIG>;
+    auto kern = raymarch_kernel<VT, SHADE, AM>;
     if ((e = set_lds(kern, lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -965,7 +1020,7 @@ static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const 
   if ((e = hipMemsetAsync(p.pool.ctrl, 0, 4 * sizeof(unsigned int), stream)) != hipSuccess) return e;
   {
     const size_t lds = (size_t)kWaves * kSpillQCap * sizeof(ShadeReq) + (size_t)p.n_alpha * sizeof(float);
-    auto kern = march_spill_kernel<VT, BIG>;
+    auto kern = march_spill_kernel<VT, AM>;
     if ((e = set_lds(kern, lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -973,7 +1028,7 @@ static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const 
   if (ev) (void)hipEventRecord(ev[1], stream);
   {
     const size_t lds = std::max<size_t>(tf_lds, 64);
-    auto kern = shade_pool_kernel<VT, SHADE, BIG>;
+    auto kern = shade_pool_kernel<VT, SHADE, AM>;
     if ((e = set_lds(kern, lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(kShadeBlocks), block, lds, stream, p);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -990,9 +1045,11 @@ static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const 
 template <int VT, int SHADE>
 static hipError_t launch_vs(const RayMarchParams& p, hipStream_t stream, const hipEvent_t* ev)
 {
-  // 32-bit byte offsets (SGPR base + VGPR offset loads) whenever the bricked volume is smaller than 4 GiB
-  if (p.vol.bytes <= 0xffffffffull) return launch_vsb<VT, SHADE, false>(p, stream, ev);
-  return launch_vsb<VT, SHADE, true>(p, stream, ev);
+  // addressing mode: 0 = 32-bit byte offsets (volume <= 4 GiB; largest byte offset = bytes - sizeof(voxel)),
+  //                  1 = 32-bit element offsets (< 2^32 stored voxels), 2 = 64-bit
+  if (p.vol.bytes <= 0x100000000ull) return launch_vsb<VT, SHADE, 0>(p, stream, ev);
+  if (p.vol.bytes / voxel_size(p.vol.type) < 0xffffffffull) return launch_vsb<VT, SHADE, 1>(p, stream, ev);
+  return launch_vsb<VT, SHADE, 2>(p, stream, ev);
 }
 
 template <int VT>
@@ -1025,7 +1082,7 @@ hipError_t launch_raymarch(const RayMarchParams& p, hipStream_t stream, const hi
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// volume relayout: linear (x fastest) -> 128-byte bricks in 32^3 macro blocks
+// volume relayout: linear (x fastest) -> 128-byte x-apron bricks in macro blocks
 // ------------------------------------------------------------------------------------------------------------------
 int device_voxel_type(int t)
 {
@@ -1056,27 +1113,51 @@ template <> struct Conv<int, float> { // array.h:78-90
 };
 
 template <typename TI, typename TO, int VT>
-__global__ __launch_bounds__(256) void relayout_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int nx, int ny, unsigned int macro_y,
+__global__ __launch_bounds__(256) void relayout_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int nx, int ny, int bricks_x, unsigned int macro_y,
                                                       unsigned long long macro_z, int z0, int nz_chunk)
 {
-  // grid: x = ceil(nx / 256), y = ny, z = nz_chunk ; src holds slices [z0, z0 + nz_chunk), x fastest
+  // grid: x = ceil(bricks_x * SX / 256) over STORED x positions, y = ny, z = nz_chunk ; src holds slices [z0, z0 + nz_chunk)
   typedef BrickMap<VT> M;
-  const int x = blockIdx.x * 256 + threadIdx.x;
+  const unsigned sx = blockIdx.x * 256 + threadIdx.x;
   const int y = blockIdx.y, zl = blockIdx.z;
-  if (x >= nx || zl >= nz_chunk) return;
+  if (sx >= (unsigned)bricks_x * M::SX || zl >= nz_chunk) return;
+  const unsigned b = sx / M::SX, xr = sx - b * M::SX;  // brick and position inside its row (xr == cx is the apron)
+  const unsigned x = b * Vox<VT>::cx + xr;
+  const unsigned xs = min(x, (unsigned)(nx - 1));      // beyond the grid: replicate the last voxel (clamp addressing)
   const unsigned z = (unsigned)(z0 + zl);
-  const TI v = src[(size_t)x + (size_t)nx * ((size_t)y + (size_t)ny * (size_t)zl)];
-  const unsigned long long off = (unsigned long long)(M::X((unsigned)x) + M::Y((unsigned)y, macro_y)) + M::Zlo(z) + (unsigned long long)(z >> 5) * macro_z;
+  const TI v = src[(size_t)xs + (size_t)nx * ((size_t)y + (size_t)ny * (size_t)zl)];
+  const unsigned m = M::div_mbx(b), bm = b - m * Vox<VT>::mbx;
+  const unsigned long long off = (unsigned long long)(xr + bm * M::BV + m * M::MV) + M::Y((unsigned)y, macro_y) + M::Zlo(z) + (unsigned long long)(z >> 5) * macro_z;
   dst[off] = Conv<TI, TO>::cv(v);
 }
 
 template <typename TI, typename TO, int VT>
 static hipError_t relayout_t(const void* src, void* dst, const VolumeDesc& vd, int z0, int nzc, hipStream_t stream)
 {
-  dim3 grid((unsigned)((vd.nx + 255) / 256), (unsigned)vd.ny, (unsigned)nzc);
-  hipLaunchKernelGGL((relayout_kernel<TI, TO, VT>), grid, dim3(256), 0, stream, (const TI*)src, (TO*)dst, vd.nx, vd.ny,
-                     32768u * (unsigned)vd.macros_x, 32768ull * (unsigned long long)vd.macros_x * (unsigned long long)vd.macros_y, z0, nzc);
+  typedef BrickMap<VT> M;
+  const int bricks_x = vd.macros_x * Vox<VT>::mbx;
+  dim3 grid((unsigned)((bricks_x * M::SX + 255) / 256), (unsigned)vd.ny, (unsigned)nzc);
+  hipLaunchKernelGGL((relayout_kernel<TI, TO, VT>), grid, dim3(256), 0, stream, (const TI*)src, (TO*)dst, vd.nx, vd.ny, bricks_x,
+                     vd.macro_elems * (unsigned)vd.macros_x, (unsigned long long)vd.macro_elems * (unsigned long long)vd.macros_x * (unsigned long long)vd.macros_y, z0, nzc);
   return hipGetLastError();
+}
+
+// layout constants the host needs to size the allocation
+void volume_layout(int voxel_type, int nx, int ny, int nz, VolumeDesc& vd)
+{
+  unsigned mcx = 30, mv = 0;
+  switch (voxel_type) {
+  case VOX_U8: mcx = BrickMap<VOX_U8>::MCX; mv = BrickMap<VOX_U8>::MV; break;
+  case VOX_I8: mcx = BrickMap<VOX_I8>::MCX; mv = BrickMap<VOX_I8>::MV; break;
+  case VOX_U16: mcx = BrickMap<VOX_U16>::MCX; mv = BrickMap<VOX_U16>::MV; break;
+  case VOX_I16: mcx = BrickMap<VOX_I16>::MCX; mv = BrickMap<VOX_I16>::MV; break;
+  default: mcx = BrickMap<VOX_F32>::MCX; mv = BrickMap<VOX_F32>::MV; break;
+  }
+  vd.macros_x = (nx + (int)mcx - 1) / (int)mcx;
+  vd.macros_y = (ny + 31) / 32;
+  vd.macros_z = (nz + 31) / 32;
+  vd.macro_elems = mv;
+  vd.bytes = (unsigned long long)vd.macros_x * vd.macros_y * vd.macros_z * mv * voxel_size(voxel_type);
 }
 
 hipError_t launch_relayout(const void* src, int vt, void* dst, const VolumeDesc& vd, int z0, int nzc, hipStream_t stream)
