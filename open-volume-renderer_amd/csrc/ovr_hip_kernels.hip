@@ -365,7 +365,10 @@ template <> struct MarchCfg<2> { static constexpr int K = 3, QCAP = 256, KS = OV
 #ifndef OVR_SPILL_K
 #define OVR_SPILL_K 6
 #endif
-constexpr int kRun = 8; // chunks a tile reserves at a time: consecutive chunks of one tile are shaded by ONE workgroup (L1/L2 reuse)
+#ifndef OVR_RUN
+#define OVR_RUN 4
+#endif
+constexpr int kRun = OVR_RUN; // chunks a tile reserves at a time: consecutive chunks of one tile are shaded by ONE workgroup (L1/L2 reuse)
 constexpr int kSpillK = OVR_SPILL_K, kSpillQCap = 128; // march_spill_kernel: spills after every sample, so 63 + 64 slots suffice
 
 struct ShadeReq { // 32 bytes; after shading the same slot holds the result (cx,cy,cz,gx,gy,gz,a,next)
