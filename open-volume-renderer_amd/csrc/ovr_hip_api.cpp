@@ -206,7 +206,8 @@ int resize_framebuffers(ovr_hip_renderer* r, int w, int h)
   }
   HIP_TRY(hipMalloc((void**)&r->d_accum, n * 4 * sizeof(float)));
   HIP_TRY(hipMemset(r->d_accum, 0, n * 4 * sizeof(float)));
-  const size_t nblk = std::max<size_t>((size_t)((w + 15) / 16) * (size_t)((h + 15) / 16), (n + 255) / 256) + 1;
+  // workgroups of the march: 8x8 pixels (4 waves x 16 rays) in dense mode, 64 list entries in sparse mode
+  const size_t nblk = std::max<size_t>((size_t)((w + 7) / 8) * (size_t)((h + 7) / 8), (n + 63) / 64) + 1;
   HIP_TRY(hipMalloc((void**)&r->d_block_counters, nblk * 5 * sizeof(unsigned int)));
   HIP_TRY(hipMalloc((void**)&r->pool.tile_first, nblk * 4 * sizeof(int)));
   HIP_TRY(hipMalloc((void**)&r->pool.tile_count, nblk * 4 * sizeof(unsigned int)));

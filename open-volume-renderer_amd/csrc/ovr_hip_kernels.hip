@@ -558,29 +558,75 @@ __device__ __forceinline__ void store_block_counters(const RayMarchParams& P, un
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// in-place pipeline: march + shade + composite in one kernel
+// the march kernel (both pipelines)
+//
+// Lane mapping - "four lanes per ray": a wave handles 16 rays (a 4x4 pixel tile); the 4 lanes of a quad are 4 CONSECUTIVE
+// STEPS of one ray.  The texture addresser coalesces a gather only inside quads of 4 consecutive lanes (16 clocks per
+// instruction when a quad shares a 128-byte line, 66 when its lanes hit 4 lines - tools/ubench_lines.hip); with one lane
+// per pixel (2 voxels apart at the bench's resolution) a quad almost never shared a brick, with 4 lanes per ray its taps
+// are 1 voxel apart and nearly always do.  A round = K instructions x 4 steps; every lane recomputes the ray's t sequence
+// (tx, ty recurrence, shaders_raymarching.cu:168-169) and the alpha recurrence (:165) for all 4K steps, fetching the
+// other lanes' opacities with DPP quad broadcasts, so the arithmetic and its order are exactly the reference's.
+//   POOLED = false: shade queued requests in place (raymarch pipeline 1)      POOLED = true: spill them to the pool
 // ------------------------------------------------------------------------------------------------------------------
-template <int VT, int SHADE, int AM>
+template <int B>
+__device__ __forceinline__ float quad_bcast(float x) // value of lane B of this lane's quad
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), B * 0x55, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sel4(float a0, float a1, float a2, float a3, int sub) { return sub == 0 ? a0 : sub == 1 ? a1 : sub == 2 ? a2 : a3; }
+
+// which pixel does this QUAD own?  (4x4 pixels per wave, 8x8 per workgroup; sparse mode: 64 list entries per workgroup)
+__device__ __forceinline__ bool assign_pixel_quad(const RayMarchParams& P, int lane, int wave, int& ix, int& iy)
+{
+  const int ray = lane >> 2;
+  bool active;
+  if (P.sparse_xy) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * (kBlock / 4) + (unsigned int)(threadIdx.x >> 2);
+    active = (2ull * i) < *P.sparse_count;
+    ix = active ? P.sparse_xy[2 * i] : 0;
+    iy = active ? P.sparse_xy[2 * i + 1] : 0;
+  }
+  else {
+    ix = blockIdx.x * 8 + (wave & 1) * 4 + (ray & 3);
+    iy = blockIdx.y * 8 + (wave >> 1) * 4 + (ray >> 2);
+    active = ix < P.width && iy < P.height;
+  }
+  if (P.world > 1 && active) active = ((ix / P.tile_w + iy / P.tile_h) % P.world) == P.rank;
+  return active;
+}
+
+template <int SHADE, bool POOLED> struct QCfg {
+  static constexpr int K = POOLED ? 4 : (SHADE == 0 ? 4 : 3);              // instructions (x4 steps) per round
+  static constexpr int QCAP = SHADE == 0 ? 0 : (POOLED ? 128 : 256);       // pooled: spills after every instruction
+};
+
+template <int VT, int SHADE, int AM, bool POOLED>
 __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P)
 {
-  using Cfg = MarchCfg<SHADE>;
+  using Cfg = QCfg<SHADE, POOLED>;
   constexpr int K = Cfg::K;
   constexpr int QCAP = Cfg::QCAP;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & 3;               // this lane's step inside each group of 4 consecutive steps
+  const int qbase = lane & ~3;            // first lane of the quad
+  const bool owner = sub == 0;            // the quad's lane that keeps the pixel's colour / request list
   const unsigned long long t_start = P.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
-  // ---- LDS carve: [request queues][TF colour][TF alpha]
+  // ---- LDS carve: [request queues][TF colour (not needed by the pooled march)][TF alpha]
   ShadeReq* const queue = reinterpret_cast<ShadeReq*>(lds_raw) + (size_t)wave * (QCAP > 0 ? QCAP : 1);
   TfConsts tf;
-  stage_tf(P, lds_raw + (size_t)kWaves * QCAP * sizeof(ShadeReq), true, tf);
+  stage_tf(P, lds_raw + (size_t)kWaves * QCAP * sizeof(ShadeReq), !POOLED, tf);
 
   int ix, iy;
-  const bool active = assign_pixel(P, lane, wave, ix, iy);
+  const bool active = assign_pixel_quad(P, lane, wave, ix, iy);
   unsigned int n_rays = 0, n_samples = 0, n_shaded = 0, n_shadow = 0;
   VolConsts vc;
   MarchConsts mc;
   setup_consts(P, vc, mc);
+  const PoolDesc& Q = P.pool;
+  const unsigned int tile = (blockIdx.x + blockIdx.y * gridDim.x) * kWaves + wave;
 
   const float rsx = 1.f / (float)P.width, rsy = 1.f / (float)P.height;
   const float scx = ((float)ix + .5f) * rsx, scy = ((float)iy + .5f) * rsy;
@@ -594,179 +640,17 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
   const int spp = P.spp;
   // wave-uniform queue cursors (stream positions; slot = position & (QCAP - 1))
   unsigned int q_head = 0, q_tail = 0;
-
-  for (int k_spp = 0; k_spp < spp; ++k_spp) { // uniform trip count: every lane of the wave runs every round
-    float sx = scx, sy = scy;
-    if (spp > 1) {
-      tea16(v0, v1);
-      sx += ((float)v0 * OVR_TEA_TOFLOAT - 0.5f) * rsx;
-      sy += ((float)v1 * OVR_TEA_TOFLOAT - 0.5f) * rsy;
-    }
-    const float ux = sx - 0.5f, uy = sy - 0.5f;
-    const f3 dir = normalize3_exact(mk3(cdir.x + ux * chor.x + uy * cver.x, cdir.y + ux * chor.y + uy * cver.y,
-                                        cdir.z + ux * chor.z + uy * cver.z));
-    // ---- __intersection__volume: object-space ray, direction not renormalised so t is shared
-    const f3 od = mk3(dir.x * mc.inv_scale.x, dir.y * mc.inv_scale.y, dir.z * mc.inv_scale.z);
-    float t0 = 0.f, t1 = FLT_MAX;
-    float alpha = 0.f;
-    f3 color = mk3(0, 0, 0), gradient = mk3(0, 0, 0);
-    bool live = active && intersect_unit_box(t0, t1, oo, od);
-    if (active) ++n_rays;
-    float tx = t0, ty = fminf(t1, t0 + mc.step);
-    int pend = 0;                 // this lane's requests not yet applied
-    unsigned int first = 0, last = 0; // stream positions of its oldest unapplied / newest request
-
-    for (;;) {
-      // ---- (1) shade queued requests: a full batch whenever 64 are queued, the remainder once no ray is live
-      if (SHADE != 0) {
-        const bool any_live = __ballot(live) != 0ull;
-        while ((q_tail - q_head) >= 64u || (!any_live && q_tail != q_head)) {
-          const unsigned int n = min(q_tail - q_head, 64u);
-          __builtin_amdgcn_wave_barrier(); // requests were written by other lanes of this wave (LDS ops are in order)
-          ShadeReq r;
-          r.px = r.py = r.pz = r.s = r.v = r.tr = r.a = 0.f; r.next = 0;
-          if ((unsigned int)lane < n) {
-            r = queue[(q_head + lane) & (QCAP - 1)];
-            shade_request<VT, SHADE, AM>(P, vc, tf, mc, r, n_shadow);
-          }
-          apply_batch(r, q_head, n, lane, pend, first, color, gradient);
-          q_head += n;
-        }
-        if (!any_live) break;
-      }
-      else {
-        if (__ballot(live) == 0ull) break;
-      }
-
-      // ---- (2) primary march: K samples, loads first
-      Tap taps[K];
-      f3 poss[K];
-      float dts[K];
-      bool valid[K];
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        valid[k] = ty > tx;
-        dts[k] = ty - tx;
-        const float tm = 0.5f * (tx + ty);
-        poss[k] = mk3(fmaf(tm, dir.x, org.x), fmaf(tm, dir.y, org.y), fmaf(tm, dir.z, org.z));
-        tap_issue<VT, AM>(vc, to_object(mc, poss[k]), taps[k]);
-        tx = ty;
-        ty = fminf(tx + mc.step, t1);
-      }
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        // branch-free sample processing (see march_shadow): the tap's loads must stay where they were issued
-        const float s = tap_finish<VT>(vc, taps[k]);
-        const float v = tf_coord(tf, s);
-        float a = opacity_correction(tf_alpha(tf, v), mc.base * dts[k]);
-        live = live && valid[k] && (alpha < 0.9999f); // the reference's loop condition, shaders_raymarching.cu:110
-        a = live ? a : 0.f;
-        n_samples += live ? 1u : 0u;
-        // A sample whose corrected opacity is exactly 0 adds exactly 0 to colour, gradient and alpha (its colour
-        // passes through clamp01 first, so it is finite): nothing is shaded for it.
-        const bool push = a > 0.f;
-        n_shaded += push ? 1u : 0u;
-        const float tr = 1.f - alpha;
-        if (SHADE == 0) {
-          if (push) {
-            const f3 rgb = tf_color(tf, v);
-            color.x = fmaf(tr * clamp01(rgb.x), a, color.x);
-            color.y = fmaf(tr * clamp01(rgb.y), a, color.y);
-            color.z = fmaf(tr * clamp01(rgb.z), a, color.z);
-          }
-        }
-        alpha = push ? fmaf(tr, a, alpha) : alpha;
-        if (SHADE != 0) {
-          const unsigned long long m = __ballot(push);
-          if (m != 0ull) {
-            if (push) {
-              const unsigned int pos_q = q_tail + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-              ShadeReq r;
-              r.px = poss[k].x; r.py = poss[k].y; r.pz = poss[k].z;
-              r.s = s; r.v = v; r.tr = tr; r.a = a; r.next = 0;
-              queue[pos_q & (QCAP - 1)] = r;
-              if (pend > 0) queue[last & (QCAP - 1)].next = (int)pos_q; else first = pos_q;
-              last = pos_q;
-              ++pend;
-            }
-            q_tail += (unsigned int)__popcll(m);
-          }
-        }
-      }
-    }
-
-    // render_raymarching / alpha_blend with an always-missing background (shaders_raymarching.cu:260-321)
-    o_a += alpha;
-    if (alpha > 0.f) {
-      o_c.x += color.x / alpha; o_c.y += color.y / alpha; o_c.z += color.z / alpha;
-      o_g.x += gradient.x / alpha; o_g.y += gradient.y / alpha; o_g.z += gradient.z / alpha;
-    }
-  }
-
-  if (active) {
-    const float rspp = 1.f / (float)spp;
-    o_a *= rspp;
-    o_c.x *= rspp; o_c.y *= rspp; o_c.z *= rspp;
-    o_g.x *= rspp; o_g.y *= rspp; o_g.z *= rspp;
-    write_pixel(P, pixel_index, o_c, o_a, o_g);
-  }
-
-  if (P.trace && lane == 0) { // diagnostic only (OVR_HIP_TRACE): per-wave residency interval and work, never read by the kernel
-    const unsigned int bid = blockIdx.x + blockIdx.y * gridDim.x;
-    unsigned long long* t = P.trace + ((size_t)bid * kWaves + wave) * 4;
-    t[0] = t_start; t[1] = __builtin_amdgcn_s_memrealtime();
-    t[2] = ((unsigned long long)n_samples << 32) | n_shaded; t[3] = n_shadow;
-  }
-  store_block_counters(P, reinterpret_cast<unsigned int*>(lds_raw), lane, wave, n_rays, n_samples, n_shaded, n_shadow, active ? 1u : 0u);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// pooled pipeline, kernel A: primary march; full batches of 64 requests are spilled to the global pool as chunks
-// ------------------------------------------------------------------------------------------------------------------
-template <int VT, int AM>
-__global__ __launch_bounds__(kBlock) void march_spill_kernel(const RayMarchParams P)
-{
-  constexpr int K = kSpillK;
-  constexpr int QCAP = kSpillQCap;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned long long t_start = P.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
-  ShadeReq* const queue = reinterpret_cast<ShadeReq*>(lds_raw) + (size_t)wave * QCAP;
-  TfConsts tf;
-  stage_tf(P, lds_raw + (size_t)kWaves * QCAP * sizeof(ShadeReq), false, tf); // alpha table only
-
-  int ix, iy;
-  const bool active = assign_pixel(P, lane, wave, ix, iy);
-  unsigned int n_rays = 0, n_samples = 0, n_shaded = 0;
-  VolConsts vc;
-  MarchConsts mc;
-  setup_consts(P, vc, mc);
-  const PoolDesc& Q = P.pool;
-  const unsigned int tile = (blockIdx.x + blockIdx.y * gridDim.x) * kWaves + wave;
-
-  const float rsx = 1.f / (float)P.width, rsy = 1.f / (float)P.height;
-  const float scx = ((float)ix + .5f) * rsx, scy = ((float)iy + .5f) * rsy;
-  const unsigned int pixel_index = (unsigned int)ix + (unsigned int)iy * (unsigned int)P.width;
-  const f3 org = ld3(P.cam_pos), cdir = ld3(P.cam_dir), chor = ld3(P.cam_hor), cver = ld3(P.cam_ver);
-  const f3 oo = to_object(mc, org);
-  const float ux = scx - 0.5f, uy = scy - 0.5f; // spp == 1: no jitter (shaders_raymarching.cu:354)
-  const f3 dir = normalize3_exact(mk3(cdir.x + ux * chor.x + uy * cver.x, cdir.y + ux * chor.y + uy * cver.y,
-                                      cdir.z + ux * chor.z + uy * cver.z));
-  const f3 od = mk3(dir.x * mc.inv_scale.x, dir.y * mc.inv_scale.y, dir.z * mc.inv_scale.z);
-  float t0 = 0.f, t1 = FLT_MAX;
-  float alpha = 0.f;
-  bool live = active && intersect_unit_box(t0, t1, oo, od);
-  if (active) ++n_rays;
-  float tx = t0, ty = fminf(t1, t0 + mc.step);
-  int pend = 0;
-  unsigned int first = 0, last = 0;
-  unsigned int last_gidx = 0;  // pool index of this lane's newest request once it has been spilled
-  unsigned int q_head = 0, q_tail = 0;
+  // pooled: the tile's current reservation of kRun consecutive chunks
+  unsigned int run_base = 0, run_left = 0;
   int prev_chunk = -1;
-  if (lane == 0) Q.tile_first[tile] = -1;
+  if (POOLED && lane == 0) Q.tile_first[tile] = -1;
+  // per-ray request list (identical in the 4 lanes of the quad; the owner lane applies the contributions)
+  int pend = 0;
+  unsigned int first = 0, last = 0, last_gidx = 0;
+  float alpha = 0.f;
+  f3 color = mk3(0, 0, 0), gradient = mk3(0, 0, 0);
 
-  // spill the n oldest queued requests as one chunk of the global pool (small: inlined after every sample)
-  unsigned int run_base = 0, run_left = 0; // the tile's current reservation of kRun consecutive chunks
+  // pooled: spill the n oldest queued requests as one chunk of the global pool
   auto spill = [&](unsigned int n) {
     if (run_left == 0) {
       unsigned int c0 = 0;
@@ -791,72 +675,176 @@ __global__ __launch_bounds__(kBlock) void march_spill_kernel(const RayMarchParam
     q_head += n;
   };
 
-  for (;;) {
-    if (__ballot(live) == 0ull) break;
-
-    // ---- (2) primary march: K samples, loads first
-    Tap taps[K];
-    f3 poss[K];
-    float dts[K];
-    bool valid[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      valid[k] = ty > tx;
-      dts[k] = ty - tx;
-      const float tm = 0.5f * (tx + ty);
-      poss[k] = mk3(fmaf(tm, dir.x, org.x), fmaf(tm, dir.y, org.y), fmaf(tm, dir.z, org.z));
-      tap_issue<VT, AM>(vc, to_object(mc, poss[k]), taps[k]);
-      tx = ty;
-      ty = fminf(tx + mc.step, t1);
+  for (int k_spp = 0; k_spp < spp; ++k_spp) { // uniform trip count: every lane of the wave runs every round
+    float sx = scx, sy = scy;
+    if (spp > 1) {
+      tea16(v0, v1);
+      sx += ((float)v0 * OVR_TEA_TOFLOAT - 0.5f) * rsx;
+      sy += ((float)v1 * OVR_TEA_TOFLOAT - 0.5f) * rsy;
     }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      // branch-free sample processing (see march_shadow)
-      const float s = tap_finish<VT>(vc, taps[k]);
-      const float v = tf_coord(tf, s);
-      float a = opacity_correction(tf_alpha(tf, v), mc.base * dts[k]);
-      live = live && valid[k] && (alpha < 0.9999f);
-      a = live ? a : 0.f;
-      n_samples += live ? 1u : 0u;
-      const bool push = a > 0.f;
-      n_shaded += push ? 1u : 0u;
-      const float tr = 1.f - alpha;
-      alpha = push ? fmaf(tr, a, alpha) : alpha;
-      const unsigned long long m = __ballot(push);
-      if (m != 0ull) {
-        if (push) {
-          const unsigned int pos_q = q_tail + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+    const float ux = sx - 0.5f, uy = sy - 0.5f;
+    const f3 dir = normalize3_exact(mk3(cdir.x + ux * chor.x + uy * cver.x, cdir.y + ux * chor.y + uy * cver.y,
+                                        cdir.z + ux * chor.z + uy * cver.z));
+    // ---- __intersection__volume: object-space ray, direction not renormalised so t is shared
+    const f3 od = mk3(dir.x * mc.inv_scale.x, dir.y * mc.inv_scale.y, dir.z * mc.inv_scale.z);
+    float t0 = 0.f, t1 = FLT_MAX;
+    alpha = 0.f;
+    color = mk3(0, 0, 0);
+    gradient = mk3(0, 0, 0);
+    bool live = active && intersect_unit_box(t0, t1, oo, od);
+    if (active && owner) ++n_rays;
+    float tx = t0, ty = fminf(t1, t0 + mc.step);
+    pend = 0;
+
+    for (;;) {
+      const bool any_live = __ballot(live) != 0ull;
+      // ---- (1) in place: shade queued requests, a full batch whenever 64 are queued, the remainder once no ray is live
+      if (SHADE != 0 && !POOLED) {
+        while ((q_tail - q_head) >= 64u || (!any_live && q_tail != q_head)) {
+          const unsigned int n = min(q_tail - q_head, 64u);
+          __builtin_amdgcn_wave_barrier(); // requests were written by other lanes of this wave (LDS ops are in order)
           ShadeReq r;
-          r.px = poss[k].x; r.py = poss[k].y; r.pz = poss[k].z;
-          r.s = s; r.v = v; r.tr = tr; r.a = a; r.next = 0;
-          queue[pos_q & (QCAP - 1)] = r;
-          if (pend > 0) {
-            if ((int)(last - q_head) >= 0) queue[last & (QCAP - 1)].next = (int)pos_q; // still in LDS
-            else Q.reqs[last_gidx].next = (int)pos_q;                                 // already spilled
+          r.px = r.py = r.pz = r.s = r.v = r.tr = r.a = 0.f; r.next = 0;
+          if ((unsigned int)lane < n) {
+            r = queue[(q_head + lane) & (QCAP - 1)];
+            shade_request<VT, SHADE, AM>(P, vc, tf, mc, r, n_shadow);
           }
-          else {
-            first = pos_q;
-          }
-          last = pos_q;
-          ++pend;
+          int opend = owner ? pend : 0;
+          apply_batch(r, q_head, n, lane, opend, first, color, gradient);
+          // the quad's lanes keep identical list cursors: take the owner's
+          pend = __builtin_amdgcn_ds_bpermute(qbase << 2, opend);
+          first = (unsigned int)__builtin_amdgcn_ds_bpermute(qbase << 2, (int)first);
+          q_head += n;
         }
-        q_tail += (unsigned int)__popcll(m);
-        if ((q_tail - q_head) >= 64u) spill(64u);
+      }
+      if (!any_live) break;
+
+      // ---- (2) the ray's next 4K steps: every lane runs the (tx, ty) recurrence, then keeps its own K steps
+      float txa[4 * K], tya[4 * K];
+#pragma unroll
+      for (int j = 0; j < 4 * K; ++j) {
+        txa[j] = tx; tya[j] = ty;
+        tx = ty;
+        ty = fminf(tx + mc.step, t1);
+      }
+      Tap taps[K];
+      f3 poss[K];
+      float dts[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float mtx = sel4(txa[4 * k], txa[4 * k + 1], txa[4 * k + 2], txa[4 * k + 3], sub);
+        const float mty = sel4(tya[4 * k], tya[4 * k + 1], tya[4 * k + 2], tya[4 * k + 3], sub);
+        dts[k] = mty - mtx;
+        const float tm = 0.5f * (mtx + mty);
+        poss[k] = mk3(fmaf(tm, dir.x, org.x), fmaf(tm, dir.y, org.y), fmaf(tm, dir.z, org.z));
+        tap_issue<VT, AM>(vc, to_object(mc, poss[k]), taps[k]);
+      }
+      // ---- (3) own samples: value, TF coordinate, corrected opacity (and colour when shading is off)
+      float sa[K], va[K], aa[K];
+      f3 ca[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        sa[k] = tap_finish<VT>(vc, taps[k]);
+        va[k] = tf_coord(tf, sa[k]);
+        aa[k] = opacity_correction(tf_alpha(tf, va[k]), mc.base * dts[k]);
+        if (SHADE == 0) {
+          const f3 rgb = tf_color(tf, va[k]);
+          ca[k] = mk3(clamp01(rgb.x), clamp01(rgb.y), clamp01(rgb.z));
+        }
+      }
+      // ---- (4) the ray's alpha recurrence over the 4K steps, in order; every lane of the quad computes all of it
+      bool mlive[K], mpush[K];
+      float mtr[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+#define OVR_STEP(B)                                                                                                            \
+        {                                                                                                                      \
+          const float aj = quad_bcast<B>(aa[k]);                                                                               \
+          live = live && (tya[4 * k + B] > txa[4 * k + B]) && (alpha < 0.9999f); /* shaders_raymarching.cu:110 */              \
+          const float ae = live ? aj : 0.f;                                                                                    \
+          /* a sample whose corrected opacity is exactly 0 adds exactly 0 to colour, gradient and alpha: nothing is shaded */  \
+          const bool pj = ae > 0.f;                                                                                            \
+          const float trj = 1.f - alpha;                                                                                       \
+          if (SHADE == 0) {                                                                                                    \
+            const float cxj = quad_bcast<B>(ca[k].x), cyj = quad_bcast<B>(ca[k].y), czj = quad_bcast<B>(ca[k].z);              \
+            color.x = pj ? fmaf(trj * cxj, ae, color.x) : color.x;                                                             \
+            color.y = pj ? fmaf(trj * cyj, ae, color.y) : color.y;                                                             \
+            color.z = pj ? fmaf(trj * czj, ae, color.z) : color.z;                                                             \
+          }                                                                                                                    \
+          alpha = pj ? fmaf(trj, ae, alpha) : alpha;                                                                           \
+          if (sub == B) { mlive[k] = live; mpush[k] = pj; mtr[k] = trj; }                                                      \
+        }
+        OVR_STEP(0) OVR_STEP(1) OVR_STEP(2) OVR_STEP(3)
+#undef OVR_STEP
+      }
+      // ---- (5) count; queue the samples that need shading (slot = tail + prefix of the ballot, lane order = step order)
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        n_samples += mlive[k] ? 1u : 0u;
+        n_shaded += mpush[k] ? 1u : 0u;
+        if (SHADE != 0) {
+          const bool push = mpush[k];
+          const unsigned long long m = __ballot(push);
+          if (m != 0ull) {
+            const unsigned int below = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+            const unsigned int quad_bits = (unsigned int)(m >> qbase) & 0xfu;
+            const unsigned int quad_first = q_tail + (unsigned int)__popcll(m & ((1ull << qbase) - 1ull)); // position of the quad's first push
+            const unsigned int quad_n = (unsigned int)__popc(quad_bits);
+            if (push) {
+              const unsigned int pos_q = q_tail + below;
+              ShadeReq r;
+              r.px = poss[k].x; r.py = poss[k].y; r.pz = poss[k].z;
+              r.s = sa[k]; r.v = va[k]; r.tr = mtr[k]; r.a = aa[k];
+              r.next = (quad_bits >> (sub + 1)) != 0u ? (int)(pos_q + 1u) : 0; // a later step of this ray is pushed by this instruction
+              queue[pos_q & (QCAP - 1)] = r;
+              if (pos_q == quad_first && pend > 0) { // link the ray's previous request to this one
+                if (!POOLED || (int)(last - q_head) >= 0) queue[last & (QCAP - 1)].next = (int)pos_q; // still in LDS
+                else Q.reqs[last_gidx].next = (int)pos_q;                                              // already spilled
+              }
+            }
+            if (quad_n != 0u) {
+              if (pend == 0) first = quad_first;
+              last = quad_first + quad_n - 1u;
+              pend += (int)quad_n;
+            }
+            q_tail += (unsigned int)__popcll(m);
+            if (POOLED && (q_tail - q_head) >= 64u) spill(64u);
+          }
+        }
+      }
+    }
+
+    // render_raymarching / alpha_blend with an always-missing background (shaders_raymarching.cu:260-321)
+    if (!POOLED) {
+      o_a += alpha;
+      if (alpha > 0.f) {
+        o_c.x += color.x / alpha; o_c.y += color.y / alpha; o_c.z += color.z / alpha;
+        o_g.x += gradient.x / alpha; o_g.y += gradient.y / alpha; o_g.z += gradient.z / alpha;
       }
     }
   }
-  if (q_tail != q_head) spill(q_tail - q_head); // the tile's last, partial chunk
-  if (lane == 0 && run_base + kRun <= Q.capacity)
-    for (unsigned int i = kRun - run_left; i < (unsigned int)kRun && run_left != 0; ++i) Q.chunk_n[run_base + i] = 0; // unused tail of the reservation
 
-  if (lane == 0) Q.tile_count[tile] = q_tail;
-  if (P.trace && lane == 0) { // diagnostic only (OVR_HIP_TRACE)
+  if (POOLED) {
+    if (q_tail != q_head) spill(q_tail - q_head); // the tile's last, partial chunk
+    if (lane == 0 && run_base + kRun <= Q.capacity)
+      for (unsigned int i = kRun - run_left; i < (unsigned int)kRun && run_left != 0; ++i) Q.chunk_n[run_base + i] = 0; // unused tail of the reservation
+    if (lane == 0) Q.tile_count[tile] = q_tail;
+    if (active && owner) Q.pix_state[pixel_index] = make_float4(alpha, __uint_as_float(first), __int_as_float(pend), 0.f);
+  }
+  else if (active && owner) {
+    const float rspp = 1.f / (float)spp;
+    o_a *= rspp;
+    o_c.x *= rspp; o_c.y *= rspp; o_c.z *= rspp;
+    o_g.x *= rspp; o_g.y *= rspp; o_g.z *= rspp;
+    write_pixel(P, pixel_index, o_c, o_a, o_g);
+  }
+
+  if (P.trace && lane == 0) { // diagnostic only (OVR_HIP_TRACE): per-wave residency interval and work, never read by the kernel
     unsigned long long* t = P.trace + (size_t)tile * 4;
     t[0] = t_start; t[1] = __builtin_amdgcn_s_memrealtime();
-    t[2] = ((unsigned long long)n_samples << 32) | n_shaded; t[3] = q_tail;
+    t[2] = ((unsigned long long)n_samples << 32) | n_shaded; t[3] = n_shadow;
   }
-  if (active) Q.pix_state[pixel_index] = make_float4(alpha, __uint_as_float(first), __int_as_float(pend), 0.f);
-  store_block_counters(P, reinterpret_cast<unsigned int*>(lds_raw), lane, wave, n_rays, n_samples, n_shaded, 0u, active ? 1u : 0u);
+  store_block_counters(P, reinterpret_cast<unsigned int*>(lds_raw), lane, wave, n_rays, n_samples, n_shaded, n_shadow, (active && owner) ? 1u : 0u);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -910,7 +898,7 @@ __global__ __launch_bounds__(kBlock) void composite_kernel(const RayMarchParams 
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int ix, iy;
-  const bool active = assign_pixel(P, lane, wave, ix, iy);
+  const bool active = assign_pixel_quad(P, lane, wave, ix, iy) && (lane & 3) == 0; // one owner lane per ray, as in the march
   const PoolDesc& Q = P.pool;
   if (Q.ctrl[0] > Q.capacity) return; // pool overflow: the host re-renders this frame with a larger pool, nothing may be written
   const unsigned int tile = (blockIdx.x + blockIdx.y * gridDim.x) * kWaves + wave;
@@ -970,8 +958,6 @@ __global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned int
   if (threadIdx.x < 5) counters[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-template <int SHADE> static size_t queue_lds_bytes() { return (size_t)kWaves * MarchCfg<SHADE>::QCAP * sizeof(ShadeReq); }
-
 size_t raymarch_lds_bytes(int n_color, int n_alpha)
 {
   // the transfer function always lives in LDS; 0 = does not fit next to the request queues (caller reports an error)
@@ -981,14 +967,14 @@ size_t raymarch_lds_bytes(int n_color, int n_alpha)
 
 size_t raymarch_grid_blocks(const RayMarchParams& p)
 {
-  if (p.sparse_xy) return ((size_t)p.width * p.height + kBlock - 1) / kBlock;
-  return (size_t)((p.width + 15) / 16) * (size_t)((p.height + 15) / 16);
+  if (p.sparse_xy) return ((size_t)p.width * p.height + kBlock / 4 - 1) / (kBlock / 4);
+  return (size_t)((p.width + 7) / 8) * (size_t)((p.height + 7) / 8);
 }
 
 static dim3 raymarch_grid(const RayMarchParams& p)
 {
-  if (p.sparse_xy) return dim3((unsigned)(((size_t)p.width * p.height + kBlock - 1) / kBlock));
-  return dim3((unsigned)((p.width + 15) / 16), (unsigned)((p.height + 15) / 16));
+  if (p.sparse_xy) return dim3((unsigned)(((size_t)p.width * p.height + kBlock / 4 - 1) / (kBlock / 4)));
+  return dim3((unsigned)((p.width + 7) / 8), (unsigned)((p.height + 7) / 8));
 }
 
 template <typename KernT>
@@ -1009,8 +995,8 @@ static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const 
   hipError_t e;
   const bool pooled = (SHADE != 0) && p.pool.reqs != nullptr && p.spp == 1;
   if (!pooled) {
-    const size_t lds = std::max<size_t>(tf_lds + queue_lds_bytes<SHADE>(), 64); // >= 64 B: the counter reduction reuses it
-    auto kern = raymarch_kernel<VT, SHADE, AM>;
+    const size_t lds = std::max<size_t>(tf_lds + (size_t)kWaves * QCfg<SHADE, false>::QCAP * sizeof(ShadeReq), 64); // >= 64 B: the counter reduction reuses it
+    auto kern = raymarch_kernel<VT, SHADE, AM, false>;
     if ((e = set_lds(kern, lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -1022,8 +1008,9 @@ static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const 
   // ---- pooled pipeline
   if ((e = hipMemsetAsync(p.pool.ctrl, 0, 4 * sizeof(unsigned int), stream)) != hipSuccess) return e;
   {
-    const size_t lds = (size_t)kWaves * kSpillQCap * sizeof(ShadeReq) + (size_t)p.n_alpha * sizeof(float);
-    auto kern = march_spill_kernel<VT, AM>;
+    constexpr int SH = SHADE == 0 ? 1 : SHADE; // (never instantiated for SHADE == 0: pooled is false)
+    const size_t lds = (size_t)kWaves * QCfg<SH, true>::QCAP * sizeof(ShadeReq) + (size_t)p.n_alpha * sizeof(float) + 64;
+    auto kern = raymarch_kernel<VT, SH, AM, true>;
     if ((e = set_lds(kern, lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     if ((e = hipGetLastError()) != hipSuccess) return e;
