@@ -45,3 +45,169 @@ def test_pipelines_bit_identical(ovr, oracle, hip_renderer_factory, shading):
     for k in ("rays", "samples", "shaded_samples", "shadow_samples"):
         assert getattr(frames[0][2], k) == getattr(frames[1][2], k)
     assert frames[1][2].pool_chunks > 0
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.int8, np.uint16, np.int16, np.float64, np.uint32, np.int32])
+def test_dtypes(ovr, oracle, hip_renderer_factory, dtype):
+    """every reference ValueType: u8/i8 normalised reads, u16/i16/f64 sampled as raw float (array.cpp:322-347)"""
+    case = make_case(ovr, oracle, n=24, dtype=dtype, tf="bumps", cam="oblique", size=(48, 40), shading=2)
+    if dtype in (np.uint32, np.int32):
+        # normalised 32-bit reads: the TF range is given in raw units and normalised like the data (array.h:96-99)
+        # (float cannot hold UINT32_MAX / INT32_MAX: the casts in integer_normalize would overflow, in the reference too)
+        case["vr"] = (0.0, 4.0e9) if dtype == np.uint32 else (-2.0e9, 2.0e9)
+    ref_rgba, ref_grad, cnt = oracle_scene(oracle, case).render()
+    ren = hip_setup(ovr, hip_renderer_factory(), case)
+    ren.render()
+    rgba, grad = hip_frame(ovr, ren)
+    # integer volumes have flat regions: zero gradients -> NaN normals -> colour 0 on both sides (DESIGN.md 3)
+    compare(oracle, rgba, ref_rgba, tol_float=5e-4, name=str(dtype))
+    st = ren.stats()
+    assert st.samples == cnt.samples and st.shaded_samples == cnt.shaded_samples
+    assert st.shadow_samples == cnt.shadow_samples_visible
+    assert cnt.shaded_samples > 0
+
+
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_non_cubic_spacing_origin_vertex_convention(ovr, oracle, hip_renderer_factory, pipeline):
+    case = make_case(ovr, oracle, n=0, dims=(40, 23, 31), tf="bumps", cam="oblique", size=(57, 43), shading=2, convention=1,
+                     spacing=(1.0, 1.5, 0.75), origin=(3.0, -2.0, 5.0), rate=2.0)
+    ref_rgba, ref_grad, cnt = oracle_scene(oracle, case).render()
+    ren = hip_setup(ovr, hip_renderer_factory(), case, pipeline=pipeline)
+    ren.render()
+    rgba, grad = hip_frame(ovr, ren)
+    compare(oracle, rgba, ref_rgba, name="aniso")
+    assert np.abs(grad - ref_grad).max() <= 2e-3
+    st = ren.stats()
+    assert (st.rays, st.samples, st.shaded_samples) == (cnt.rays, cnt.samples, cnt.shaded_samples)
+    assert st.active_pixels == 57 * 43
+
+
+def test_camera_inside_volume(ovr, oracle, hip_renderer_factory):
+    case = make_case(ovr, oracle, n=32, tf="sparse", cam="inside", size=(64, 64), shading=2)
+    ref_rgba, _, cnt = oracle_scene(oracle, case).render()
+    ren = hip_setup(ovr, hip_renderer_factory(), case)
+    ren.render()
+    rgba, _ = hip_frame(ovr, ren)
+    compare(oracle, rgba, ref_rgba, name="inside")
+    assert ren.stats().samples == cnt.samples
+
+
+@pytest.mark.parametrize("spp", [1, 3])
+def test_accumulation_and_spp(ovr, oracle, hip_renderer_factory, spp):
+    """frame accumulation over 3 frames (shaders_raymarching.cu:389-403) and TEA pixel jitter when spp > 1 (:351-357)"""
+    case = make_case(ovr, oracle, n=24, tf="bumps", cam="oblique", size=(40, 32), shading=2, spp=spp)
+    ref_rgba, _, cnt = oracle_scene(oracle, case).render(frames=3, accumulate=True)
+    ren = hip_setup(ovr, hip_renderer_factory(), case, accumulate=True)
+    for _ in range(3):
+        ren.render()
+    st = ren.stats()
+    assert st.frame_index == 3
+    rgba, _ = hip_frame(ovr, ren)
+    compare(oracle, rgba, ref_rgba, name=f"accum spp{spp}")
+    assert st.rays == 40 * 32 * spp and st.samples == cnt.samples
+    # any committed change restarts the accumulation (device_impl.cpp:116-196,225-233)
+    ren.set_volume_sampling_rate(1.0)
+    ren.commit()
+    ren.render()
+    assert ren.stats().frame_index == 1
+
+
+def test_sparse_sampling_mask_and_frame(ovr, oracle, hip_renderer_factory):
+    """foveated sparse sampling: the compacted pixel list must be bit-identical (integer work), the frame matches at the
+    sampled pixels and is zero elsewhere (device_impl.cpp:234-239)"""
+    rng = np.random.default_rng(11)
+    noise = (rng.integers(0, 256, size=(64, 64, 64)) / 255.0).astype(np.float32)
+    case = make_case(ovr, oracle, n=24, tf="bumps", cam="oblique", size=(72, 40), shading=2)
+    focus = ((0.45, 0.55), 0.25, 0.1)
+    sc = oracle_scene(oracle, case, sparse=True, focus=focus, noise=noise)
+    ren = hip_setup(ovr, hip_renderer_factory(), case)
+    ren.set_noise_tile(noise)
+    ren.set_focus(*focus)
+    ren.set_sparse_sampling(True)
+    ren.commit()
+    for frame in (1, 2, 70):
+        exp = oracle.sparse_mask(frame, 72, 40, focus[0], focus[1], focus[2], noise)
+        got = ren.sparse_mask(frame)
+        assert np.array_equal(got, exp), f"mask differs at frame {frame}"
+    ren.render()   # frame_index 1, no accumulation
+    rgba, _ = hip_frame(ovr, ren)
+    ref_rgba, _, cnt = sc.render(frames=1)
+    compare(oracle, rgba, ref_rgba, name="sparse frame")
+    st = ren.stats()
+    n_kept = len(oracle.sparse_mask(1, 72, 40, focus[0], focus[1], focus[2], noise)) // 2
+    assert st.active_pixels == n_kept and 0 < n_kept < 72 * 40
+    assert st.samples == cnt.samples
+
+
+def test_tea_kat_on_device(ovr, oracle, hip_renderer_factory):
+    ren = hip_setup(ovr, hip_renderer_factory(), make_case(ovr, oracle, n=8, size=(8, 8)))
+    seeds = np.array([[1, 0], [1, 12345], [7, 2073599], [0xFFFFFFFF, 0xFFFFFFFF], [0, 0]], dtype=np.uint32)
+    floats, states = ren.tea_floats(seeds)
+    for i, (a, b) in enumerate(seeds):
+        (f0, f1), st = oracle.tea_floats(int(a), int(b))
+        assert floats[2 * i] == np.float32(f0) and floats[2 * i + 1] == np.float32(f1)
+        assert tuple(states.reshape(-1, 2)[i]) == st
+
+
+def test_double_buffer_and_device_mapping(ovr, oracle, hip_renderer_factory):
+    """renderapp's protocol: commit, mapframe (previous frame), swap, render (apps/main_app.cpp:244-263); the mapped frame
+    must stay intact while the next one renders into the other set; device mapping hands out HBM without a copy"""
+    import torch
+    case = make_case(ovr, oracle, n=24, tf="bumps", cam="front", size=(48, 32), shading=1)
+    ren = hip_setup(ovr, hip_renderer_factory(), case)
+    ren.render()
+    fb_dev = ovr.FrameBufferData()
+    ren.mapframe(fb_dev, device=True)
+    assert fb_dev.rgba.data().is_cuda and fb_dev.rgba.data().shape == (32, 48, 4)
+    first = fb_dev.rgba.to_cpu().data().copy()
+    ren.swap()
+    eye, at, up = case["cam"]
+    ren.set_camera((eye[0] + 5.0, eye[1], eye[2]), at, up)
+    ren.commit()
+    ren.render()
+    torch.cuda.synchronize()
+    assert np.array_equal(fb_dev.rgba.to_cpu().data(), first), "the mapped set was overwritten by the next render"
+    second, _ = hip_frame(ovr, ren)
+    assert not np.array_equal(second, first)
+
+
+def test_image_shards_reassemble_bit_exactly(ovr, oracle, hip_renderer_factory):
+    """multi-GPU image-plane sharding on ONE card: 3 renderers play 3 ranks; pack -> unpack must rebuild the unsharded frame"""
+    import ctypes as C
+    import torch
+    case = make_case(ovr, oracle, n=24, tf="bumps", cam="oblique", size=(80, 56), shading=2)
+    full = hip_setup(ovr, hip_renderer_factory(), case)
+    full.render()
+    ref, _ = hip_frame(ovr, full)
+    world, TW, TH = 3, 16, 8
+    slots = ovr.tiles.max_owned_tiles(80, 56, TW, TH, world)
+    frame = torch.zeros((56, 80, 4), dtype=torch.float32, device="cuda")
+    root = None
+    for rank in range(world):
+        ren = hip_renderer_factory()
+        ren.set_image_shard(rank, world, TW, TH)
+        hip_setup(ovr, ren, case)
+        ren.render()
+        assert ren.stats().active_pixels == sum(min(TW, 80 - tx * TW) * min(TH, 56 - ty * TH) for tx, ty in ovr.tiles.owned_tiles(80, 56, TW, TH, rank, world))
+        payload = torch.zeros((slots, TH, TW, 4), dtype=torch.float32, device="cuda")
+        ovr._lib.check(ren._lib.ovr_hip_pack_tiles(ren._h, C.c_void_p(payload.data_ptr()), payload.numel() * 4))
+        ren.sync()
+        root = root or ren
+        torch.cuda.synchronize()
+        ovr._lib.check(root._lib.ovr_hip_unpack_tiles(root._h, rank, C.c_void_p(payload.data_ptr()), payload.numel() * 4,
+                                                      C.c_void_p(frame.data_ptr()), frame.numel() * 4))
+        root.sync()
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), ref)
+
+
+def test_errors_are_loud(ovr, oracle, hip_renderer_factory):
+    ren = hip_renderer_factory()
+    ren.set_fbsize((16, 16))
+    ren.commit()
+    with pytest.raises(RuntimeError, match="before a volume was set"):
+        ren.render()
+    with pytest.raises(RuntimeError, match="positive"):
+        ren.set_sample_per_pixel(0)
+    with pytest.raises(RuntimeError, match="path tracing"):
+        ren.set_path_tracing(True)
