@@ -362,14 +362,9 @@ template <> struct MarchCfg<1> { static constexpr int K = 3, QCAP = 256, KS = 1;
 #define OVR_SHADOW_K 4
 #endif
 template <> struct MarchCfg<2> { static constexpr int K = 3, QCAP = 256, KS = OVR_SHADOW_K; };
-#ifndef OVR_SPILL_K
-#define OVR_SPILL_K 6
-#endif
-#ifndef OVR_RUN
-#define OVR_RUN 4
-#endif
-constexpr int kRun = OVR_RUN; // chunks a tile reserves at a time: consecutive chunks of one tile are shaded by ONE workgroup (L1/L2 reuse)
-constexpr int kSpillK = OVR_SPILL_K, kSpillQCap = 128; // march_spill_kernel: spills after every sample, so 63 + 64 slots suffice
+// chunks a tile reserves at a time: consecutive chunks of one tile are shaded by ONE workgroup, one chunk per wave
+// (L1/L2 reuse: measured 2.4 -> 1.5 ms for the shading kernel at C3; 8 / 16 / 32 are slower - imbalance)
+constexpr int kRun = 4;
 
 struct ShadeReq { // 32 bytes; after shading the same slot holds the result (cx,cy,cz,gx,gy,gz,a,next)
   float px, py, pz; // world-space sample position          | colour contribution  tr*clamp01(rgb*shade)
@@ -597,7 +592,10 @@ __device__ __forceinline__ bool assign_pixel_quad(const RayMarchParams& P, int l
 }
 
 template <int SHADE, bool POOLED> struct QCfg {
-  static constexpr int K = POOLED ? 4 : (SHADE == 0 ? 4 : 3);              // instructions (x4 steps) per round
+#ifndef OVR_POOLED_K
+#define OVR_POOLED_K 4
+#endif
+  static constexpr int K = POOLED ? OVR_POOLED_K : (SHADE == 0 ? 4 : 3);   // instructions (x4 steps) per round
   static constexpr int QCAP = SHADE == 0 ? 0 : (POOLED ? 128 : 256);       // pooled: spills after every instruction
 };
 
