@@ -705,7 +705,7 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
           r.px = r.py = r.pz = r.s = r.v = r.tr = r.a = 0.f; r.next = 0;
           if ((unsigned int)lane < n) {
             r = queue[(q_head + lane) & (QCAP - 1)];
-            shade_request<VT, SHADE, AM>(P, vc, tf, mc, r, n_shadow);
+            if (r.a > 0.f) shade_request<VT, SHADE, AM>(P, vc, tf, mc, r, n_shadow); // a == 0: null request
           }
           int opend = owner ? pend : 0;
           apply_batch(r, q_head, n, lane, opend, first, color, gradient);
@@ -781,29 +781,35 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
         n_samples += mlive[k] ? 1u : 0u;
         n_shaded += mpush[k] ? 1u : 0u;
         if (SHADE != 0) {
+          // Quad-granular compaction: if any of a ray's 4 steps needs shading the ray takes 4 consecutive slots (the steps
+          // that do not are written as null requests, a == 0, and cost the shader nothing but an idle lane).  Stream
+          // positions stay multiples of 4, so in every 64-request chunk the 4 lanes of a quad shade 4 consecutive steps of
+          // ONE ray: their gradient and shadow taps are 1 voxel apart and share bricks (texture-addresser coalescing).
           const bool push = mpush[k];
-          const unsigned long long m = __ballot(push);
-          if (m != 0ull) {
+          const unsigned long long mp = __ballot(push);
+          if (mp != 0ull) {
+            const unsigned int quad_bits = (unsigned int)(mp >> qbase) & 0xfu;
+            const bool qpush = quad_bits != 0u;
+            const unsigned long long m = __ballot(qpush); // whole quads
             const unsigned int below = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-            const unsigned int quad_bits = (unsigned int)(m >> qbase) & 0xfu;
-            const unsigned int quad_first = q_tail + (unsigned int)__popcll(m & ((1ull << qbase) - 1ull)); // position of the quad's first push
-            const unsigned int quad_n = (unsigned int)__popc(quad_bits);
-            if (push) {
-              const unsigned int pos_q = q_tail + below;
+            if (qpush) {
+              const unsigned int pos_q = q_tail + below;            // = quad_first + sub
+              const unsigned int quad_first = pos_q - (unsigned int)sub;
+              const unsigned int higher = quad_bits >> (sub + 1);   // later steps of this ray pushed by this instruction
               ShadeReq r;
               r.px = poss[k].x; r.py = poss[k].y; r.pz = poss[k].z;
-              r.s = sa[k]; r.v = va[k]; r.tr = mtr[k]; r.a = aa[k];
-              r.next = (quad_bits >> (sub + 1)) != 0u ? (int)(pos_q + 1u) : 0; // a later step of this ray is pushed by this instruction
+              r.s = sa[k]; r.v = va[k]; r.tr = mtr[k];
+              r.a = push ? aa[k] : 0.f;
+              r.next = (push && higher != 0u) ? (int)(pos_q + 1u + (unsigned int)__builtin_ctz(higher)) : 0;
               queue[pos_q & (QCAP - 1)] = r;
-              if (pos_q == quad_first && pend > 0) { // link the ray's previous request to this one
+              const unsigned int first_sub = (unsigned int)__builtin_ctz(quad_bits), last_sub = 31u - (unsigned int)__builtin_clz(quad_bits);
+              if (push && (unsigned int)sub == first_sub && pend > 0) { // link the ray's previous request to this one
                 if (!POOLED || (int)(last - q_head) >= 0) queue[last & (QCAP - 1)].next = (int)pos_q; // still in LDS
                 else Q.reqs[last_gidx].next = (int)pos_q;                                              // already spilled
               }
-            }
-            if (quad_n != 0u) {
-              if (pend == 0) first = quad_first;
-              last = quad_first + quad_n - 1u;
-              pend += (int)quad_n;
+              if (pend == 0) first = quad_first + first_sub;
+              last = quad_first + last_sub;
+              pend += (int)__popc(quad_bits);
             }
             q_tail += (unsigned int)__popcll(m);
             if (POOLED && (q_tail - q_head) >= 64u) spill(64u);
@@ -875,8 +881,10 @@ __global__ __launch_bounds__(kBlock) void shade_pool_kernel(const RayMarchParams
       const unsigned int n = Q.chunk_n[c];
       if ((unsigned int)lane < n) {
         ShadeReq r = Q.reqs[(size_t)c * 64 + lane];
-        shade_request<VT, SHADE, AM>(P, vc, tf, mc, r, n_shadow);
-        Q.reqs[(size_t)c * 64 + lane] = r;
+        if (r.a > 0.f) { // a == 0: null request (a step of the quad that needs no shading)
+          shade_request<VT, SHADE, AM>(P, vc, tf, mc, r, n_shadow);
+          Q.reqs[(size_t)c * 64 + lane] = r;
+        }
       }
     }
   }
