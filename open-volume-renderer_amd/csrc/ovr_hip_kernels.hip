@@ -751,29 +751,35 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
         }
       }
       // ---- (4) the ray's alpha recurrence over the 4K steps, in order; every lane of the quad computes all of it
+      //      (a dead or zero-opacity step feeds a = 0: fma(tr, 0, alpha) == alpha exactly, so no select is needed)
       bool mlive[K], mpush[K];
       float mtr[K];
 #pragma unroll
       for (int k = 0; k < K; ++k) {
+        float al[4];   // alpha BEFORE each of the 4 steps
+        bool lv[4];    // the reference's loop condition at each step, shaders_raymarching.cu:110
 #define OVR_STEP(B)                                                                                                            \
         {                                                                                                                      \
           const float aj = quad_bcast<B>(aa[k]);                                                                               \
-          live = live && (tya[4 * k + B] > txa[4 * k + B]) && (alpha < 0.9999f); /* shaders_raymarching.cu:110 */              \
+          live = live && (tya[4 * k + B] > txa[4 * k + B]) && (alpha < 0.9999f);                                               \
+          lv[B] = live;                                                                                                        \
+          al[B] = alpha;                                                                                                       \
           const float ae = live ? aj : 0.f;                                                                                    \
-          /* a sample whose corrected opacity is exactly 0 adds exactly 0 to colour, gradient and alpha: nothing is shaded */  \
-          const bool pj = ae > 0.f;                                                                                            \
           const float trj = 1.f - alpha;                                                                                       \
           if (SHADE == 0) {                                                                                                    \
             const float cxj = quad_bcast<B>(ca[k].x), cyj = quad_bcast<B>(ca[k].y), czj = quad_bcast<B>(ca[k].z);              \
-            color.x = pj ? fmaf(trj * cxj, ae, color.x) : color.x;                                                             \
-            color.y = pj ? fmaf(trj * cyj, ae, color.y) : color.y;                                                             \
-            color.z = pj ? fmaf(trj * czj, ae, color.z) : color.z;                                                             \
+            color.x = fmaf(trj * cxj, ae, color.x);                                                                            \
+            color.y = fmaf(trj * cyj, ae, color.y);                                                                            \
+            color.z = fmaf(trj * czj, ae, color.z);                                                                            \
           }                                                                                                                    \
-          alpha = pj ? fmaf(trj, ae, alpha) : alpha;                                                                           \
-          if (sub == B) { mlive[k] = live; mpush[k] = pj; mtr[k] = trj; }                                                      \
+          alpha = fmaf(trj, ae, alpha);                                                                                        \
         }
         OVR_STEP(0) OVR_STEP(1) OVR_STEP(2) OVR_STEP(3)
 #undef OVR_STEP
+        mlive[k] = sub == 0 ? lv[0] : sub == 1 ? lv[1] : sub == 2 ? lv[2] : lv[3];
+        mtr[k] = 1.f - sel4(al[0], al[1], al[2], al[3], sub);
+        // a sample whose corrected opacity is exactly 0 adds exactly 0 to colour, gradient and alpha: nothing is shaded
+        mpush[k] = mlive[k] && (aa[k] > 0.f);
       }
       // ---- (5) count; queue the samples that need shading (slot = tail + prefix of the ballot, lane order = step order)
 #pragma unroll
