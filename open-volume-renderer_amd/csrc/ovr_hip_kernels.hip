@@ -123,6 +123,9 @@ template <int VT> struct BrickMap {
 
 struct VolConsts {
   const void* data;
+  // per-axis offset tables in LDS (AM 0 / 1): tx[x] = X(x), ty[y] = Y(y), tz[z] = Z(z), bytes (AM 0) or elements (AM 1);
+  // ty / tz hold one extra entry equal to the last one, so (i, i + 1) is clamp-to-edge without a select
+  const unsigned int *tab_x, *tab_y, *tab_z;
   int nx1, ny1, nz1; // n - 1
   unsigned int macro_y;          // stored elements between macro rows: MV * macros_x
   unsigned long long macro_z;    // stored elements between macro layers: MV * macros_x * macros_y
@@ -160,30 +163,34 @@ __device__ __forceinline__ void tap_issue(const VolConsts& vc, f3 p, Tap& t)
   axis_tap(p.y, vc.cs.y, vc.cb.y, vc.fy1, vc.ny1, y0, y1, t.fy);
   axis_tap(p.z, vc.cs.z, vc.cb.z, vc.fz1, vc.nz1, z0, z1, t.fz);
   (void)x1; // the pair's upper member is the brick's next element (apron / replicated edge)
-  const unsigned ox = M::X((unsigned)x0);
-  const unsigned o0 = ox + M::Y((unsigned)y0, vc.macro_y), o1 = ox + M::Y((unsigned)y1, vc.macro_y);
   P p00, p10, p01, p11;
-  if (AM == 2) { // > 2^32 elements: 64-bit element offsets
+  if (AM == 2) { // > 2^32 elements: 64-bit element offsets, computed arithmetically
+    const unsigned ox = M::X((unsigned)x0);
+    const unsigned o0 = ox + M::Y((unsigned)y0, vc.macro_y), o1 = ox + M::Y((unsigned)y1, vc.macro_y);
     const T* base = static_cast<const T*>(vc.data);
     const unsigned long long oz0 = (unsigned long long)M::Zlo((unsigned)z0) + (unsigned long long)((unsigned)z0 >> 5) * vc.macro_z;
     const unsigned long long oz1 = (unsigned long long)M::Zlo((unsigned)z1) + (unsigned long long)((unsigned)z1 >> 5) * vc.macro_z;
     p00 = *reinterpret_cast<const P*>(base + (oz0 + o0)); p10 = *reinterpret_cast<const P*>(base + (oz0 + o1));
     p01 = *reinterpret_cast<const P*>(base + (oz1 + o0)); p11 = *reinterpret_cast<const P*>(base + (oz1 + o1));
   }
-  else if (AM == 1) { // < 2^32 elements: 32-bit element offsets, one 64-bit shift-add per load
-    const T* base = static_cast<const T*>(vc.data);
-    const unsigned oz0 = M::Zlo((unsigned)z0) + ((unsigned)z0 >> 5) * (unsigned)vc.macro_z;
-    const unsigned oz1 = M::Zlo((unsigned)z1) + ((unsigned)z1 >> 5) * (unsigned)vc.macro_z;
-    p00 = *reinterpret_cast<const P*>(base + (oz0 + o0)); p10 = *reinterpret_cast<const P*>(base + (oz0 + o1));
-    p01 = *reinterpret_cast<const P*>(base + (oz1 + o0)); p11 = *reinterpret_cast<const P*>(base + (oz1 + o1));
-  }
-  else { // the whole volume is <= 4 GiB: 32-bit BYTE offsets, so the loads use the SGPR-base + 32-bit-VGPR-offset form
-    const unsigned oz0 = M::Zlo((unsigned)z0) + ((unsigned)z0 >> 5) * (unsigned)vc.macro_z;
-    const unsigned oz1 = M::Zlo((unsigned)z1) + ((unsigned)z1 >> 5) * (unsigned)vc.macro_z;
-    const char* cb = static_cast<const char*>(vc.data);
-#define OVR_LD(off) (*reinterpret_cast<const P*>(cb + (unsigned)((off) * (unsigned)sizeof(T))))
-    p00 = OVR_LD(oz0 + o0); p10 = OVR_LD(oz0 + o1); p01 = OVR_LD(oz1 + o0); p11 = OVR_LD(oz1 + o1);
-#undef OVR_LD
+  else {
+    // three LDS lookups (one b32 + two adjacent pairs) replace ~40 bit-field / multiply instructions per tap: the march is
+    // VALU-bound once its gathers coalesce, and the LDS pipe is otherwise nearly idle
+    (void)y1; (void)z1;
+    const unsigned ox = vc.tab_x[x0];
+    const unsigned oy0 = vc.tab_y[y0], oy1 = vc.tab_y[y0 + 1];
+    const unsigned oz0 = vc.tab_z[z0], oz1 = vc.tab_z[z0 + 1];
+    const unsigned o0 = ox + oy0, o1 = ox + oy1;
+    if (AM == 1) { // < 2^32 elements: 32-bit element offsets, one 64-bit shift-add per load
+      const T* base = static_cast<const T*>(vc.data);
+      p00 = *reinterpret_cast<const P*>(base + (oz0 + o0)); p10 = *reinterpret_cast<const P*>(base + (oz0 + o1));
+      p01 = *reinterpret_cast<const P*>(base + (oz1 + o0)); p11 = *reinterpret_cast<const P*>(base + (oz1 + o1));
+    }
+    else { // the whole volume is <= 4 GiB: 32-bit BYTE offsets, the loads use the SGPR-base + 32-bit-VGPR-offset form
+      const char* cb = static_cast<const char*>(vc.data);
+      p00 = *reinterpret_cast<const P*>(cb + (oz0 + o0)); p10 = *reinterpret_cast<const P*>(cb + (oz0 + o1));
+      p01 = *reinterpret_cast<const P*>(cb + (oz1 + o0)); p11 = *reinterpret_cast<const P*>(cb + (oz1 + o1));
+    }
   }
   t.c000 = (float)p00.x; t.c100 = (float)p00.y; t.c010 = (float)p10.x; t.c110 = (float)p10.y;
   t.c001 = (float)p01.x; t.c101 = (float)p01.y; t.c011 = (float)p11.x; t.c111 = (float)p11.y;
@@ -394,6 +401,30 @@ __device__ __forceinline__ void setup_consts(const RayMarchParams& P, VolConsts&
   mc.gstep = ld3(P.grad_step);
   mc.ginv = mk3(1.f / mc.gstep.x, 1.f / mc.gstep.y, 1.f / mc.gstep.z);
   mc.step = P.step; mc.base = P.base; mc.shadow_stride = P.shadow_stride;
+}
+
+// build the per-axis offset tables in LDS (all threads of the workgroup); returns the bytes used
+template <int VT, int AM>
+__device__ __forceinline__ size_t stage_tables(const RayMarchParams& P, unsigned char* base, VolConsts& vc)
+{
+  typedef BrickMap<VT> M;
+  if (AM == 2) { vc.tab_x = vc.tab_y = vc.tab_z = nullptr; return 0; }
+  unsigned int* tx = reinterpret_cast<unsigned int*>(base);
+  unsigned int* ty = tx + P.vol.nx;
+  unsigned int* tz = ty + P.vol.ny + 1;
+  const unsigned int mul = AM == 0 ? (unsigned int)sizeof(typename Vox<VT>::T) : 1u;
+  for (int i = threadIdx.x; i < P.vol.nx; i += kBlock) tx[i] = M::X((unsigned)i) * mul;
+  for (int i = threadIdx.x; i <= P.vol.ny; i += kBlock) ty[i] = M::Y((unsigned)min(i, P.vol.ny - 1), vc.macro_y) * mul;
+  for (int i = threadIdx.x; i <= P.vol.nz; i += kBlock) {
+    const unsigned z = (unsigned)min(i, P.vol.nz - 1);
+    tz[i] = (M::Zlo(z) + (z >> 5) * (unsigned)vc.macro_z) * mul;
+  }
+  vc.tab_x = tx; vc.tab_y = ty; vc.tab_z = tz;
+  return (size_t)(P.vol.nx + P.vol.ny + P.vol.nz + 2) * sizeof(unsigned int);
+}
+__host__ inline size_t table_lds_bytes(const RayMarchParams& p, int am)
+{
+  return am == 2 ? 0 : (((size_t)(p.vol.nx + p.vol.ny + p.vol.nz + 2) * sizeof(unsigned int) + 15) & ~(size_t)15);
 }
 
 // stage the transfer function in LDS (all threads of the workgroup); color may be skipped by alpha-only kernels
@@ -612,17 +643,36 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
   const bool owner = sub == 0;            // the quad's lane that keeps the pixel's colour / request list
   const unsigned long long t_start = P.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
-  // ---- LDS carve: [request queues][TF colour (not needed by the pooled march)][TF alpha]
-  ShadeReq* const queue = reinterpret_cast<ShadeReq*>(lds_raw) + (size_t)wave * (QCAP > 0 ? QCAP : 1);
-  TfConsts tf;
-  stage_tf(P, lds_raw + (size_t)kWaves * QCAP * sizeof(ShadeReq), !POOLED, tf);
-
   int ix, iy;
   const bool active = assign_pixel_quad(P, lane, wave, ix, iy);
   unsigned int n_rays = 0, n_samples = 0, n_shaded = 0, n_shadow = 0;
   VolConsts vc;
   MarchConsts mc;
   setup_consts(P, vc, mc);
+
+  // ---- LDS carve: [request queues][offset tables][TF colour (not needed by the pooled march)][TF alpha]
+  // A workgroup none of whose rays can hit the volume (most of the image outside the silhouette) stages nothing.
+  ShadeReq* const queue = reinterpret_cast<ShadeReq*>(lds_raw) + (size_t)wave * (QCAP > 0 ? QCAP : 1);
+  TfConsts tf;
+  {
+    bool need = active;
+    if (P.spp == 1 && active) { // spp == 1: the (unjittered) ray is known - test it
+      const float ux0 = ((float)ix + .5f) / (float)P.width - 0.5f, uy0 = ((float)iy + .5f) / (float)P.height - 0.5f;
+      const f3 c0 = ld3(P.cam_dir), h0 = ld3(P.cam_hor), v0 = ld3(P.cam_ver);
+      const f3 d0 = normalize3_exact(mk3(c0.x + ux0 * h0.x + uy0 * v0.x, c0.y + ux0 * h0.y + uy0 * v0.y, c0.z + ux0 * h0.z + uy0 * v0.z));
+      float a0 = 0.f, b0 = FLT_MAX;
+      need = intersect_unit_box(a0, b0, to_object(mc, ld3(P.cam_pos)), mk3(d0.x * mc.inv_scale.x, d0.y * mc.inv_scale.y, d0.z * mc.inv_scale.z));
+    }
+    if (__syncthreads_or(need ? 1 : 0)) {
+      unsigned char* base = lds_raw + (size_t)kWaves * QCAP * sizeof(ShadeReq);
+      const size_t tb = (stage_tables<VT, AM>(P, base, vc) + 15) & ~(size_t)15;
+      stage_tf(P, base + tb, !POOLED, tf);
+    }
+    else {
+      tf = TfConsts{};
+      vc.tab_x = vc.tab_y = vc.tab_z = nullptr;
+    }
+  }
   const PoolDesc& Q = P.pool;
   const unsigned int tile = (blockIdx.x + blockIdx.y * gridDim.x) * kWaves + wave;
 
@@ -866,10 +916,11 @@ __global__ __launch_bounds__(kBlock) void shade_pool_kernel(const RayMarchParams
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   TfConsts tf;
-  stage_tf(P, lds_raw, true, tf);
   VolConsts vc;
   MarchConsts mc;
   setup_consts(P, vc, mc);
+  const size_t tb = (stage_tables<VT, AM>(P, lds_raw, vc) + 15) & ~(size_t)15; // [offset tables][TF]
+  stage_tf(P, lds_raw + tb, true, tf);
   const PoolDesc& Q = P.pool;
   const unsigned int n_runs = Q.ctrl[0] > Q.capacity ? 0u : Q.ctrl[0] / (unsigned int)kRun; // overflow: the frame is re-rendered
   unsigned int n_shadow = 0;
@@ -1007,7 +1058,7 @@ static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const 
   hipError_t e;
   const bool pooled = (SHADE != 0) && p.pool.reqs != nullptr && p.spp == 1;
   if (!pooled) {
-    const size_t lds = std::max<size_t>(tf_lds + (size_t)kWaves * QCfg<SHADE, false>::QCAP * sizeof(ShadeReq), 64); // >= 64 B: the counter reduction reuses it
+    const size_t lds = std::max<size_t>(tf_lds + table_lds_bytes(p, AM) + (size_t)kWaves * QCfg<SHADE, false>::QCAP * sizeof(ShadeReq), 64); // >= 64 B: the counter reduction reuses it
     auto kern = raymarch_kernel<VT, SHADE, AM, false>;
     if ((e = set_lds(kern, lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
@@ -1021,7 +1072,7 @@ static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const 
   if ((e = hipMemsetAsync(p.pool.ctrl, 0, 4 * sizeof(unsigned int), stream)) != hipSuccess) return e;
   {
     constexpr int SH = SHADE == 0 ? 1 : SHADE; // (never instantiated for SHADE == 0: pooled is false)
-    const size_t lds = (size_t)kWaves * QCfg<SH, true>::QCAP * sizeof(ShadeReq) + (size_t)p.n_alpha * sizeof(float) + 64;
+    const size_t lds = (size_t)kWaves * QCfg<SH, true>::QCAP * sizeof(ShadeReq) + table_lds_bytes(p, AM) + (size_t)p.n_alpha * sizeof(float) + 64;
     auto kern = raymarch_kernel<VT, SH, AM, true>;
     if ((e = set_lds(kern, lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
@@ -1029,7 +1080,7 @@ static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const 
   }
   if (ev) (void)hipEventRecord(ev[1], stream);
   {
-    const size_t lds = std::max<size_t>(tf_lds, 64);
+    const size_t lds = std::max<size_t>(tf_lds + table_lds_bytes(p, AM), 64);
     auto kern = shade_pool_kernel<VT, SHADE, AM>;
     if ((e = set_lds(kern, lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(kShadeBlocks), block, lds, stream, p);
