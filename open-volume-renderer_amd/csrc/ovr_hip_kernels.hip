@@ -767,21 +767,24 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
       }
       if (!any_live) break;
 
-      // ---- (2) the ray's next 4K steps: every lane runs the (tx, ty) recurrence, then keeps its own K steps
-      float txa[4 * K], tya[4 * K];
-#pragma unroll
-      for (int j = 0; j < 4 * K; ++j) {
-        txa[j] = tx; tya[j] = ty;
-        tx = ty;
-        ty = fminf(tx + mc.step, t1);
-      }
+      // ---- (2) the ray's next 4K steps: every lane runs the (tx, ty) recurrence, keeps its own K steps and one validity
+      //      bit per step (ty > tx, the first half of the reference's loop condition)
+      unsigned int vmask = 0;
       Tap taps[K];
       f3 poss[K];
       float dts[K];
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const float mtx = sel4(txa[4 * k], txa[4 * k + 1], txa[4 * k + 2], txa[4 * k + 3], sub);
-        const float mty = sel4(tya[4 * k], tya[4 * k + 1], tya[4 * k + 2], tya[4 * k + 3], sub);
+        float txq[4], tyq[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          txq[b] = tx; tyq[b] = ty;
+          vmask |= (ty > tx) ? (1u << (4 * k + b)) : 0u;
+          tx = ty;
+          ty = fminf(tx + mc.step, t1);
+        }
+        const float mtx = sel4(txq[0], txq[1], txq[2], txq[3], sub);
+        const float mty = sel4(tyq[0], tyq[1], tyq[2], tyq[3], sub);
         dts[k] = mty - mtx;
         const float tm = 0.5f * (mtx + mty);
         poss[k] = mk3(fmaf(tm, dir.x, org.x), fmaf(tm, dir.y, org.y), fmaf(tm, dir.z, org.z));
@@ -811,7 +814,7 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
 #define OVR_STEP(B)                                                                                                            \
         {                                                                                                                      \
           const float aj = quad_bcast<B>(aa[k]);                                                                               \
-          live = live && (tya[4 * k + B] > txa[4 * k + B]) && (alpha < 0.9999f);                                               \
+          live = live && ((vmask >> (4 * k + B)) & 1u) != 0u && (alpha < 0.9999f);                                             \
           lv[B] = live;                                                                                                        \
           al[B] = alpha;                                                                                                       \
           const float ae = live ? aj : 0.f;                                                                                    \
