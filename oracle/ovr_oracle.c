@@ -575,11 +575,13 @@ static void* worker(void* p)
   const int tw = s->tile_w > 0 ? s->tile_w : s->width, th = s->tile_h > 0 ? s->tile_h : s->height;
   const int tiles_x = (s->width + tw - 1) / tw;
   const int world = s->world > 0 ? s->world : 1;
-  for (int iy = w->tid; iy < s->height; iy += w->nthreads)
-    for (int ix = 0; ix < s->width; ++ix) {
-      if (world > 1 && ovr_oracle_tile_owner(ix / tw, iy / th, tiles_x, world) != s->rank) continue;
-      render_pixel(w->fc, ix, iy, w->frame_index, w->frame_accumulation, w->accum, w->out_rgba, w->out_grad, &w->cnt);
-    }
+  /* pixels are interleaved over the threads (any split gives the same frame: pixels are independent) */
+  const long long npix = (long long)s->width * s->height;
+  for (long long i = w->tid; i < npix; i += w->nthreads) {
+    const int ix = (int)(i % s->width), iy = (int)(i / s->width);
+    if (world > 1 && ovr_oracle_tile_owner(ix / tw, iy / th, tiles_x, world) != s->rank) continue;
+    render_pixel(w->fc, ix, iy, w->frame_index, w->frame_accumulation, w->accum, w->out_rgba, w->out_grad, &w->cnt);
+  }
   return NULL;
 }
 
