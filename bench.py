@@ -117,8 +117,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # "nccl" IS RCCL on ROCm.  OVR_BENCH_BACKEND=gloo + OVR_BENCH_ONE_GPU=1 rehearse the N > 1 path on a one-GPU box
+        backend = os.environ.get("OVR_BENCH_BACKEND", "nccl")
+        if os.environ.get("OVR_BENCH_ONE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     dev = torch.device("cuda", local_rank)

@@ -999,18 +999,20 @@ __global__ __launch_bounds__(kBlock) void composite_kernel(const RayMarchParams 
   }
 }
 
-// sums the per-workgroup partials into counters[0..4] (one workgroup; deterministic)
+// sums the per-workgroup partials into counters[0..4]: each workgroup reduces a slice and adds its 5 sums with one
+// atomic each (integer sums: the result does not depend on the order); counters are zeroed by a memset node before
 __global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned int* __restrict__ partials, int n_blocks, const unsigned int* __restrict__ shade_partials,
                                                              int n_shade_blocks, unsigned long long* counters)
 {
   __shared__ unsigned long long red[4][5];
   unsigned long long acc[5] = { 0, 0, 0, 0, 0 };
-  for (int b = threadIdx.x; b < n_blocks; b += 256) {
+  const int stride = gridDim.x * 256;
+  for (int b = blockIdx.x * 256 + threadIdx.x; b < n_blocks; b += stride) {
 #pragma unroll
     for (int c = 0; c < 5; ++c) acc[c] += partials[(size_t)b * 5 + c];
   }
   if (shade_partials)
-    for (int b = threadIdx.x; b < n_shade_blocks; b += 256) acc[3] += shade_partials[b];
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < n_shade_blocks; b += stride) acc[3] += shade_partials[b];
 #pragma unroll
   for (int c = 0; c < 5; ++c) {
     for (int off = 32; off > 0; off >>= 1) acc[c] += __shfl_down(acc[c], off);
@@ -1021,8 +1023,9 @@ __global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned int
     for (int c = 0; c < 5; ++c) red[wave][c] = acc[c];
   }
   __syncthreads();
-  if (threadIdx.x < 5) counters[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (threadIdx.x < 5) atomicAdd(&counters[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+constexpr int kReduceBlocks = 64;
 
 size_t raymarch_lds_bytes(int n_color, int n_alpha)
 {
@@ -1067,8 +1070,10 @@ static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const 
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (ev) { (void)hipEventRecord(ev[1], stream); (void)hipEventRecord(ev[2], stream); }
-    if (p.block_counters && p.counters)
-      hipLaunchKernelGGL(reduce_counters_kernel, dim3(1), dim3(256), 0, stream, p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)nullptr, 0, p.counters);
+    if (p.block_counters && p.counters) {
+      if ((e = hipMemsetAsync(p.counters, 0, 5 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+      hipLaunchKernelGGL(reduce_counters_kernel, dim3(kReduceBlocks), dim3(256), 0, stream, p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)nullptr, 0, p.counters);
+    }
     return hipGetLastError();
   }
   // ---- pooled pipeline
@@ -1092,9 +1097,11 @@ static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const 
   if (ev) (void)hipEventRecord(ev[2], stream);
   hipLaunchKernelGGL(composite_kernel, grid, block, 0, stream, p);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  if (p.block_counters && p.counters)
-    hipLaunchKernelGGL(reduce_counters_kernel, dim3(1), dim3(256), 0, stream, p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)p.pool.shade_counters,
+  if (p.block_counters && p.counters) {
+    if ((e = hipMemsetAsync(p.counters, 0, 5 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(reduce_counters_kernel, dim3(kReduceBlocks), dim3(256), 0, stream, p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)p.pool.shade_counters,
                        kShadeBlocks, p.counters);
+  }
   return hipGetLastError();
 }
 
