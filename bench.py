@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--shading", type=int, default=None, choices=[0, 1, 2])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--skip-empty", action="store_true", help="enable macrocell empty-space skipping (not the headline: fewer samples are fetched)")
     args = ap.parse_args()
 
     import numpy as np
@@ -144,6 +145,7 @@ def main():
     ren.set_sample_per_pixel(cfg["spp"])
     ren.set_volume_sampling_rate(cfg["rate"])
     ren.set_shading(cfg["shading"])
+    ren.set_empty_space_skipping(args.skip_empty)
     ren.set_transfer_function(colors, alphas, vr)
     if world > 1:
         ren.set_image_shard(rank, world, args.tile, args.tile)
@@ -185,7 +187,7 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    tot = dict(samples=0, shaded_samples=0, shadow_samples=0, rays=0, active_pixels=0)
+    tot = dict(samples=0, shaded_samples=0, shadow_samples=0, rays=0, active_pixels=0, skipped_samples=0, skipped_shadow_samples=0)
     kernel_ms = 0.0
     phase_ms = [0.0, 0.0, 0.0]
     t0 = time.perf_counter()
@@ -247,7 +249,7 @@ def main():
             "config": {"workload": cfg["workload"], "name": args.config, "volume": f"{n}^3 {cfg['dtype']}", "image": f"{W}x{H}",
                        "transfer_function": cfg["tf"], "camera": cfg["cam"], "fovy": 60, "sampling_rate": cfg["rate"],
                        "spp": cfg["spp"], "shading": ["none", "gradient", "gradient+shadow"][cfg["shading"]],
-                       "frame_accumulation": True, "parallelism": f"image tiles {args.tile}x{args.tile} over {world} rank(s)"},
+                       "frame_accumulation": True, "empty_space_skipping": bool(args.skip_empty), "parallelism": f"image tiles {args.tile}x{args.tile} over {world} rank(s)"},
             "per_frame": {k: per_step[k] for k in sorted(per_step)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

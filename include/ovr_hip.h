@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OVR_HIP_ABI_VERSION 2
+#define OVR_HIP_ABI_VERSION 3
 
 /* error codes */
 #define OVR_HIP_OK 0
@@ -72,6 +72,8 @@ typedef struct ovr_hip_stats {
   double shade_ms;          /* pooled pipeline: the persistent shading kernel                                  */
   double composite_ms;      /* pooled pipeline: composite + counter reduction                                  */
   uint64_t pool_chunks;     /* pooled pipeline: 2 KiB request chunks used by the frame                         */
+  uint64_t skipped_samples; /* empty-space skipping: primary iterations whose voxel fetch was skipped (not in `samples`) */
+  uint64_t skipped_shadow_samples; /* same for shadow-march iterations (not in `shadow_samples`)                 */
 } ovr_hip_stats;
 
 const char* ovr_hip_last_error(void);
@@ -122,6 +124,13 @@ int ovr_hip_set_shading(ovr_hip_renderer* r, int32_t mode);
  * (the tile's own wave shades its request batches), 2 = pooled (request chunks go through a global pool and are shaded
  * by a separate, load-balanced kernel).  Both produce bit-identical frames. */
 int ovr_hip_set_shading_pipeline(ovr_hip_renderer* r, int32_t mode);
+/* extension: empty-space skipping with the reference's macrocell grids (16^3 value-range cells +
+ * per-TF max-opacity cells, ovr/devices/optix7/accel/sp_singlemc.cu:10-97 - the reference computes them but only its path
+ * tracer uses them).  Samples whose cell has majorant 0 have opacity exactly 0: their voxel fetch is skipped, frames stay
+ * bit-identical.  Off by default (the reference's ray marcher visits every sample). */
+int ovr_hip_set_empty_space_skipping(ovr_hip_renderer* r, int32_t enabled);
+/* downloads the macrocell grids (for known-answer tests): dims = cells per axis; minmax = 2 floats per cell, majorant = 1 */
+int ovr_hip_get_macrocells(ovr_hip_renderer* r, int32_t dims[3], float* minmax_host, float* majorant_host, size_t capacity_cells);
 /* extension (multi-GPU): this renderer draws only the image tiles owned by `rank` of `world`;
  * owner(tile_x, tile_y) = (tile_x + tile_y) % world.  world = 1 restores the single-GPU behaviour. */
 int ovr_hip_set_image_shard(ovr_hip_renderer* r, int32_t rank, int32_t world, int32_t tile_w, int32_t tile_h);

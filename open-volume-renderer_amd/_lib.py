@@ -34,6 +34,8 @@ class Stats(C.Structure):
         ("shade_ms", C.c_double),
         ("composite_ms", C.c_double),
         ("pool_chunks", C.c_uint64),
+        ("skipped_samples", C.c_uint64),
+        ("skipped_shadow_samples", C.c_uint64),
     ]
 
 
@@ -59,6 +61,8 @@ SYMBOLS = {
     "ovr_hip_set_noise_tile": (C.c_int, [_H, _F3, C.c_int32]),
     "ovr_hip_set_shading": (C.c_int, [_H, C.c_int32]),
     "ovr_hip_set_shading_pipeline": (C.c_int, [_H, C.c_int32]),
+    "ovr_hip_set_empty_space_skipping": (C.c_int, [_H, C.c_int32]),
+    "ovr_hip_get_macrocells": (C.c_int, [_H, C.POINTER(C.c_int32), _F3, _F3, C.c_size_t]),
     "ovr_hip_set_image_shard": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "ovr_hip_commit": (C.c_int, [_H]),
     "ovr_hip_render": (C.c_int, [_H]),

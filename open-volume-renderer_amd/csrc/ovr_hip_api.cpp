@@ -105,7 +105,7 @@ struct ovr_hip_renderer {
   Queued<CameraP> camera;
   Queued<TfnP> tfn;
   Queued<FocusP> focus;
-  Queued<int> spp, sparse, accumulate, shading, grid_convention, pipeline;
+  Queued<int> spp, sparse, accumulate, shading, grid_convention, pipeline, skipping;
   Queued<float> rate;
   Queued<ShardP> shard;
 
@@ -116,6 +116,12 @@ struct ovr_hip_renderer {
   int value_type = 0;
   float origin[3] = { 0, 0, 0 }, spacing[3] = { 1, 1, 1 };
   bool have_volume = false;
+
+  // macrocells (empty-space skipping)
+  float* d_mc_minmax = nullptr;
+  float* d_mc_majorant = nullptr;
+  size_t mc_cells = 0;
+  bool mc_ranges_valid = false, mc_majorant_valid = false;
 
   // transfer function
   float* d_tf_color = nullptr;
@@ -208,7 +214,7 @@ int resize_framebuffers(ovr_hip_renderer* r, int w, int h)
   HIP_TRY(hipMemset(r->d_accum, 0, n * 4 * sizeof(float)));
   // workgroups of the march: 8x8 pixels (4 waves x 16 rays) in dense mode, 64 list entries in sparse mode
   const size_t nblk = std::max<size_t>((size_t)((w + 7) / 8) * (size_t)((h + 7) / 8), (n + 63) / 64) + 1;
-  HIP_TRY(hipMalloc((void**)&r->d_block_counters, nblk * 5 * sizeof(unsigned int)));
+  HIP_TRY(hipMalloc((void**)&r->d_block_counters, nblk * 7 * sizeof(unsigned int)));
   HIP_TRY(hipMalloc((void**)&r->pool.tile_first, nblk * 4 * sizeof(int)));
   HIP_TRY(hipMalloc((void**)&r->pool.tile_count, nblk * 4 * sizeof(unsigned int)));
   HIP_TRY(hipMalloc((void**)&r->pool.pix_state, std::max<size_t>(n, 1) * sizeof(float4)));
@@ -369,6 +375,34 @@ SparseMaskParams make_mask_params(ovr_hip_renderer* r, int frame_index, int32_t*
 
 int launch_frame(ovr_hip_renderer* r);
 
+// (re)build the macrocell grids when empty-space skipping is on: ranges once per volume, majorants per TF / range change
+int update_macrocells(ovr_hip_renderer* r, hipStream_t st)
+{
+  const size_t cells = (size_t)((r->vd.nx + 15) / 16) * ((r->vd.ny + 15) / 16) * ((r->vd.nz + 15) / 16);
+  if (cells != r->mc_cells || !r->d_mc_minmax) {
+    HIP_TRY(hipDeviceSynchronize());
+    if (r->d_mc_minmax) HIP_TRY(hipFree(r->d_mc_minmax));
+    if (r->d_mc_majorant) HIP_TRY(hipFree(r->d_mc_majorant));
+    HIP_TRY(hipMalloc((void**)&r->d_mc_minmax, cells * 2 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&r->d_mc_majorant, cells * sizeof(float)));
+    r->mc_cells = cells;
+    r->mc_ranges_valid = r->mc_majorant_valid = false;
+  }
+  if (!r->mc_ranges_valid) {
+    VolumeDesc vd = r->vd;
+    vd.data = r->d_volume;
+    HIP_TRY(launch_macrocell_ranges(vd, r->d_mc_minmax, st));
+    r->mc_ranges_valid = true;
+    r->mc_majorant_valid = false;
+  }
+  if (!r->mc_majorant_valid) {
+    // tfn.value_range / range_rcp_norm of the reference (volume.cpp:147-153) - the TF range, normalised like the data
+    HIP_TRY(launch_macrocell_majorants(r->d_mc_minmax, (unsigned int)cells, r->d_tf_alpha, r->n_alpha, r->P.tf_lower, r->P.tf_upper, r->d_mc_majorant, st));
+    r->mc_majorant_valid = true;
+  }
+  return 0;
+}
+
 // Impl::render up to and including the launch (device_impl.cpp:199-262); no host synchronisation
 int enqueue_frame(ovr_hip_renderer* r)
 {
@@ -429,6 +463,11 @@ int enqueue_frame(ovr_hip_renderer* r)
   P.tile_w = r->shard.current.tw;
   P.tile_h = r->shard.current.th;
   P.counters = r->d_counters;
+  P.majorant = nullptr;
+  if (r->skipping.current) {
+    if (int e = update_macrocells(r, st)) return e;
+    P.majorant = r->d_mc_majorant;
+  }
   P.block_counters = r->d_block_counters;
   P.trace = r->d_trace;
   P.sparse_xy = nullptr;
@@ -451,7 +490,7 @@ int enqueue_frame(ovr_hip_renderer* r)
     if (int e = ensure_pool(r, std::max<size_t>(guess, r->pool.capacity))) return e;
     if (!r->pool.ctrl) {
       HIP_TRY(hipMalloc((void**)&r->pool.ctrl, 4 * sizeof(unsigned int)));
-      HIP_TRY(hipMalloc((void**)&r->pool.shade_counters, pool_shade_blocks() * sizeof(unsigned int)));
+      HIP_TRY(hipMalloc((void**)&r->pool.shade_counters, pool_shade_blocks() * 2 * sizeof(unsigned int)));
       HIP_TRY(hipHostMalloc((void**)&r->h_ctrl, 4 * sizeof(unsigned int), hipHostMallocDefault));
     }
     P.pool = r->pool;
@@ -504,6 +543,8 @@ int finish_frame(ovr_hip_renderer* r)
   r->stats.shaded_samples = r->h_counters[2];
   r->stats.shadow_samples = r->h_counters[3];
   r->stats.active_pixels = r->h_counters[4];
+  r->stats.skipped_samples = r->h_counters[5];
+  r->stats.skipped_shadow_samples = r->h_counters[6];
   r->stats.frame_index = r->frame_index;
   if (r->d_trace) {
     if (const char* path = getenv("OVR_HIP_TRACE_FILE")) {
@@ -566,6 +607,8 @@ void ovr_hip_destroy(ovr_hip_renderer* r)
   if (r->d_tf_color) (void)hipFree(r->d_tf_color);
   if (r->d_tf_alpha) (void)hipFree(r->d_tf_alpha);
   if (r->d_noise) (void)hipFree(r->d_noise);
+  if (r->d_mc_minmax) (void)hipFree(r->d_mc_minmax);
+  if (r->d_mc_majorant) (void)hipFree(r->d_mc_majorant);
   if (r->d_counters) (void)hipFree(r->d_counters);
   if (r->d_sparse_count) (void)hipFree(r->d_sparse_count);
   if (r->h_counters) (void)hipHostFree(r->h_counters);
@@ -651,6 +694,7 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
   std::memcpy(r->origin, grid_origin, sizeof(r->origin));
   std::memcpy(r->spacing, grid_spacing, sizeof(r->spacing));
   r->have_volume = true;
+  r->mc_ranges_valid = r->mc_majorant_valid = false;
   update_volume_params(r);
   update_tfn_range(r);
   r->fb_reset = true;
@@ -720,6 +764,7 @@ OVR_SIMPLE_SETTER(ovr_hip_set_frame_accumulation, accumulate, int32_t, true, "")
 OVR_SIMPLE_SETTER(ovr_hip_set_sparse_sampling, sparse, int32_t, true, "")
 OVR_SIMPLE_SETTER(ovr_hip_set_shading, shading, int32_t, v >= 0 && v <= 2, "[hip] unknown shading mode")
 OVR_SIMPLE_SETTER(ovr_hip_set_shading_pipeline, pipeline, int32_t, v >= 0 && v <= 2, "[hip] unknown shading pipeline")
+OVR_SIMPLE_SETTER(ovr_hip_set_empty_space_skipping, skipping, int32_t, true, "")
 
 int ovr_hip_set_focus(ovr_hip_renderer* r, float cx, float cy, float scale, float base_noise)
 {
@@ -777,6 +822,7 @@ int ovr_hip_commit(ovr_hip_renderer* r)
   if (r->tfn.update()) { // :146-153
     if (int e = upload_tfn(r)) return e;
     update_tfn_range(r);
+    r->mc_majorant_valid = false;
     r->fb_reset = true;
   }
   if (r->grid_convention.update()) {
@@ -790,6 +836,7 @@ int ovr_hip_commit(ovr_hip_renderer* r)
   if (r->rate.update()) r->fb_reset = true;       // :190-196
   if (r->shading.update()) r->fb_reset = true;
   (void)r->pipeline.update(); // both pipelines produce the same frame: no accumulation reset
+  (void)r->skipping.update(); // skipping does not change the frame either
   if (r->shard.update()) r->fb_reset = true;
   return 0;
 }
@@ -870,6 +917,24 @@ int ovr_hip_get_stats(const ovr_hip_renderer* r, ovr_hip_stats* out)
   if (!r || !out) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_get_stats: null argument");
   if (r->async_pending) return fail(OVR_HIP_ESTATE, "[hip] ovr_hip_get_stats: a frame is still in flight (call ovr_hip_sync)");
   *out = r->stats;
+  return 0;
+}
+
+int ovr_hip_get_macrocells(ovr_hip_renderer* r, int32_t dims[3], float* minmax_host, float* majorant_host, size_t capacity_cells)
+{
+  if (!r || !dims) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_get_macrocells: null argument");
+  if (!r->have_volume || !r->have_tfn) return fail(OVR_HIP_ESTATE, "[hip] ovr_hip_get_macrocells: needs a volume and a transfer function");
+  if (int e = set_device(r)) return e;
+  if (int e = finish_frame(r)) return e;
+  dims[0] = (r->vd.nx + 15) / 16; dims[1] = (r->vd.ny + 15) / 16; dims[2] = (r->vd.nz + 15) / 16;
+  const size_t cells = (size_t)dims[0] * dims[1] * dims[2];
+  if (!minmax_host && !majorant_host) return 0;
+  if (capacity_cells < cells) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_get_macrocells: output too small");
+  hipStream_t st = r->stream();
+  if (int e = update_macrocells(r, st)) return e;
+  HIP_TRY(hipStreamSynchronize(st));
+  if (minmax_host) HIP_TRY(hipMemcpy(minmax_host, r->d_mc_minmax, cells * 2 * sizeof(float), hipMemcpyDeviceToHost));
+  if (majorant_host) HIP_TRY(hipMemcpy(majorant_host, r->d_mc_majorant, cells * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
 

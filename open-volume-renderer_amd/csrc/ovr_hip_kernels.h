@@ -43,7 +43,7 @@ struct PoolDesc {
   int* tile_first;              // per tile (wave of the march grid): first chunk or -1
   unsigned int* tile_count;     // per tile: requests pushed
   float4* pix_state;            // per pixel: alpha, first request position, request count
-  unsigned int* shade_counters; // per shade workgroup: shadow-march iterations
+  unsigned int* shade_counters; // per shade workgroup: 2 words (shadow-march iterations fetched, skipped)
 };
 
 struct RayMarchParams {
@@ -76,10 +76,11 @@ struct RayMarchParams {
   // sparse sampling: compacted (x,y) list + device-side count (2 * pixels), null in dense mode
   const int32_t* sparse_xy;
   const unsigned long long* sparse_count;
-  // counters: [0] rays [1] samples [2] shaded samples [3] shadow samples [4] active pixels
+  // counters: [0] rays [1] samples [2] shaded samples [3] shadow samples [4] active pixels [5] skipped samples [6] skipped shadow samples
   unsigned long long* counters;
+  const float* majorant;        // per-macrocell max TF opacity: empty-space skipping (null = off)
   unsigned long long* trace;    // diagnostic (OVR_HIP_TRACE=1): 4 words per wave, null otherwise
-  unsigned int* block_counters; // workspace: raymarch_grid_blocks() * 5 per-workgroup partial sums
+  unsigned int* block_counters; // workspace: raymarch_grid_blocks() * 7 per-workgroup partial sums
   PoolDesc pool;
   VolumeDesc vol;
 };
@@ -114,6 +115,11 @@ size_t sparse_mask_workspace_elems(int width, int height);
 hipError_t launch_sparse_mask(const SparseMaskParams& p, hipStream_t stream);
 
 hipError_t launch_tea(uint32_t* v0v1, float* out, int64_t n, hipStream_t stream);
+
+// macrocells (reference accel/sp_singlemc.cu): (min,max) per 16^3 cell once per volume; majorant per cell on every TF change
+hipError_t launch_macrocell_ranges(const VolumeDesc& vd, float* out_minmax, hipStream_t stream);
+hipError_t launch_macrocell_majorants(const float* minmax, unsigned int count, const float* alphas, int n_alpha, float vr_lo, float vr_hi, float* out,
+                                      hipStream_t stream);
 
 // tile pack/unpack for the RCCL gather payload
 hipError_t launch_pack_tiles(const float* frame, float* dst, int width, int height, int tile_w, int tile_h, int rank, int world,

@@ -17,6 +17,7 @@
 #include "ovr_hip_kernels.h"
 
 #include <float.h>
+#include <math.h>
 #include <algorithm>
 
 namespace ovrhip {
@@ -127,6 +128,8 @@ struct VolConsts {
   // ty / tz hold one extra entry equal to the last one, so (i, i + 1) is clamp-to-edge without a select
   const unsigned int *tab_x, *tab_y, *tab_z;
   int nx1, ny1, nz1; // n - 1
+  const float* majorant; // per-macrocell max TF opacity (null: empty-space skipping off)
+  int mcx1, mcy1, mcz1;  // macrocell grid dims - 1
   unsigned int macro_y;          // stored elements between macro rows: MV * macros_x
   unsigned long long macro_z;    // stored elements between macro layers: MV * macros_x * macros_y
   float fx1, fy1, fz1;
@@ -150,19 +153,35 @@ __device__ __forceinline__ void axis_tap(float po, float cs, float cb, float fn1
 struct Tap {
   float c000, c100, c010, c110, c001, c101, c011, c111;
   float fx, fy, fz;
+  int x0, y0, z0; // lower corner of the footprint (live only between tap_coords and tap_loads)
 };
 
+// macrocell (16^3 voxels, reference accel/spatial_partition.h:24) whose value range covers the footprint (i0, i0 + 1) on
+// every axis: cell c holds voxels [16c - 1, 16c + 15] (sp_singlemc.cu:36-42), i.e. c = (i0 + 1) >> 4
+
+__device__ __forceinline__ void tap_coords(const VolConsts& vc, f3 p, Tap& t)
+{
+  int x1, y1, z1;
+  axis_tap(p.x, vc.cs.x, vc.cb.x, vc.fx1, vc.nx1, t.x0, x1, t.fx);
+  axis_tap(p.y, vc.cs.y, vc.cb.y, vc.fy1, vc.ny1, t.y0, y1, t.fy);
+  axis_tap(p.z, vc.cs.z, vc.cb.z, vc.fz1, vc.nz1, t.z0, z1, t.fz);
+  (void)x1; (void)y1; (void)z1;
+}
+
+__device__ __forceinline__ unsigned int tap_cell(const VolConsts& vc, const Tap& t)
+{
+  const int cx = min((t.x0 + 1) >> 4, vc.mcx1), cy = min((t.y0 + 1) >> 4, vc.mcy1), cz = min((t.z0 + 1) >> 4, vc.mcz1);
+  return (unsigned int)cx + (unsigned int)(vc.mcx1 + 1) * ((unsigned int)cy + (unsigned int)(vc.mcy1 + 1) * (unsigned int)cz);
+}
+
 template <int VT, int AM>
-__device__ __forceinline__ void tap_issue(const VolConsts& vc, f3 p, Tap& t)
+__device__ __forceinline__ void tap_loads(const VolConsts& vc, Tap& t)
 {
   typedef BrickMap<VT> M;
   typedef typename Vox<VT>::T T;
   typedef typename Vox<VT>::P P;
-  int x0, x1, y0, y1, z0, z1;
-  axis_tap(p.x, vc.cs.x, vc.cb.x, vc.fx1, vc.nx1, x0, x1, t.fx);
-  axis_tap(p.y, vc.cs.y, vc.cb.y, vc.fy1, vc.ny1, y0, y1, t.fy);
-  axis_tap(p.z, vc.cs.z, vc.cb.z, vc.fz1, vc.nz1, z0, z1, t.fz);
-  (void)x1; // the pair's upper member is the brick's next element (apron / replicated edge)
+  const int x0 = t.x0, y0 = t.y0, z0 = t.z0;
+  const int y1 = min(y0 + 1, vc.ny1), z1 = min(z0 + 1, vc.nz1);
   P p00, p10, p01, p11;
   if (AM == 2) { // > 2^32 elements: 64-bit element offsets, computed arithmetically
     const unsigned ox = M::X((unsigned)x0);
@@ -194,6 +213,13 @@ __device__ __forceinline__ void tap_issue(const VolConsts& vc, f3 p, Tap& t)
   }
   t.c000 = (float)p00.x; t.c100 = (float)p00.y; t.c010 = (float)p10.x; t.c110 = (float)p10.y;
   t.c001 = (float)p01.x; t.c101 = (float)p01.y; t.c011 = (float)p11.x; t.c111 = (float)p11.y;
+}
+
+template <int VT, int AM>
+__device__ __forceinline__ void tap_issue(const VolConsts& vc, f3 p, Tap& t)
+{
+  tap_coords(vc, p, t);
+  tap_loads<VT, AM>(vc, t);
 }
 
 template <int VT>
@@ -300,7 +326,8 @@ __device__ __forceinline__ f3 to_object(const MarchConsts& mc, f3 p)
 // KS taps are issued before the first one is consumed; taps past the end of the march or past the early-termination
 // point are speculative (their coordinates are clamped, so the loads are always in bounds) and simply dropped.
 template <int VT, int AM, int KS>
-__device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConsts& tf, const MarchConsts& mc, f3 org, unsigned int& n_shadow)
+__device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConsts& tf, const MarchConsts& mc, f3 org, unsigned int& n_shadow,
+                                              unsigned int& n_shadow_skipped)
 {
   const f3 oo = to_object(mc, org);
   const f3 od = mk3(mc.light.x * mc.inv_scale.x, mc.light.y * mc.inv_scale.y, mc.light.z * mc.inv_scale.z);
@@ -311,7 +338,7 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
   bool live = true;
   while (live) {
     Tap taps[KS];
-    float dts[KS];
+    float dts[KS], mj[KS];
     bool valid[KS];
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
@@ -319,10 +346,14 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
       dts[k] = ty - tx;
       const float tm = 0.5f * (tx + ty);
       const f3 pos = mk3(fmaf(tm, mc.light.x, org.x), fmaf(tm, mc.light.y, org.y), fmaf(tm, mc.light.z, org.z));
-      tap_issue<VT, AM>(vc, to_object(mc, pos), taps[k]);
+      tap_coords(vc, to_object(mc, pos), taps[k]);
+      mj[k] = vc.majorant ? vc.majorant[tap_cell(vc, taps[k])] : 1.f; // empty-space skipping: max TF opacity of the macrocell
       tx = ty;
       ty = fminf(tx + mc.shadow_stride, t1);
     }
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+      if (mj[k] > 0.f) tap_loads<VT, AM>(vc, taps[k]);
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
       // branch-free on purpose: a conditional use would let the compiler sink this tap's loads into the branch and
@@ -330,9 +361,11 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
       const float s = tap_finish<VT>(vc, taps[k]);
       float a = tf_alpha(tf, tf_coord(tf, s));
       a = opacity_correction(a, mc.base * dts[k]);
+      a = mj[k] > 0.f ? a : 0.f; // a macrocell whose majorant is 0 holds no sample with opacity > 0
       live = live && valid[k] && (alpha < 0.9999f);
       alpha = live ? fmaf(1.f - alpha, a, alpha) : alpha;
-      n_shadow += live ? 1u : 0u;
+      n_shadow += (live && mj[k] > 0.f) ? 1u : 0u;
+      n_shadow_skipped += (live && !(mj[k] > 0.f)) ? 1u : 0u;
     }
   }
   return alpha;
@@ -397,6 +430,8 @@ __device__ __forceinline__ void setup_consts(const RayMarchParams& P, VolConsts&
   vc.macro_z = (unsigned long long)P.vol.macro_elems * (unsigned long long)P.vol.macros_x * (unsigned long long)P.vol.macros_y;
   vc.cs = ld3(P.coord_scale); vc.cb = ld3(P.coord_bias);
   vc.vscale = P.vol.value_scale; vc.vmin = P.vol.value_min_clamp;
+  vc.majorant = P.majorant;
+  vc.mcx1 = (P.vol.nx + 15) / 16 - 1; vc.mcy1 = (P.vol.ny + 15) / 16 - 1; vc.mcz1 = (P.vol.nz + 15) / 16 - 1;
   mc.inv_scale = ld3(P.inv_scale); mc.wto_p = ld3(P.wto_p); mc.otw_it = ld3(P.otw_it); mc.light = ld3(P.light);
   mc.gstep = ld3(P.grad_step);
   mc.ginv = mk3(1.f / mc.gstep.x, 1.f / mc.gstep.y, 1.f / mc.gstep.z);
@@ -493,7 +528,7 @@ __device__ __forceinline__ void write_pixel(const RayMarchParams& P, unsigned in
 // (shaders_raymarching.cu:124-158).  Writes the result over the request.
 template <int VT, int SHADE, int AM>
 __device__ __forceinline__ void shade_request(const RayMarchParams& P, const VolConsts& vc, const TfConsts& tf, const MarchConsts& mc, ShadeReq& r,
-                                              unsigned int& n_shadow)
+                                              unsigned int& n_shadow, unsigned int& n_shadow_skipped)
 {
   const f3 pos = mk3(r.px, r.py, r.pz);
   const f3 po = to_object(mc, pos);
@@ -518,7 +553,7 @@ __device__ __forceinline__ void shade_request(const RayMarchParams& P, const Vol
                          fmaf(n_w.x, m[2], fmaf(n_w.y, m[5], n_w.z * m[8]))));
   }
   float shadow = 0.f;
-  if (SHADE == 2) shadow = march_shadow<VT, AM, MarchCfg<2>::KS>(vc, tf, mc, pos, n_shadow);
+  if (SHADE == 2) shadow = march_shadow<VT, AM, MarchCfg<2>::KS>(vc, tf, mc, pos, n_shadow, n_shadow_skipped);
   const float cosNL = fabsf(dot3(mc.light, n_w));
   const float shade = 0.5f + 0.5f * cosNL * 2.f * (1.f - shadow); // shaders_raymarching.cu:156-157
   const float tr = r.tr;
@@ -556,9 +591,11 @@ __device__ __forceinline__ void apply_batch(const ShadeReq& res, unsigned int ba
   }
 }
 
-// per-wave counters -> LDS -> one plain store of the workgroup's partial sums (lds must hold kWaves*5 uints)
+constexpr int kNC = 7; // counters: rays, samples, shaded, shadow, active pixels, skipped samples, skipped shadow samples
+// per-wave counters -> LDS -> one plain store of the workgroup's partial sums (lds must hold kWaves*kNC uints)
 __device__ __forceinline__ void store_block_counters(const RayMarchParams& P, unsigned int* red, int lane, int wave, unsigned int n_rays,
-                                                     unsigned int n_samples, unsigned int n_shaded, unsigned int n_shadow, unsigned int n_active)
+                                                     unsigned int n_samples, unsigned int n_shaded, unsigned int n_shadow, unsigned int n_active,
+                                                     unsigned int n_skipped, unsigned int n_shadow_skipped)
 {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -567,19 +604,21 @@ __device__ __forceinline__ void store_block_counters(const RayMarchParams& P, un
     n_shaded += __shfl_down(n_shaded, off);
     n_shadow += __shfl_down(n_shadow, off);
     n_active += __shfl_down(n_active, off);
+    n_skipped += __shfl_down(n_skipped, off);
+    n_shadow_skipped += __shfl_down(n_shadow_skipped, off);
   }
   if (!P.block_counters) return;
   __syncthreads(); // LDS is dead at this point: reuse its front
   if (lane == 0) {
-    red[wave * 5 + 0] = n_rays; red[wave * 5 + 1] = n_samples; red[wave * 5 + 2] = n_shaded;
-    red[wave * 5 + 3] = n_shadow; red[wave * 5 + 4] = n_active;
+    red[wave * kNC + 0] = n_rays; red[wave * kNC + 1] = n_samples; red[wave * kNC + 2] = n_shaded;
+    red[wave * kNC + 3] = n_shadow; red[wave * kNC + 4] = n_active; red[wave * kNC + 5] = n_skipped; red[wave * kNC + 6] = n_shadow_skipped;
   }
   __syncthreads();
-  if (threadIdx.x < 5) {
+  if (threadIdx.x < kNC) {
     const unsigned int bid = blockIdx.x + blockIdx.y * gridDim.x;
     unsigned int sum = 0;
-    for (int w = 0; w < kWaves; ++w) sum += red[w * 5 + threadIdx.x];
-    P.block_counters[(size_t)bid * 5 + threadIdx.x] = sum;
+    for (int w = 0; w < kWaves; ++w) sum += red[w * kNC + threadIdx.x];
+    P.block_counters[(size_t)bid * kNC + threadIdx.x] = sum;
   }
 }
 
@@ -645,7 +684,7 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
 
   int ix, iy;
   const bool active = assign_pixel_quad(P, lane, wave, ix, iy);
-  unsigned int n_rays = 0, n_samples = 0, n_shaded = 0, n_shadow = 0;
+  unsigned int n_rays = 0, n_samples = 0, n_shaded = 0, n_shadow = 0, n_skipped = 0, n_shadow_skipped = 0;
   VolConsts vc;
   MarchConsts mc;
   setup_consts(P, vc, mc);
@@ -755,7 +794,7 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
           r.px = r.py = r.pz = r.s = r.v = r.tr = r.a = 0.f; r.next = 0;
           if ((unsigned int)lane < n) {
             r = queue[(q_head + lane) & (QCAP - 1)];
-            if (r.a > 0.f) shade_request<VT, SHADE, AM>(P, vc, tf, mc, r, n_shadow); // a == 0: null request
+            if (r.a > 0.f) shade_request<VT, SHADE, AM>(P, vc, tf, mc, r, n_shadow, n_shadow_skipped); // a == 0: null request
           }
           int opend = owner ? pend : 0;
           apply_batch(r, q_head, n, lane, opend, first, color, gradient);
@@ -772,7 +811,7 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
       unsigned int vmask = 0;
       Tap taps[K];
       f3 poss[K];
-      float dts[K];
+      float dts[K], mj[K];
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         float txq[4], tyq[4];
@@ -788,8 +827,12 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
         dts[k] = mty - mtx;
         const float tm = 0.5f * (mtx + mty);
         poss[k] = mk3(fmaf(tm, dir.x, org.x), fmaf(tm, dir.y, org.y), fmaf(tm, dir.z, org.z));
-        tap_issue<VT, AM>(vc, to_object(mc, poss[k]), taps[k]);
+        tap_coords(vc, to_object(mc, poss[k]), taps[k]);
+        mj[k] = vc.majorant ? vc.majorant[tap_cell(vc, taps[k])] : 1.f; // empty-space skipping: the macrocell's max TF opacity
       }
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (mj[k] > 0.f) tap_loads<VT, AM>(vc, taps[k]);
       // ---- (3) own samples: value, TF coordinate, corrected opacity (and colour when shading is off)
       float sa[K], va[K], aa[K];
       f3 ca[K];
@@ -798,6 +841,7 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
         sa[k] = tap_finish<VT>(vc, taps[k]);
         va[k] = tf_coord(tf, sa[k]);
         aa[k] = opacity_correction(tf_alpha(tf, va[k]), mc.base * dts[k]);
+        aa[k] = mj[k] > 0.f ? aa[k] : 0.f; // a macrocell whose majorant is 0 holds no sample with opacity > 0
         if (SHADE == 0) {
           const f3 rgb = tf_color(tf, va[k]);
           ca[k] = mk3(clamp01(rgb.x), clamp01(rgb.y), clamp01(rgb.z));
@@ -837,7 +881,8 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
       // ---- (5) count; queue the samples that need shading (slot = tail + prefix of the ballot, lane order = step order)
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        n_samples += mlive[k] ? 1u : 0u;
+        n_samples += (mlive[k] && mj[k] > 0.f) ? 1u : 0u;
+        n_skipped += (mlive[k] && !(mj[k] > 0.f)) ? 1u : 0u;
         n_shaded += mpush[k] ? 1u : 0u;
         if (SHADE != 0) {
           // Quad-granular compaction: if any of a ray's 4 steps needs shading the ray takes 4 consecutive slots (the steps
@@ -907,7 +952,8 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
     t[0] = t_start; t[1] = __builtin_amdgcn_s_memrealtime();
     t[2] = ((unsigned long long)n_samples << 32) | n_shaded; t[3] = n_shadow;
   }
-  store_block_counters(P, reinterpret_cast<unsigned int*>(lds_raw), lane, wave, n_rays, n_samples, n_shaded, n_shadow, (active && owner) ? 1u : 0u);
+  store_block_counters(P, reinterpret_cast<unsigned int*>(lds_raw), lane, wave, n_rays, n_samples, n_shaded, n_shadow, (active && owner) ? 1u : 0u, n_skipped,
+                       n_shadow_skipped);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -926,7 +972,7 @@ __global__ __launch_bounds__(kBlock) void shade_pool_kernel(const RayMarchParams
   stage_tf(P, lds_raw + tb, true, tf);
   const PoolDesc& Q = P.pool;
   const unsigned int n_runs = Q.ctrl[0] > Q.capacity ? 0u : Q.ctrl[0] / (unsigned int)kRun; // overflow: the frame is re-rendered
-  unsigned int n_shadow = 0;
+  unsigned int n_shadow = 0, n_shadow_skipped = 0;
   __shared__ unsigned int s_run;
   for (;;) {
     // one returning atomic per workgroup and run; the 4 waves shade the run's chunks (consecutive depth steps of ONE
@@ -942,19 +988,25 @@ __global__ __launch_bounds__(kBlock) void shade_pool_kernel(const RayMarchParams
       if ((unsigned int)lane < n) {
         ShadeReq r = Q.reqs[(size_t)c * 64 + lane];
         if (r.a > 0.f) { // a == 0: null request (a step of the quad that needs no shading)
-          shade_request<VT, SHADE, AM>(P, vc, tf, mc, r, n_shadow);
+          shade_request<VT, SHADE, AM>(P, vc, tf, mc, r, n_shadow, n_shadow_skipped);
           Q.reqs[(size_t)c * 64 + lane] = r;
         }
       }
     }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) n_shadow += __shfl_down(n_shadow, off);
+  for (int off = 32; off > 0; off >>= 1) {
+    n_shadow += __shfl_down(n_shadow, off);
+    n_shadow_skipped += __shfl_down(n_shadow_skipped, off);
+  }
   __syncthreads();
   unsigned int* red = reinterpret_cast<unsigned int*>(lds_raw);
-  if (lane == 0) red[wave] = n_shadow;
+  if (lane == 0) { red[wave] = n_shadow; red[kWaves + wave] = n_shadow_skipped; }
   __syncthreads();
-  if (threadIdx.x == 0 && Q.shade_counters) Q.shade_counters[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0 && Q.shade_counters) {
+    Q.shade_counters[2 * blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    Q.shade_counters[2 * blockIdx.x + 1] = red[4] + red[5] + red[6] + red[7];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1004,26 +1056,29 @@ __global__ __launch_bounds__(kBlock) void composite_kernel(const RayMarchParams 
 __global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned int* __restrict__ partials, int n_blocks, const unsigned int* __restrict__ shade_partials,
                                                              int n_shade_blocks, unsigned long long* counters)
 {
-  __shared__ unsigned long long red[4][5];
-  unsigned long long acc[5] = { 0, 0, 0, 0, 0 };
+  __shared__ unsigned long long red[4][kNC];
+  unsigned long long acc[kNC] = { 0, 0, 0, 0, 0, 0, 0 };
   const int stride = gridDim.x * 256;
   for (int b = blockIdx.x * 256 + threadIdx.x; b < n_blocks; b += stride) {
 #pragma unroll
-    for (int c = 0; c < 5; ++c) acc[c] += partials[(size_t)b * 5 + c];
+    for (int c = 0; c < kNC; ++c) acc[c] += partials[(size_t)b * kNC + c];
   }
   if (shade_partials)
-    for (int b = blockIdx.x * 256 + threadIdx.x; b < n_shade_blocks; b += stride) acc[3] += shade_partials[b];
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < n_shade_blocks; b += stride) {
+      acc[3] += shade_partials[2 * b];
+      acc[6] += shade_partials[2 * b + 1];
+    }
 #pragma unroll
-  for (int c = 0; c < 5; ++c) {
+  for (int c = 0; c < kNC; ++c) {
     for (int off = 32; off > 0; off >>= 1) acc[c] += __shfl_down(acc[c], off);
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
 #pragma unroll
-    for (int c = 0; c < 5; ++c) red[wave][c] = acc[c];
+    for (int c = 0; c < kNC; ++c) red[wave][c] = acc[c];
   }
   __syncthreads();
-  if (threadIdx.x < 5) atomicAdd(&counters[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (threadIdx.x < kNC) atomicAdd(&counters[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 constexpr int kReduceBlocks = 64;
 
@@ -1071,7 +1126,7 @@ static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const 
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (ev) { (void)hipEventRecord(ev[1], stream); (void)hipEventRecord(ev[2], stream); }
     if (p.block_counters && p.counters) {
-      if ((e = hipMemsetAsync(p.counters, 0, 5 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+      if ((e = hipMemsetAsync(p.counters, 0, 8 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
       hipLaunchKernelGGL(reduce_counters_kernel, dim3(kReduceBlocks), dim3(256), 0, stream, p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)nullptr, 0, p.counters);
     }
     return hipGetLastError();
@@ -1098,7 +1153,7 @@ static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const 
   hipLaunchKernelGGL(composite_kernel, grid, block, 0, stream, p);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if (p.block_counters && p.counters) {
-    if ((e = hipMemsetAsync(p.counters, 0, 5 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(p.counters, 0, 8 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(reduce_counters_kernel, dim3(kReduceBlocks), dim3(256), 0, stream, p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)p.pool.shade_counters,
                        kShadeBlocks, p.counters);
   }
@@ -1236,6 +1291,94 @@ hipError_t launch_relayout(const void* src, int vt, void* dst, const VolumeDesc&
   case 500: return relayout_t<double, float, VOX_F32>(src, dst, vd, z0, nzc, stream);
   default: return hipErrorInvalidValue;
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// macrocells (reference ovr/devices/optix7/accel/sp_singlemc.cu): 16^3-voxel cells with a value range and, per transfer
+// function, the largest opacity any sample inside can get.  The reference builds both grids but only its path tracer uses
+// them; here the ray marcher and the shadow march skip the voxel fetch of samples whose cell has majorant 0 - such a
+// sample's opacity is exactly 0, so frames are bit-identical with and without skipping.
+// ------------------------------------------------------------------------------------------------------------------
+// value_range_kernel, sp_singlemc.cu:10-54: one WAVE per macrocell (the reference uses one thread), wave min/max reduction
+template <int VT>
+__global__ __launch_bounds__(256) void macrocell_range_kernel(const void* __restrict__ vol, VolumeDesc vd, int mcx, int mcy, int mcz, float2* __restrict__ out)
+{
+  typedef BrickMap<VT> M;
+  typedef typename Vox<VT>::T T;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long cell = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cell >= (unsigned long long)mcx * mcy * mcz) return;
+  const int cx = (int)(cell % mcx), cy = (int)((cell / mcx) % mcy), cz = (int)(cell / ((unsigned long long)mcx * mcy));
+  const int W = 16;
+  const int bx = max(cx * W - 1, 0), by = max(cy * W - 1, 0), bz = max(cz * W - 1, 0);
+  const int ex = min(bx + W + 1, vd.nx), ey = min(by + W + 1, vd.ny), ez = min(bz + W + 1, vd.nz);
+  const int dx = ex - bx, dy = ey - by, dz = ez - bz;
+  const unsigned macro_y = vd.macro_elems * (unsigned)vd.macros_x;
+  const unsigned long long macro_z = (unsigned long long)vd.macro_elems * vd.macros_x * vd.macros_y;
+  const T* base = static_cast<const T*>(vol);
+  float lo = INFINITY, hi = -INFINITY; // range1f() is empty
+  for (int i = lane; i < dx * dy * dz; i += 64) {
+    const int x = bx + i % dx, y = by + (i / dx) % dy, z = bz + i / (dx * dy);
+    const unsigned long long off = (unsigned long long)(M::X((unsigned)x) + M::Y((unsigned)y, macro_y)) + M::Zlo((unsigned)z) + (unsigned long long)((unsigned)z >> 5) * macro_z;
+    float f = (float)base[off];
+    if (VT == VOX_U8) f = f / 255.f;                            // what the normalized texture read returns (array.cpp:304-306)
+    if (VT == VOX_I8) { f = f / 127.f; f = f < -1.f ? -1.f : f; }
+    lo = fminf(lo, f);
+    hi = fmaxf(hi, f);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, off));
+    hi = fmaxf(hi, __shfl_xor(hi, off));
+  }
+  if (lane == 0) out[cell] = make_float2(lo, hi);
+}
+
+// majorant_kernel, sp_singlemc.cu:56-97: the alpha table is staged in LDS exactly as the reference stages it in shared memory
+__global__ __launch_bounds__(256) void macrocell_majorant_kernel(const float2* __restrict__ ranges, unsigned int count, const float* __restrict__ alphas, int n_alpha,
+                                                                float vr_lo, float vr_hi, float* __restrict__ out)
+{
+  extern __shared__ float lds_alpha[];
+  for (int i = threadIdx.x; i < n_alpha; i += 256) lds_alpha[i] = alphas[i];
+  __syncthreads();
+  const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const float2 r = ranges[i];
+  const float rcp = 1.f / (vr_hi - vr_lo);
+  const float lower = (fminf(fmaxf(r.x, vr_lo), vr_hi) - vr_lo) * rcp;
+  const float upper = (fminf(fmaxf(r.y, vr_lo), vr_hi) - vr_lo) * rcp;
+  const float fl = floorf(fmaf(lower, (float)(n_alpha - 1), 0.5f)) - 1.f;
+  const float fu = floorf(fmaf(upper, (float)(n_alpha - 1), 0.5f)) + 1.f;
+  unsigned int il = fl < 0.f ? 0u : (unsigned int)fl; // float -> uint32 saturates in the reference's device code
+  unsigned int iu = fu < 0.f ? 0u : (unsigned int)fu;
+  il = min(il, (unsigned int)(n_alpha - 1));
+  iu = min(iu, (unsigned int)(n_alpha - 1));
+  float op = 0.f;
+  for (unsigned int k = il; k <= iu; ++k) op = fmaxf(op, lds_alpha[k]);
+  out[i] = op;
+}
+
+hipError_t launch_macrocell_ranges(const VolumeDesc& vd, float* out_minmax, hipStream_t stream)
+{
+  const int mcx = (vd.nx + 15) / 16, mcy = (vd.ny + 15) / 16, mcz = (vd.nz + 15) / 16;
+  const unsigned long long cells = (unsigned long long)mcx * mcy * mcz;
+  const dim3 grid((unsigned)((cells + 3) / 4)), block(256);
+  switch (vd.type) {
+  case VOX_U8: hipLaunchKernelGGL(macrocell_range_kernel<VOX_U8>, grid, block, 0, stream, vd.data, vd, mcx, mcy, mcz, (float2*)out_minmax); break;
+  case VOX_I8: hipLaunchKernelGGL(macrocell_range_kernel<VOX_I8>, grid, block, 0, stream, vd.data, vd, mcx, mcy, mcz, (float2*)out_minmax); break;
+  case VOX_U16: hipLaunchKernelGGL(macrocell_range_kernel<VOX_U16>, grid, block, 0, stream, vd.data, vd, mcx, mcy, mcz, (float2*)out_minmax); break;
+  case VOX_I16: hipLaunchKernelGGL(macrocell_range_kernel<VOX_I16>, grid, block, 0, stream, vd.data, vd, mcx, mcy, mcz, (float2*)out_minmax); break;
+  default: hipLaunchKernelGGL(macrocell_range_kernel<VOX_F32>, grid, block, 0, stream, vd.data, vd, mcx, mcy, mcz, (float2*)out_minmax); break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_macrocell_majorants(const float* minmax, unsigned int count, const float* alphas, int n_alpha, float vr_lo, float vr_hi, float* out,
+                                      hipStream_t stream)
+{
+  hipLaunchKernelGGL(macrocell_majorant_kernel, dim3((count + 255) / 256), dim3(256), (size_t)n_alpha * sizeof(float), stream, (const float2*)minmax, count, alphas,
+                     n_alpha, vr_lo, vr_hi, out);
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -182,6 +182,20 @@ class DeviceHIP:
         """0 auto, 1 in place, 2 pooled (include/ovr_hip.h) - both produce bit-identical frames"""
         L.check(self._lib.ovr_hip_set_shading_pipeline(self._h, int(mode)))
 
+    def set_empty_space_skipping(self, on):
+        """skip the voxel fetch of samples in macrocells whose max TF opacity is 0 (frames stay bit-identical)"""
+        L.check(self._lib.ovr_hip_set_empty_space_skipping(self._h, int(bool(on))))
+
+    def macrocells(self):
+        """(minmax[mz,my,mx,2], majorant[mz,my,mx]) of the reference's 16^3 macrocell grids"""
+        dims = (C.c_int32 * 3)()
+        L.check(self._lib.ovr_hip_get_macrocells(self._h, dims, None, None, 0))
+        n = dims[0] * dims[1] * dims[2]
+        mm = np.zeros((dims[2], dims[1], dims[0], 2), np.float32)
+        mj = np.zeros((dims[2], dims[1], dims[0]), np.float32)
+        L.check(self._lib.ovr_hip_get_macrocells(self._h, dims, mm.ctypes.data_as(C.POINTER(C.c_float)), mj.ctypes.data_as(C.POINTER(C.c_float)), n))
+        return mm, mj
+
     def set_grid_convention(self, convention):
         L.check(self._lib.ovr_hip_set_grid_convention(self._h, int(convention)))
 

@@ -153,6 +153,15 @@ class OracleScene:
         self.lib.ovr_oracle_sample_tfn(C.byref(self.s), float(sample), o)
         return np.array(o[:], dtype=np.float32)
 
+    def macrocells(self):
+        nz, ny, nx = self.volume.shape
+        mx, my, mz = (nx + 15) // 16, (ny + 15) // 16, (nz + 15) // 16
+        mm = np.zeros((mz, my, mx, 2), np.float32)
+        mj = np.zeros((mz, my, mx), np.float32)
+        self.lib.ovr_oracle_macrocell_value_range(C.byref(self.s), _fp(mm))
+        self.lib.ovr_oracle_macrocell_majorant(C.byref(self.s), _fp(mm), mx * my * mz, _fp(mj))
+        return mm, mj
+
     def trace(self, org, direction):
         o = (C.c_float * 3)(*map(float, org))
         d = (C.c_float * 3)(*map(float, direction))

@@ -211,3 +211,37 @@ def test_errors_are_loud(ovr, oracle, hip_renderer_factory):
         ren.set_sample_per_pixel(0)
     with pytest.raises(RuntimeError, match="path tracing"):
         ren.set_path_tracing(True)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint8, np.uint16])
+def test_macrocell_grids_match_oracle(ovr, oracle, hip_renderer_factory, dtype):
+    """value-range and majorant grids of the reference's SpacePartiton_SingleMC (sp_singlemc.cu:10-97)"""
+    case = make_case(ovr, oracle, n=0, dims=(40, 33, 50), dtype=dtype, tf="bumps", cam="oblique", size=(32, 32), shading=2)
+    ren = hip_setup(ovr, hip_renderer_factory(), case)
+    mm, mj = ren.macrocells()
+    rmm, rmj = oracle_scene(oracle, case).macrocells()
+    assert mm.shape == (4, 3, 3, 2)
+    assert np.array_equal(mm, rmm)
+    assert np.array_equal(mj, rmj)
+    assert (mj == 0).any() and (mj > 0).any()
+
+
+@pytest.mark.parametrize("pipeline", [1, 2])
+@pytest.mark.parametrize("tf", ["sparse", "bumps"])
+def test_empty_space_skipping_is_bit_identical(ovr, oracle, hip_renderer_factory, tf, pipeline):
+    case = make_case(ovr, oracle, n=64, tf=tf, cam="oblique", size=(96, 72), shading=2)
+    frames = []
+    for skip in (False, True):
+        ren = hip_setup(ovr, hip_renderer_factory(), case, pipeline=pipeline)
+        ren.set_empty_space_skipping(skip)
+        ren.commit()
+        ren.render()
+        frames.append(hip_frame(ovr, ren) + (ren.stats(),))
+    (a_rgba, a_grad, a), (b_rgba, b_grad, b) = frames
+    assert np.array_equal(a_rgba, b_rgba) and np.array_equal(a_grad, b_grad)
+    assert a.skipped_samples == 0 and b.skipped_samples > 0
+    assert a.samples == b.samples + b.skipped_samples
+    assert a.shaded_samples == b.shaded_samples
+    assert a.shadow_samples == b.shadow_samples + b.skipped_shadow_samples
+    _, _, cnt = oracle_scene(oracle, case).render()
+    assert cnt.samples == b.samples + b.skipped_samples
