@@ -325,7 +325,7 @@ __device__ __forceinline__ f3 to_object(const MarchConsts& mc, f3 p)
 // raymarching_shadow, shaders_raymarching.cu:44-85 (+ :205-229): alpha-only march toward the light.
 // KS taps are issued before the first one is consumed; taps past the end of the march or past the early-termination
 // point are speculative (their coordinates are clamped, so the loads are always in bounds) and simply dropped.
-template <int VT, int AM, int KS>
+template <int VT, int AM, int KS, bool SKIP>
 __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConsts& tf, const MarchConsts& mc, f3 org, unsigned int& n_shadow,
                                               unsigned int& n_shadow_skipped)
 {
@@ -347,13 +347,13 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
       const float tm = 0.5f * (tx + ty);
       const f3 pos = mk3(fmaf(tm, mc.light.x, org.x), fmaf(tm, mc.light.y, org.y), fmaf(tm, mc.light.z, org.z));
       tap_coords(vc, to_object(mc, pos), taps[k]);
-      mj[k] = vc.majorant ? vc.majorant[tap_cell(vc, taps[k])] : 1.f; // empty-space skipping: max TF opacity of the macrocell
+      mj[k] = SKIP ? vc.majorant[tap_cell(vc, taps[k])] : 1.f; // empty-space skipping: max TF opacity of the macrocell
       tx = ty;
       ty = fminf(tx + mc.shadow_stride, t1);
     }
 #pragma unroll
     for (int k = 0; k < KS; ++k)
-      if (mj[k] > 0.f) tap_loads<VT, AM>(vc, taps[k]);
+      if (!SKIP || mj[k] > 0.f) tap_loads<VT, AM>(vc, taps[k]);
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
       // branch-free on purpose: a conditional use would let the compiler sink this tap's loads into the branch and
@@ -361,11 +361,11 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
       const float s = tap_finish<VT>(vc, taps[k]);
       float a = tf_alpha(tf, tf_coord(tf, s));
       a = opacity_correction(a, mc.base * dts[k]);
-      a = mj[k] > 0.f ? a : 0.f; // a macrocell whose majorant is 0 holds no sample with opacity > 0
+      if (SKIP) a = mj[k] > 0.f ? a : 0.f; // a macrocell whose majorant is 0 holds no sample with opacity > 0
       live = live && valid[k] && (alpha < 0.9999f);
       alpha = live ? fmaf(1.f - alpha, a, alpha) : alpha;
-      n_shadow += (live && mj[k] > 0.f) ? 1u : 0u;
-      n_shadow_skipped += (live && !(mj[k] > 0.f)) ? 1u : 0u;
+      n_shadow += (live && (!SKIP || mj[k] > 0.f)) ? 1u : 0u;
+      if (SKIP) n_shadow_skipped += (live && !(mj[k] > 0.f)) ? 1u : 0u;
     }
   }
   return alpha;
@@ -526,7 +526,7 @@ __device__ __forceinline__ void write_pixel(const RayMarchParams& P, unsigned in
 
 // shade one request: gradient (shaders_common.h:195-215), normals, shadow march, Lambert-ish term
 // (shaders_raymarching.cu:124-158).  Writes the result over the request.
-template <int VT, int SHADE, int AM>
+template <int VT, int SHADE, int AM, bool SKIP>
 __device__ __forceinline__ void shade_request(const RayMarchParams& P, const VolConsts& vc, const TfConsts& tf, const MarchConsts& mc, ShadeReq& r,
                                               unsigned int& n_shadow, unsigned int& n_shadow_skipped)
 {
@@ -553,7 +553,7 @@ __device__ __forceinline__ void shade_request(const RayMarchParams& P, const Vol
                          fmaf(n_w.x, m[2], fmaf(n_w.y, m[5], n_w.z * m[8]))));
   }
   float shadow = 0.f;
-  if (SHADE == 2) shadow = march_shadow<VT, AM, MarchCfg<2>::KS>(vc, tf, mc, pos, n_shadow, n_shadow_skipped);
+  if (SHADE == 2) shadow = march_shadow<VT, AM, MarchCfg<2>::KS, SKIP>(vc, tf, mc, pos, n_shadow, n_shadow_skipped);
   const float cosNL = fabsf(dot3(mc.light, n_w));
   const float shade = 0.5f + 0.5f * cosNL * 2.f * (1.f - shadow); // shaders_raymarching.cu:156-157
   const float tr = r.tr;
@@ -669,7 +669,7 @@ template <int SHADE, bool POOLED> struct QCfg {
   static constexpr int QCAP = SHADE == 0 ? 0 : (POOLED ? 128 : 256);       // pooled: spills after every instruction
 };
 
-template <int VT, int SHADE, int AM, bool POOLED>
+template <int VT, int SHADE, int AM, bool POOLED, bool SKIP>
 __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P)
 {
   using Cfg = QCfg<SHADE, POOLED>;
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
           r.px = r.py = r.pz = r.s = r.v = r.tr = r.a = 0.f; r.next = 0;
           if ((unsigned int)lane < n) {
             r = queue[(q_head + lane) & (QCAP - 1)];
-            if (r.a > 0.f) shade_request<VT, SHADE, AM>(P, vc, tf, mc, r, n_shadow, n_shadow_skipped); // a == 0: null request
+            if (r.a > 0.f) shade_request<VT, SHADE, AM, SKIP>(P, vc, tf, mc, r, n_shadow, n_shadow_skipped); // a == 0: null request
           }
           int opend = owner ? pend : 0;
           apply_batch(r, q_head, n, lane, opend, first, color, gradient);
@@ -828,11 +828,29 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
         const float tm = 0.5f * (mtx + mty);
         poss[k] = mk3(fmaf(tm, dir.x, org.x), fmaf(tm, dir.y, org.y), fmaf(tm, dir.z, org.z));
         tap_coords(vc, to_object(mc, poss[k]), taps[k]);
-        mj[k] = vc.majorant ? vc.majorant[tap_cell(vc, taps[k])] : 1.f; // empty-space skipping: the macrocell's max TF opacity
+        mj[k] = SKIP ? vc.majorant[tap_cell(vc, taps[k])] : 1.f; // empty-space skipping: the macrocell's max TF opacity
+      }
+      if (SKIP) {
+        // empty-space fast path (wave-uniform): every sample of this round lies in a macrocell whose majorant is 0, so all
+        // opacities are exactly 0, alpha does not move and nothing is pushed - only liveness and the counters advance
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) any = any || (mj[k] > 0.f);
+        if (__ballot(any) == 0ull) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              live = live && ((vmask >> (4 * k + b)) & 1u) != 0u && (alpha < 0.9999f);
+              n_skipped += (live && sub == b) ? 1u : 0u;
+            }
+          }
+          continue;
+        }
       }
 #pragma unroll
       for (int k = 0; k < K; ++k)
-        if (mj[k] > 0.f) tap_loads<VT, AM>(vc, taps[k]);
+        if (!SKIP || mj[k] > 0.f) tap_loads<VT, AM>(vc, taps[k]);
       // ---- (3) own samples: value, TF coordinate, corrected opacity (and colour when shading is off)
       float sa[K], va[K], aa[K];
       f3 ca[K];
@@ -841,7 +859,7 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
         sa[k] = tap_finish<VT>(vc, taps[k]);
         va[k] = tf_coord(tf, sa[k]);
         aa[k] = opacity_correction(tf_alpha(tf, va[k]), mc.base * dts[k]);
-        aa[k] = mj[k] > 0.f ? aa[k] : 0.f; // a macrocell whose majorant is 0 holds no sample with opacity > 0
+        if (SKIP) aa[k] = mj[k] > 0.f ? aa[k] : 0.f; // a macrocell whose majorant is 0 holds no sample with opacity > 0
         if (SHADE == 0) {
           const f3 rgb = tf_color(tf, va[k]);
           ca[k] = mk3(clamp01(rgb.x), clamp01(rgb.y), clamp01(rgb.z));
@@ -881,8 +899,8 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
       // ---- (5) count; queue the samples that need shading (slot = tail + prefix of the ballot, lane order = step order)
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        n_samples += (mlive[k] && mj[k] > 0.f) ? 1u : 0u;
-        n_skipped += (mlive[k] && !(mj[k] > 0.f)) ? 1u : 0u;
+        n_samples += (mlive[k] && (!SKIP || mj[k] > 0.f)) ? 1u : 0u;
+        if (SKIP) n_skipped += (mlive[k] && !(mj[k] > 0.f)) ? 1u : 0u;
         n_shaded += mpush[k] ? 1u : 0u;
         if (SHADE != 0) {
           // Quad-granular compaction: if any of a ray's 4 steps needs shading the ray takes 4 consecutive slots (the steps
@@ -959,7 +977,7 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
 // ------------------------------------------------------------------------------------------------------------------
 // pooled pipeline, kernel B: persistent waves shade chunks from all tiles; one returning atomic per chunk
 // ------------------------------------------------------------------------------------------------------------------
-template <int VT, int SHADE, int AM>
+template <int VT, int SHADE, int AM, bool SKIP>
 __global__ __launch_bounds__(kBlock) void shade_pool_kernel(const RayMarchParams P)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -988,7 +1006,7 @@ __global__ __launch_bounds__(kBlock) void shade_pool_kernel(const RayMarchParams
       if ((unsigned int)lane < n) {
         ShadeReq r = Q.reqs[(size_t)c * 64 + lane];
         if (r.a > 0.f) { // a == 0: null request (a step of the quad that needs no shading)
-          shade_request<VT, SHADE, AM>(P, vc, tf, mc, r, n_shadow, n_shadow_skipped);
+          shade_request<VT, SHADE, AM, SKIP>(P, vc, tf, mc, r, n_shadow, n_shadow_skipped);
           Q.reqs[(size_t)c * 64 + lane] = r;
         }
       }
@@ -1110,8 +1128,8 @@ static hipError_t set_lds(KernT kern, size_t lds)
 
 constexpr int kShadeBlocks = 1024; // persistent shade grid: 4 workgroups per CU
 
-template <int VT, int SHADE, int AM>
-static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const hipEvent_t* ev)
+template <int VT, int SHADE, int AM, bool SKIP>
+static hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const hipEvent_t* ev)
 {
   const size_t tf_lds = raymarch_lds_bytes(p.n_color, p.n_alpha);
   if (tf_lds == 0) return hipErrorInvalidValue;
@@ -1120,7 +1138,7 @@ static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const 
   const bool pooled = (SHADE != 0) && p.pool.reqs != nullptr && p.spp == 1;
   if (!pooled) {
     const size_t lds = std::max<size_t>(tf_lds + table_lds_bytes(p, AM) + (size_t)kWaves * QCfg<SHADE, false>::QCAP * sizeof(ShadeReq), 64); // >= 64 B: the counter reduction reuses it
-    auto kern = raymarch_kernel<VT, SHADE, AM, false>;
+    auto kern = raymarch_kernel<VT, SHADE, AM, false, SKIP>;
     if ((e = set_lds(kern, lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -1136,7 +1154,7 @@ static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const 
   {
     constexpr int SH = SHADE == 0 ? 1 : SHADE; // (never instantiated for SHADE == 0: pooled is false)
     const size_t lds = (size_t)kWaves * QCfg<SH, true>::QCAP * sizeof(ShadeReq) + table_lds_bytes(p, AM) + (size_t)p.n_alpha * sizeof(float) + 64;
-    auto kern = raymarch_kernel<VT, SH, AM, true>;
+    auto kern = raymarch_kernel<VT, SH, AM, true, SKIP>;
     if ((e = set_lds(kern, lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -1144,7 +1162,7 @@ static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const 
   if (ev) (void)hipEventRecord(ev[1], stream);
   {
     const size_t lds = std::max<size_t>(tf_lds + table_lds_bytes(p, AM), 64);
-    auto kern = shade_pool_kernel<VT, SHADE, AM>;
+    auto kern = shade_pool_kernel<VT, SHADE, AM, SKIP>;
     if ((e = set_lds(kern, lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(kShadeBlocks), block, lds, stream, p);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -1158,6 +1176,14 @@ static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const 
                        kShadeBlocks, p.counters);
   }
   return hipGetLastError();
+}
+
+template <int VT, int SHADE, int AM>
+static hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const hipEvent_t* ev)
+{
+  // empty-space skipping is a separate instantiation: the non-skipping kernels stay exactly as they are
+  if (p.majorant) return launch_vsbs<VT, SHADE, AM, true>(p, stream, ev);
+  return launch_vsbs<VT, SHADE, AM, false>(p, stream, ev);
 }
 
 template <int VT, int SHADE>
