@@ -232,6 +232,16 @@ def main():
         abytes = algorithmic_bytes(cfg, per_launch, pixels_per_launch)
         nbytes = nominal_bytes(cfg, per_launch, pixels_per_launch)
         achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        # measured HBM traffic (rocprofv3 PMC) of this exact configuration, if a profile of it is committed under profiles/
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                key = f"{args.config}|{cfg['cam']}|{cfg['tf']}|{cfg['shading']}|{world}"
+                ent = json.load(f).get(key)
+                if ent and not args.skip_empty:
+                    traffic = ent["traffic_bytes_per_launch"]
+        except OSError:
+            pass
         out = {
             "metric": "Msamples/s (primary ray-march samples after ERT); fps alongside",
             "value": tot["samples"] / dt / 1e6,
@@ -252,7 +262,7 @@ def main():
                        "frame_accumulation": True, "empty_space_skipping": bool(args.skip_empty), "parallelism": f"image tiles {args.tile}x{args.tile} over {world} rank(s)"},
             "per_frame": {k: per_step[k] for k in sorted(per_step)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "raymarch pipeline (march + shade + composite)" if last_stats.pipeline == 2 else "raymarch_kernel",
                          "kernel_ms": k_ms, "phase_ms_rank0": {"march": phase_ms[0] / steps, "shade": phase_ms[1] / steps, "composite": phase_ms[2] / steps},
                          "pool_chunks": int(last_stats.pool_chunks), "algorithmic_bytes_per_launch": abytes,
