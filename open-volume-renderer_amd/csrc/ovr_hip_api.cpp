@@ -486,7 +486,8 @@ int enqueue_frame(ovr_hip_renderer* r)
   if (want_pool) {
     // first guess: room for 8 shaded samples per pixel; grown after an overflow (finish_frame)
     // (every tile reserves runs of 8 chunks, so add one run per tile)
-    const size_t guess = std::min<size_t>(std::max<size_t>(n * 8 / 64, 4096) + r->pool_tiles * 32, (size_t)1 << 22);
+    size_t guess = std::min<size_t>(std::max<size_t>(n * 8 / 64, 4096) + r->pool_tiles * 4, (size_t)1 << 22);
+    if (const char* pc = getenv("OVR_HIP_POOL_CHUNKS")) guess = std::max<size_t>(8, (size_t)atoll(pc)); // diagnostic: force the overflow path
     if (int e = ensure_pool(r, std::max<size_t>(guess, r->pool.capacity))) return e;
     if (!r->pool.ctrl) {
       HIP_TRY(hipMalloc((void**)&r->pool.ctrl, 4 * sizeof(unsigned int)));

@@ -55,8 +55,14 @@ def gather_frame(local_payload, width, height, tile_w, tile_h, rank, world, unpa
     if rank == dst:
         bufs = [torch.empty_like(local_payload) for _ in range(world)]
         dist.gather(local_payload, gather_list=bufs, dst=dst)
+        if local_payload.is_cuda:
+            # RCCL runs on its own stream and torch only orders it against torch's current stream; the unpack kernels run on
+            # the renderer's stream, so wait for the collective on the host before launching them
+            torch.cuda.current_stream(local_payload.device).synchronize()
         for src in range(world):
             unpack(src, bufs[src])
         return True
     dist.gather(local_payload, gather_list=None, dst=dst)
+    if local_payload.is_cuda:
+        torch.cuda.current_stream(local_payload.device).synchronize()  # the payload buffer is reused by the next frame
     return False

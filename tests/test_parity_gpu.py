@@ -245,3 +245,51 @@ def test_empty_space_skipping_is_bit_identical(ovr, oracle, hip_renderer_factory
     assert a.shadow_samples == b.shadow_samples + b.skipped_shadow_samples
     _, _, cnt = oracle_scene(oracle, case).render()
     assert cnt.samples == b.samples + b.skipped_samples
+
+
+@pytest.mark.parametrize("dims,size", [((1, 1, 1), (9, 7)), ((2, 3, 5), (13, 7)), ((31, 30, 29), (1, 1)), ((33, 5, 70), (25, 41))])
+def test_ragged_sizes(ovr, oracle, hip_renderer_factory, dims, size):
+    """grids that are not multiples of the brick / macro block / macrocell sizes, framebuffers that are not multiples of the
+    4x4 ray tile, single voxels and single pixels"""
+    case = make_case(ovr, oracle, n=0, dims=dims, tf="dense", cam="oblique", size=size, shading=2)
+    ref_rgba, ref_grad, cnt = oracle_scene(oracle, case).render()
+    for skip in (False, True):
+        ren = hip_setup(ovr, hip_renderer_factory(), case)
+        ren.set_empty_space_skipping(skip)
+        ren.commit()
+        ren.render()
+        rgba, grad = hip_frame(ovr, ren)
+        compare(oracle, rgba, ref_rgba, name=f"{dims} {size}")
+        st = ren.stats()
+        assert st.samples + st.skipped_samples == cnt.samples and st.active_pixels == size[0] * size[1]
+
+
+def test_large_transfer_function_and_tiny_one(ovr, oracle, hip_renderer_factory):
+    for tf_n in (2, 4096):
+        case = make_case(ovr, oracle, n=24, tf="dense", cam="front", size=(40, 32), shading=2, tf_n=tf_n)
+        ref_rgba, _, cnt = oracle_scene(oracle, case).render()
+        ren = hip_setup(ovr, hip_renderer_factory(), case)
+        ren.render()
+        rgba, _ = hip_frame(ovr, ren)
+        compare(oracle, rgba, ref_rgba, name=f"tf {tf_n}")
+        assert ren.stats().samples == cnt.samples
+    # beyond what fits in LDS the backend refuses loudly instead of silently degrading
+    case = make_case(ovr, oracle, n=8, tf="dense", cam="front", size=(8, 8), shading=2, tf_n=8192)
+    ren = hip_setup(ovr, hip_renderer_factory(), case)
+    with pytest.raises(RuntimeError, match="transfer function too large"):
+        ren.render()
+
+
+def test_pool_overflow_is_recovered(ovr, oracle, hip_renderer_factory, monkeypatch):
+    """the request pool starts too small (forced with OVR_HIP_POOL_CHUNKS): the march overflows it, the frame is re-rendered with
+    a larger pool and must still be exact (accumulation must not see the aborted attempt)"""
+    monkeypatch.setenv("OVR_HIP_POOL_CHUNKS", "64")
+    case = make_case(ovr, oracle, n=48, tf="dense", cam="oblique", size=(64, 64), shading=2, rate=4.0)
+    ref_rgba, _, cnt = oracle_scene(oracle, case).render(frames=2, accumulate=True)
+    ren = hip_setup(ovr, hip_renderer_factory(), case, accumulate=True, pipeline=2)
+    ren.render()
+    ren.render()
+    rgba, _ = hip_frame(ovr, ren)
+    compare(oracle, rgba, ref_rgba, name="overflow")
+    st = ren.stats()
+    assert st.frame_index == 2 and st.shaded_samples == cnt.shaded_samples and st.pool_chunks > 64
