@@ -293,3 +293,23 @@ def test_pool_overflow_is_recovered(ovr, oracle, hip_renderer_factory, monkeypat
     compare(oracle, rgba, ref_rgba, name="overflow")
     st = ren.stats()
     assert st.frame_index == 2 and st.shaded_samples == cnt.shaded_samples and st.pool_chunks > 64
+
+
+def test_render_from_scene_file(tmp_path, ovr, oracle, hip_renderer_factory):
+    """f1 end to end in Python: VIDI3D file -> our loader -> DeviceHIP, with the scene's own fovy and sampling rate"""
+    vol = ovr.synth.make_volume(32, np.uint8)
+    colors, alphas, vr = ovr.synth.make_tfn("bumps", 256, np.uint8)
+    cam = ovr.synth.make_camera("oblique", 32)
+    path = ovr.vidi3d.write_scene(str(tmp_path), "s", vol, ovr.synth._RAINBOW, alphas[1::2], (0.0, 1.0), cam, fovy=45.0, sample_distance=0.5)
+    scene, camera = ovr.vidi3d.scene_from_file(path)
+    ren = hip_renderer_factory()
+    ren.set_fbsize((64, 48))
+    ren.init(scene, camera)
+    ren.render()
+    rgba, _ = hip_frame(ovr, ren)
+    d = ovr.vidi3d.read_scene(path)
+    tfc = d["tfn_color"][:, :3].ravel()
+    tfa = np.stack([np.linspace(0, 1, 256, dtype=np.float32), d["tfn_opacity"]], 1).ravel()
+    ref, _, cnt = oracle.OracleScene(vol, tfc, tfa, d["value_range"], cam, 64, 48, fovy=45.0, rate=2.0, shading=oracle.SHADE_FULL).render()
+    compare(oracle, rgba, ref, name="scene file")
+    assert ren.stats().samples == cnt.samples
