@@ -160,27 +160,19 @@ def main():
     del vol
     torch.cuda.empty_cache()
 
-    payload = frame = None
+    gatherer = None
     if world > 1:
-        slots = ovr.tiles.max_owned_tiles(W, H, args.tile, args.tile, world)
-        payload = torch.zeros((slots, args.tile, args.tile, 4), dtype=torch.float32, device=dev)
-        frame = torch.zeros((H, W, 4), dtype=torch.float32, device=dev) if rank == 0 else None
-        import ctypes as C
-
-        def unpack(src, buf):
-            ovr._lib.check(ren._lib.ovr_hip_unpack_tiles(ren._h, src, C.c_void_p(buf.data_ptr()), buf.numel() * 4,
-                                                         C.c_void_p(frame.data_ptr()), frame.numel() * 4))
+        gatherer = ovr.tiles.TileGather(ren, W, H, args.tile, rank, world, dev)
 
     def step():
-        ren.render()
-        if world > 1:
-            import ctypes as C
-            ovr._lib.check(ren._lib.ovr_hip_pack_tiles(ren._h, C.c_void_p(payload.data_ptr()), payload.numel() * 4))
+        if world == 1:
+            ren.render()          # blocking, like the reference's render() (optix7/device.cpp:35-43)
+        else:
+            # one frame = march/shade/composite of this rank's tiles, then the gather of all tiles to rank 0; everything is
+            # ordered on one stream, the host waits once per frame
+            ren.render_async()
+            gatherer.run()
             ren.sync()
-            torch.cuda.synchronize()
-            ovr.tiles.gather_frame(payload, W, H, args.tile, args.tile, rank, world, unpack if rank == 0 else None)
-            if rank == 0:
-                ren.sync()
 
     for _ in range(args.warmup):
         step()

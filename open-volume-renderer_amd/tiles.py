@@ -66,3 +66,36 @@ def gather_frame(local_payload, width, height, tile_w, tile_h, rank, world, unpa
     if local_payload.is_cuda:
         torch.cuda.current_stream(local_payload.device).synchronize()  # the payload buffer is reused by the next frame
     return False
+
+
+class TileGather:
+    """Per-frame gather of a sharded frame with no host synchronisation inside the frame: the renderer is put on a torch stream,
+    so pack -> gather (RCCL) -> unpack are ordered by that one stream; the caller synchronises once per frame (ren.sync())."""
+
+    def __init__(self, ren, width, height, tile, rank, world, device, dst=0):
+        import ctypes as C
+        import torch
+        self.C, self.torch = C, torch
+        self.ren, self.rank, self.world, self.dst = ren, rank, world, dst
+        self.stream = torch.cuda.Stream(device=device)
+        ren.set_stream(self.stream.cuda_stream)
+        slots = max_owned_tiles(width, height, tile, tile, world)
+        with torch.cuda.stream(self.stream):
+            self.payload = torch.zeros((slots, tile, tile, 4), dtype=torch.float32, device=device)
+            self.bufs = [torch.zeros_like(self.payload) for _ in range(world)] if rank == dst else None
+            self.frame = torch.zeros((height, width, 4), dtype=torch.float32, device=device) if rank == dst else None
+        self.stream.synchronize()
+
+    def run(self):
+        """enqueue pack, gather and (on dst) unpack behind the frame that was just enqueued with ren.render_async()"""
+        import torch.distributed as dist
+        from . import _lib as L
+        C, ren = self.C, self.ren
+        with self.torch.cuda.stream(self.stream):
+            L.check(ren._lib.ovr_hip_pack_tiles(ren._h, C.c_void_p(self.payload.data_ptr()), self.payload.numel() * 4))
+            dist.gather(self.payload, gather_list=self.bufs, dst=self.dst)
+            if self.rank == self.dst:
+                for src in range(self.world):
+                    b = self.bufs[src]
+                    L.check(ren._lib.ovr_hip_unpack_tiles(ren._h, src, C.c_void_p(b.data_ptr()), b.numel() * 4,
+                                                           C.c_void_p(self.frame.data_ptr()), self.frame.numel() * 4))
