@@ -135,6 +135,8 @@ struct ovr_hip_renderer {
   float* h_rgba[2] = { nullptr, nullptr };
   float* h_grad[2] = { nullptr, nullptr };
   float* d_accum = nullptr;
+  float* d_spp_rgba = nullptr; // pooled pipeline, spp > 1: sums over the sample-per-pixel generations
+  float* d_spp_grad = nullptr;
   size_t fb_pixels = 0;
   int cur = 0;
   bool fb_reset = true;
@@ -184,6 +186,9 @@ int free_framebuffers(ovr_hip_renderer* r)
   }
   if (r->d_accum) HIP_TRY(hipFree(r->d_accum));
   r->d_accum = nullptr;
+  if (r->d_spp_rgba) HIP_TRY(hipFree(r->d_spp_rgba));
+  if (r->d_spp_grad) HIP_TRY(hipFree(r->d_spp_grad));
+  r->d_spp_rgba = r->d_spp_grad = nullptr;
   if (r->d_block_counters) HIP_TRY(hipFree(r->d_block_counters));
   r->d_block_counters = nullptr;
   if (r->pool.tile_first) HIP_TRY(hipFree(r->pool.tile_first));
@@ -481,7 +486,7 @@ int enqueue_frame(ovr_hip_renderer* r)
   }
   // ---- shading pipeline: pooled (march -> shade -> composite) when it applies, else in place
   const int pipe = r->pipeline.current;
-  const bool want_pool = P.shading != 0 && P.spp == 1 && pipe != 1;
+  const bool want_pool = P.shading != 0 && pipe != 1;
   P.pool = PoolDesc{};
   if (want_pool) {
     // first guess: room for 8 shaded samples per pixel; grown after an overflow (finish_frame)
@@ -495,7 +500,14 @@ int enqueue_frame(ovr_hip_renderer* r)
       HIP_TRY(hipHostMalloc((void**)&r->h_ctrl, 4 * sizeof(unsigned int), hipHostMallocDefault));
     }
     P.pool = r->pool;
+    if (P.spp > 1 && !r->d_spp_rgba) {
+      HIP_TRY(hipMalloc((void**)&r->d_spp_rgba, std::max<size_t>(n, 1) * 4 * sizeof(float)));
+      HIP_TRY(hipMalloc((void**)&r->d_spp_grad, std::max<size_t>(n, 1) * 3 * sizeof(float)));
+    }
   }
+  P.spp_index = 0;
+  P.spp_sum_rgba = r->d_spp_rgba;
+  P.spp_sum_grad = r->d_spp_grad;
   r->stats.pipeline = want_pool ? 2 : 1;
   return launch_frame(r);
 }
@@ -517,15 +529,15 @@ int finish_frame(ovr_hip_renderer* r)
   if (r->P.pool.reqs) {
     // pool overflow: the march asked for more chunks than the pool holds; nothing was written to the framebuffer.
     // Grow the pool to what the frame needs (+25 %) and render the same frame again.
-    for (int attempt = 0; attempt < 4 && r->h_ctrl[0] > r->pool.capacity; ++attempt) {
-      const size_t need = (size_t)r->h_ctrl[0] + (size_t)r->h_ctrl[0] / 4 + 64;
+    for (int attempt = 0; attempt < 4 && r->h_ctrl[3] > r->pool.capacity; ++attempt) {
+      const size_t need = (size_t)r->h_ctrl[3] + (size_t)r->h_ctrl[3] / 4 + 64;
       if (int e = ensure_pool(r, need)) return e;
       r->P.pool = r->pool;
       if (int e = launch_frame(r)) return e;
       HIP_TRY(hipStreamSynchronize(r->stream()));
     }
-    if (r->h_ctrl[0] > r->pool.capacity) return fail(OVR_HIP_EDEVICE, "[hip] request pool overflow persists after re-sizing");
-    r->stats.pool_chunks = r->h_ctrl[0];
+    if (r->h_ctrl[3] > r->pool.capacity) return fail(OVR_HIP_EDEVICE, "[hip] request pool overflow persists after re-sizing");
+    r->stats.pool_chunks = r->h_ctrl[3];
   }
   else {
     r->stats.pool_chunks = 0;

@@ -37,7 +37,8 @@ struct float3_ { float x, y, z; };
 struct PoolDesc {
   struct ShadeReq* reqs;        // capacity * 64 requests of 32 bytes (null = pipeline disabled)
   unsigned int capacity;        // chunks
-  unsigned int* ctrl;           // [0] chunks requested by the march  [1] shade cursor  [2..3] reserved; zeroed per frame
+  unsigned int* ctrl;           // [0] chunks requested by the march  [1] shade cursor (both zeroed per generation)
+                                // [3] most chunks any generation of the frame requested (zeroed per frame)
   int* chunk_next;              // per chunk: next chunk of the same tile
   unsigned int* chunk_n;        // per chunk: requests in it (64 except a tile's last)
   int* tile_first;              // per tile (wave of the march grid): first chunk or -1
@@ -55,6 +56,9 @@ struct RayMarchParams {
   int frame_index;  // 1-based
   int accumulate;
   int spp;
+  int spp_index;        // pooled pipeline: the sample-per-pixel generation this launch renders
+  float* spp_sum_rgba;  // pooled pipeline, spp > 1: per-pixel sums over the generations (W*H*4, W*H*3)
+  float* spp_sum_grad;
   // camera (params.h:65-70), basis from device_impl.cpp:125-144
   float3_ cam_pos, cam_dir, cam_hor, cam_ver;
   // volume transform: world -> object is diagonal (device_impl.cpp:288-296)

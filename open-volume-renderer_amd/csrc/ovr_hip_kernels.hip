@@ -384,7 +384,7 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
 //    form a linked list), so the result is bit-identical to shading in place.
 //  * two ways to shade a batch:
 //      in place   (raymarch_kernel)  the wave that owns the tile shades its own batches and gets the contributions
-//                                    back with ds_bpermute.  Used for spp > 1 and as the reference pipeline.
+//                                    back with ds_bpermute.  Used when shading is off and as the reference pipeline.
 //      pooled     (march_spill_kernel -> shade_pool_kernel -> composite_kernel)  the tile's wave spills each full
 //                                    batch as a 2 KiB chunk into a global pool; a second, persistent kernel shades
 //                                    chunks from ALL tiles with perfect load balance (the shadow work of a frame sits in
@@ -724,7 +724,9 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
 
   float o_a = 0.f;
   f3 o_c = mk3(0, 0, 0), o_g = mk3(0, 0, 0);
-  const int spp = P.spp;
+  const int spp = POOLED ? 1 : P.spp; // pooled: one launch per sample-per-pixel generation (P.spp_index), in place: all here
+  if (POOLED && P.spp > 1)
+    for (int i = 0; i < P.spp_index; ++i) tea16(v0, v1); // RandomTEA state of this generation (random.h:146-188)
   // wave-uniform queue cursors (stream positions; slot = position & (QCAP - 1))
   unsigned int q_head = 0, q_tail = 0;
   // pooled: the tile's current reservation of kRun consecutive chunks
@@ -764,7 +766,7 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
 
   for (int k_spp = 0; k_spp < spp; ++k_spp) { // uniform trip count: every lane of the wave runs every round
     float sx = scx, sy = scy;
-    if (spp > 1) {
+    if (P.spp > 1) {
       tea16(v0, v1);
       sx += ((float)v0 * OVR_TEA_TOFLOAT - 0.5f) * rsx;
       sy += ((float)v1 * OVR_TEA_TOFLOAT - 0.5f) * rsy;
@@ -970,7 +972,8 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
     t[0] = t_start; t[1] = __builtin_amdgcn_s_memrealtime();
     t[2] = ((unsigned long long)n_samples << 32) | n_shaded; t[3] = n_shadow;
   }
-  store_block_counters(P, reinterpret_cast<unsigned int*>(lds_raw), lane, wave, n_rays, n_samples, n_shaded, n_shadow, (active && owner) ? 1u : 0u, n_skipped,
+  store_block_counters(P, reinterpret_cast<unsigned int*>(lds_raw), lane, wave, n_rays, n_samples, n_shaded, n_shadow,
+                       (active && owner && (!POOLED || P.spp_index == 0)) ? 1u : 0u, n_skipped,
                        n_shadow_skipped);
 }
 
@@ -1064,16 +1067,37 @@ __global__ __launch_bounds__(kBlock) void composite_kernel(const RayMarchParams 
       o_c = mk3(color.x / alpha, color.y / alpha, color.z / alpha);
       o_g = mk3(gradient.x / alpha, gradient.y / alpha, gradient.z / alpha);
     }
+    float o_a = alpha;
+    if (P.spp > 1) {
+      // one launch per sample-per-pixel generation: sum the generations in order (shaders_raymarching.cu:351-376)
+      float4* sr = reinterpret_cast<float4*>(P.spp_sum_rgba) + pixel_index;
+      float* sg = P.spp_sum_grad + 3ull * pixel_index;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      f3 accg = mk3(0, 0, 0);
+      if (P.spp_index > 0) { acc = *sr; accg = mk3(sg[0], sg[1], sg[2]); }
+      acc.x += o_c.x; acc.y += o_c.y; acc.z += o_c.z; acc.w += alpha;
+      accg.x += o_g.x; accg.y += o_g.y; accg.z += o_g.z;
+      if (P.spp_index + 1 < P.spp) {
+        *sr = acc; sg[0] = accg.x; sg[1] = accg.y; sg[2] = accg.z;
+        return;
+      }
+      if (Q.ctrl[3] > Q.capacity) return; // an earlier generation overflowed the pool: the whole frame is re-rendered
+      const float rspp = 1.f / (float)P.spp;
+      o_a = acc.w * rspp;
+      o_c = mk3(acc.x * rspp, acc.y * rspp, acc.z * rspp);
+      o_g = mk3(accg.x * rspp, accg.y * rspp, accg.z * rspp);
+    }
     // spp == 1: (x + 0) * (1 / 1) is exact, so this equals the in-place kernel's o_c * rspp bit for bit
-    write_pixel(P, pixel_index, o_c, alpha, o_g);
+    write_pixel(P, pixel_index, o_c, o_a, o_g);
   }
 }
 
 // sums the per-workgroup partials into counters[0..4]: each workgroup reduces a slice and adds its 5 sums with one
 // atomic each (integer sums: the result does not depend on the order); counters are zeroed by a memset node before
 __global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned int* __restrict__ partials, int n_blocks, const unsigned int* __restrict__ shade_partials,
-                                                             int n_shade_blocks, unsigned long long* counters)
+                                                             int n_shade_blocks, unsigned long long* counters, unsigned int* pool_ctrl)
 {
+  if (pool_ctrl && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&pool_ctrl[3], pool_ctrl[0]); // most chunks any generation asked for
   __shared__ unsigned long long red[4][kNC];
   unsigned long long acc[kNC] = { 0, 0, 0, 0, 0, 0, 0 };
   const int stride = gridDim.x * 256;
@@ -1135,7 +1159,7 @@ static hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
   if (tf_lds == 0) return hipErrorInvalidValue;
   const dim3 grid = raymarch_grid(p), block(kBlock);
   hipError_t e;
-  const bool pooled = (SHADE != 0) && p.pool.reqs != nullptr && p.spp == 1;
+  const bool pooled = (SHADE != 0) && p.pool.reqs != nullptr;
   if (!pooled) {
     const size_t lds = std::max<size_t>(tf_lds + table_lds_bytes(p, AM) + (size_t)kWaves * QCfg<SHADE, false>::QCAP * sizeof(ShadeReq), 64); // >= 64 B: the counter reduction reuses it
     auto kern = raymarch_kernel<VT, SHADE, AM, false, SKIP>;
@@ -1145,35 +1169,40 @@ static hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
     if (ev) { (void)hipEventRecord(ev[1], stream); (void)hipEventRecord(ev[2], stream); }
     if (p.block_counters && p.counters) {
       if ((e = hipMemsetAsync(p.counters, 0, 8 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
-      hipLaunchKernelGGL(reduce_counters_kernel, dim3(kReduceBlocks), dim3(256), 0, stream, p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)nullptr, 0, p.counters);
+      hipLaunchKernelGGL(reduce_counters_kernel, dim3(kReduceBlocks), dim3(256), 0, stream, p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)nullptr, 0, p.counters, (unsigned int*)nullptr);
     }
     return hipGetLastError();
   }
-  // ---- pooled pipeline
+  // ---- pooled pipeline: march -> shade -> composite, once per sample-per-pixel generation
   if ((e = hipMemsetAsync(p.pool.ctrl, 0, 4 * sizeof(unsigned int), stream)) != hipSuccess) return e;
-  {
-    constexpr int SH = SHADE == 0 ? 1 : SHADE; // (never instantiated for SHADE == 0: pooled is false)
-    const size_t lds = (size_t)kWaves * QCfg<SH, true>::QCAP * sizeof(ShadeReq) + table_lds_bytes(p, AM) + (size_t)p.n_alpha * sizeof(float) + 64;
-    auto kern = raymarch_kernel<VT, SH, AM, true, SKIP>;
-    if ((e = set_lds(kern, lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-  }
-  if (ev) (void)hipEventRecord(ev[1], stream);
-  {
-    const size_t lds = std::max<size_t>(tf_lds + table_lds_bytes(p, AM), 64);
-    auto kern = shade_pool_kernel<VT, SHADE, AM, SKIP>;
-    if ((e = set_lds(kern, lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(kShadeBlocks), block, lds, stream, p);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-  }
-  if (ev) (void)hipEventRecord(ev[2], stream);
-  hipLaunchKernelGGL(composite_kernel, grid, block, 0, stream, p);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
-  if (p.block_counters && p.counters) {
+  if (p.block_counters && p.counters)
     if ((e = hipMemsetAsync(p.counters, 0, 8 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(reduce_counters_kernel, dim3(kReduceBlocks), dim3(256), 0, stream, p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)p.pool.shade_counters,
-                       kShadeBlocks, p.counters);
+  RayMarchParams q = p;
+  for (int g = 0; g < p.spp; ++g) {
+    q.spp_index = g;
+    if (g > 0 && (e = hipMemsetAsync(p.pool.ctrl, 0, 2 * sizeof(unsigned int), stream)) != hipSuccess) return e;
+    {
+      constexpr int SH = SHADE == 0 ? 1 : SHADE; // (never instantiated for SHADE == 0: pooled is false)
+      const size_t lds = (size_t)kWaves * QCfg<SH, true>::QCAP * sizeof(ShadeReq) + table_lds_bytes(p, AM) + (size_t)p.n_alpha * sizeof(float) + 64;
+      auto kern = raymarch_kernel<VT, SH, AM, true, SKIP>;
+      if ((e = set_lds(kern, lds)) != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, grid, block, lds, stream, q);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (ev && g == p.spp - 1) (void)hipEventRecord(ev[1], stream);
+    {
+      const size_t lds = std::max<size_t>(tf_lds + table_lds_bytes(p, AM), 64);
+      auto kern = shade_pool_kernel<VT, SHADE, AM, SKIP>;
+      if ((e = set_lds(kern, lds)) != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(kShadeBlocks), block, lds, stream, q);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (ev && g == p.spp - 1) (void)hipEventRecord(ev[2], stream);
+    hipLaunchKernelGGL(composite_kernel, grid, block, 0, stream, q);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (p.block_counters && p.counters)
+      hipLaunchKernelGGL(reduce_counters_kernel, dim3(kReduceBlocks), dim3(256), 0, stream, p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)p.pool.shade_counters,
+                         kShadeBlocks, p.counters, p.pool.ctrl);
   }
   return hipGetLastError();
 }

@@ -31,10 +31,12 @@ def test_frame_parity_f32(ovr, oracle, hip_renderer_factory, shading, cam, tf, p
         assert st.shadow_samples == cnt.shadow_samples_visible
 
 
+@pytest.mark.parametrize("spp", [1, 4])
 @pytest.mark.parametrize("shading", [1, 2])
-def test_pipelines_bit_identical(ovr, oracle, hip_renderer_factory, shading):
-    """in-place and pooled shading apply every pixel's contributions in the same order: the frames must be equal bit for bit"""
-    case = make_case(ovr, oracle, n=48, tf="bumps", cam="oblique", size=(160, 96), shading=shading)
+def test_pipelines_bit_identical(ovr, oracle, hip_renderer_factory, shading, spp):
+    """in-place and pooled shading apply every pixel's contributions in the same order: the frames must be equal bit for bit
+    (spp > 1: the pooled pipeline runs once per sample-per-pixel generation and sums the generations in order)"""
+    case = make_case(ovr, oracle, n=48, tf="bumps", cam="oblique", size=(160, 96), shading=shading, spp=spp)
     frames = []
     for pipeline in (1, 2):
         ren = hip_setup(ovr, hip_renderer_factory(), case, pipeline=pipeline)
