@@ -795,9 +795,15 @@ int ovr_hip_set_noise_tile(ovr_hip_renderer* r, const float* tile, int32_t xy)
   if (int e = finish_frame(r)) return e;
   HIP_TRY(hipDeviceSynchronize());
   if (r->d_noise) HIP_TRY(hipFree(r->d_noise));
+  if (xy > 128) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_noise_tile: tiles larger than 128 x 128 are not supported");
   const size_t bytes = (size_t)xy * xy * 64 * sizeof(float);
+  // stored transposed, [t][y][x], so that one frame's slice is contiguous (the reference's layout is [y][x][t])
+  std::vector<float> tr((size_t)xy * xy * 64);
+  for (int y = 0; y < xy; ++y)
+    for (int x = 0; x < xy; ++x)
+      for (int t = 0; t < 64; ++t) tr[((size_t)t * xy + y) * xy + x] = tile[((size_t)y * xy + x) * 64 + t];
   HIP_TRY(hipMalloc((void**)&r->d_noise, bytes));
-  HIP_TRY(hipMemcpy(r->d_noise, tile, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(r->d_noise, tr.data(), bytes, hipMemcpyHostToDevice));
   r->noise_xy = xy;
   r->fb_reset = true;
   return 0;

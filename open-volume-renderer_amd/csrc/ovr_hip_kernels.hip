@@ -1459,12 +1459,28 @@ __device__ __forceinline__ float exp_det(float x)
   return p * __uint_as_float((unsigned int)((int)n + 127) << 23);
 }
 
-__device__ __forceinline__ bool mask_keep(const SparseMaskParams& p, unsigned int i, int& x, int& y)
+// The noise tile is stored transposed, [t][y][x] (the reference's file is [y][x][t], blue_noise.h:95-99), so the slice of one
+// frame is a contiguous xy x xy block (16 - 64 KiB) instead of one float every 256 bytes.  A workgroup covers 256 consecutive
+// pixels = at most two image rows; the noise rows they need are staged in LDS (lds_noise[2][xy]) with coalesced loads.
+__device__ __forceinline__ void stage_noise_rows(const SparseMaskParams& p, float* lds_noise, unsigned int first_pixel)
+{
+  const int xy = p.noise_xy;
+  const float* slice = p.noise + (size_t)(p.frame_index % 64) * xy * xy;
+  const int y0 = (int)(first_pixel / (unsigned int)p.width);
+  for (int i = threadIdx.x; i < 2 * xy; i += 256) {
+    const int r = i / xy, c = i - r * xy;
+    lds_noise[i] = slice[(size_t)((y0 + r) % xy) * xy + c];
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ bool mask_keep(const SparseMaskParams& p, const float* lds_noise, unsigned int first_pixel, unsigned int i, int& x, int& y)
 {
   x = (int)(i % (unsigned int)p.width);
   y = (int)(i / (unsigned int)p.width);
   const int xy = p.noise_xy;
-  const float val = p.noise[(size_t)(y % xy) * xy * 64 + (size_t)(x % xy) * 64 + (size_t)(p.frame_index % 64)];
+  const int r = y - (int)(first_pixel / (unsigned int)p.width); // 0 or 1 (a third row only if width < 128: read the slice directly)
+  const float val = r < 2 ? lds_noise[r * xy + (x % xy)] : p.noise[(size_t)(p.frame_index % 64) * xy * xy + (size_t)(y % xy) * xy + (x % xy)];
   const float aspect = (float)p.width / p.height;
   const float fx = ((float)x / p.width - p.mean_x);
   const float fy = ((float)y / p.height - p.mean_y) / aspect;
@@ -1475,10 +1491,12 @@ __device__ __forceinline__ bool mask_keep(const SparseMaskParams& p, unsigned in
 __global__ __launch_bounds__(256) void mask_count_kernel(const SparseMaskParams p)
 {
   __shared__ unsigned int wave_cnt[4];
+  __shared__ float lds_noise[2 * 128];
   const unsigned int n = (unsigned int)p.width * (unsigned int)p.height;
   const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+  stage_noise_rows(p, lds_noise, blockIdx.x * 256);
   int x, y;
-  const bool keep = (i < n) && mask_keep(p, i, x, y);
+  const bool keep = (i < n) && mask_keep(p, lds_noise, blockIdx.x * 256, i, x, y);
   const unsigned long long b = __ballot(keep);
   if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = (unsigned int)__popcll(b);
   __syncthreads();
@@ -1518,10 +1536,12 @@ __global__ __launch_bounds__(1024) void mask_scan_kernel(unsigned int* counts, i
 __global__ __launch_bounds__(256) void mask_write_kernel(const SparseMaskParams p)
 {
   __shared__ unsigned int wave_cnt[4];
+  __shared__ float lds_noise[2 * 128];
   const unsigned int n = (unsigned int)p.width * (unsigned int)p.height;
   const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+  stage_noise_rows(p, lds_noise, blockIdx.x * 256);
   int x = 0, y = 0;
-  const bool keep = (i < n) && mask_keep(p, i, x, y);
+  const bool keep = (i < n) && mask_keep(p, lds_noise, blockIdx.x * 256, i, x, y);
   const unsigned long long b = __ballot(keep);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // prefix of the ballot below this lane = v_mbcnt

@@ -315,3 +315,18 @@ def test_render_from_scene_file(tmp_path, ovr, oracle, hip_renderer_factory):
     ref, _, cnt = oracle.OracleScene(vol, tfc, tfa, d["value_range"], cam, 64, 48, fovy=45.0, rate=2.0, shading=oracle.SHADE_FULL).render()
     compare(oracle, rgba, ref, name="scene file")
     assert ren.stats().samples == cnt.samples
+
+
+@pytest.mark.parametrize("xy,size", [(128, (300, 21)), (64, (640, 5)), (128, (97, 33))])
+def test_sparse_mask_tile_sizes(ovr, oracle, hip_renderer_factory, xy, size):
+    """STBN-sized (128) and blue-noise-sized (64) tiles, rows wider and narrower than a workgroup's 256 pixels"""
+    rng = np.random.default_rng(xy)
+    noise = (rng.integers(0, 256, size=(xy, xy, 64)) / 255.0).astype(np.float32)
+    case = make_case(ovr, oracle, n=8, tf="dense", cam="front", size=size, shading=0)
+    ren = hip_setup(ovr, hip_renderer_factory(), case)
+    ren.set_noise_tile(noise)
+    focus = ((0.3, 0.6), 0.4, 0.05)
+    ren.set_focus(*focus)
+    ren.commit()
+    for frame in (1, 63, 64, 129):
+        assert np.array_equal(ren.sparse_mask(frame), oracle.sparse_mask(frame, size[0], size[1], focus[0], focus[1], focus[2], noise))
