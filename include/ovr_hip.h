@@ -144,7 +144,8 @@ int ovr_hip_commit(ovr_hip_renderer* r);
 int ovr_hip_render(ovr_hip_renderer* r);
 /* non-blocking variant: enqueues the frame on the renderer's stream and returns (for hipEvent timing / graphs) */
 int ovr_hip_render_async(ovr_hip_renderer* r);
-/* waits for everything enqueued by render_async */
+/* waits for the frame enqueued by render_async and for everything else enqueued on the renderer's stream
+ * (ovr_hip_pack_tiles / ovr_hip_unpack_tiles launches included) */
 int ovr_hip_sync(ovr_hip_renderer* r);
 
 /* replaces Impl::mapframe (device_impl.cpp:271-281): publishes the CURRENT framebuffer set.

@@ -872,7 +872,9 @@ int ovr_hip_sync(ovr_hip_renderer* r)
 {
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
   if (int e = set_device(r)) return e;
-  return finish_frame(r);
+  if (int e = finish_frame(r)) return e;
+  HIP_TRY(hipStreamSynchronize(r->stream())); // also covers pack / unpack / mask work enqueued after the frame
+  return 0;
 }
 
 int ovr_hip_render(ovr_hip_renderer* r)

@@ -1,0 +1,142 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (the CPU oracle would need minutes per frame there):
+pipelines and options that must not change a single bit, conservation of the sample counters, sharded == unsharded, and the
+oracle itself on a 1/64 subset of the pixels of the full-size frame."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(ovr, ren, vol, n, size, shading, tf="sparse", cam="oblique", accumulate=False, pipeline=0, skip=False, shard=None, dtype=np.float32):
+    colors, alphas, vr = ovr.synth.make_tfn(tf, 1024, dtype)
+    eye, at, up = ovr.synth.make_camera(cam, n)
+    ren.set_fbsize(size)
+    ren.set_frame_accumulation(accumulate)
+    ren.set_shading(shading)
+    ren.set_shading_pipeline(pipeline)
+    ren.set_empty_space_skipping(skip)
+    ren.set_transfer_function(colors, alphas, vr)
+    if shard:
+        ren.set_image_shard(*shard)
+    ren.init(ovr.Scene(volume=vol, transfer_function=None), ovr.Camera(eye, at, up))
+    ren.commit()
+    return ren
+
+
+def _frame(ovr, ren):
+    fb = ovr.FrameBufferData()
+    ren.mapframe(fb)
+    return np.array(fb.rgba.data(), copy=True)
+
+
+@pytest.fixture(scope="module")
+def c3_volume(ovr):
+    import torch
+    return ovr.synth.make_volume_torch(1024, torch.device("cuda", 0), "float32")
+
+
+def test_c3_invariants(ovr, oracle, hip_renderer_factory, c3_volume):
+    """C3: 1024^3 f32, 1920x1080, reference shading.  pooled == in place == pooled + skipping, bit for bit; counters conserved;
+    accumulating identical frames leaves the frame unchanged; frame is finite with alpha in [0, 1]"""
+    n, size = 1024, (1920, 1080)
+    ref = stats_ref = None
+    for pipeline, skip in ((2, False), (1, False), (2, True)):
+        ren = _setup(ovr, hip_renderer_factory(), c3_volume, n, size, 2, pipeline=pipeline, skip=skip, accumulate=True)
+        ren.render()
+        f, st = _frame(ovr, ren), ren.stats()
+        if ref is None:
+            ref, stats_ref = f, st
+            assert np.isfinite(f).all() and f[..., 3].min() >= 0.0 and f[..., 3].max() <= 1.0
+            assert st.rays == size[0] * size[1] and st.samples > 2e8 and st.shadow_samples > 1e8
+            ren.render()
+            ren.render()
+            assert ren.stats().frame_index == 3
+            f3 = _frame(ovr, ren)
+            assert np.abs(f3 - f).max() <= 2e-7      # (x + x + x) / 3
+        else:
+            assert np.array_equal(f, ref), (pipeline, skip)
+            assert st.samples + st.skipped_samples == stats_ref.samples
+            assert st.shaded_samples == stats_ref.shaded_samples
+            assert st.shadow_samples + st.skipped_shadow_samples == stats_ref.shadow_samples
+        ren.close()
+
+
+def test_c3_shards_and_oracle_subset(ovr, oracle, hip_renderer_factory, c3_volume):
+    """C3 sharded over 8 'ranks' (run one after the other on this card) reassembles to the unsharded frame bit for bit; and the
+    CPU oracle agrees on a subset of the full-size frame's pixels (the 17 64x64 tiles of one anti-diagonal, gradient shading)"""
+    import torch
+    n, size, tile = 1024, (1920, 1080), 64
+    full = _setup(ovr, hip_renderer_factory(), c3_volume, n, size, 1)
+    full.render()
+    ref = _frame(ovr, full)
+    world = 8
+    slots = ovr.tiles.max_owned_tiles(size[0], size[1], tile, tile, world)
+    frame = torch.zeros((size[1], size[0], 4), dtype=torch.float32, device="cuda")
+    total = 0
+    root = None  # the gathering rank's renderer (it knows the shard geometry) scatters every rank's payload
+    for rank in range(world):
+        ren = _setup(ovr, hip_renderer_factory(), c3_volume, n, size, 1, shard=(rank, world, tile, tile))
+        ren.render()
+        total += ren.stats().samples
+        payload = torch.zeros((slots, tile, tile, 4), dtype=torch.float32, device="cuda")
+        ovr._lib.check(ren._lib.ovr_hip_pack_tiles(ren._h, C.c_void_p(payload.data_ptr()), payload.numel() * 4))
+        ren.sync()
+        root = root or ren
+        ovr._lib.check(root._lib.ovr_hip_unpack_tiles(root._h, rank, C.c_void_p(payload.data_ptr()), payload.numel() * 4,
+                                                      C.c_void_p(frame.data_ptr()), frame.numel() * 4))
+        root.sync()
+        if ren is not root:
+            ren.close()
+    torch.cuda.synchronize()
+    got = frame.cpu().numpy()
+    bad = np.argwhere(np.any(got != ref, axis=2))
+    assert bad.size == 0, (len(bad), bad.min(axis=0), bad.max(axis=0), got[tuple(bad[0])], ref[tuple(bad[0])])
+    assert total == full.stats().samples
+    # oracle on 1/64 of the tiles of the same full-size frame (the anti-diagonal tx + ty == 23 through the image centre)
+    vol_host = c3_volume.cpu().numpy()
+    colors, alphas, vr = ovr.synth.make_tfn("sparse", 1024)
+    cam = ovr.synth.make_camera("oblique", n)
+    sc = oracle.OracleScene(vol_host, colors, alphas, vr, cam, size[0], size[1], shading=oracle.SHADE_GRADIENT, shard=(23, 64, tile, tile))
+    o_rgba, _, cnt = sc.render()
+    mask = np.zeros((size[1], size[0]), bool)
+    for tx, ty in ovr.tiles.owned_tiles(size[0], size[1], tile, tile, 23, 64):
+        mask[ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile] = True
+    assert mask.sum() > 30000 and cnt.samples > 1e6
+    d8 = np.abs(oracle.rgba8(ref, flip=False).astype(int) - oracle.rgba8(o_rgba, flip=False).astype(int))[mask]
+    assert d8.max() <= 1
+    assert np.abs(ref - o_rgba)[mask].max() <= 2e-4
+
+
+def test_c2_and_c4_sizes(ovr, oracle, hip_renderer_factory):
+    """C2 (512^3 f32, 1024^2, no shading) and a C4-shaped case (u16, > 4 GiB of bricks: 64-bit-capable addressing modes)"""
+    import torch
+    vol = ovr.synth.make_volume_torch(512, torch.device("cuda", 0), "float32")
+    a = _setup(ovr, hip_renderer_factory(), vol, 512, (1024, 1024), 0)
+    a.render()
+    b = _setup(ovr, hip_renderer_factory(), vol, 512, (1024, 1024), 0, skip=True)
+    b.render()
+    assert np.array_equal(_frame(ovr, a), _frame(ovr, b))
+    assert a.stats().samples == b.stats().samples + b.stats().skipped_samples
+    del vol
+    torch.cuda.empty_cache()
+    # 1600 x 1280 x 1200 u16: 2.46 G voxels -> 6.6 GB bricked: element offsets still fit 32 bits (addressing mode 1) ...
+    for dims in ((1600, 1280, 1200),):
+        v = ovr.synth.make_volume_torch(max(dims), torch.device("cuda", 0), "uint16")[: dims[2], : dims[1], : dims[0]].contiguous()
+        colors, alphas, vr = ovr.synth.make_tfn("sparse", 1024, np.uint16)
+        frames = []
+        for pipeline in (2, 1):
+            ren = hip_renderer_factory()
+            ren.set_fbsize((640, 360))
+            ren.set_shading(2)
+            ren.set_shading_pipeline(pipeline)
+            ren.set_transfer_function(colors, alphas, vr)
+            c = (dims[0] / 2, dims[1] / 2, dims[2] / 2)
+            ren.init(ovr.Scene(volume=v, transfer_function=None), ovr.Camera((c[0] - 2500.0, c[1] + 1200.0, c[2] + 1300.0), c, (0, 1, 0)))
+            ren.commit()
+            ren.render()
+            frames.append(_frame(ovr, ren))
+            assert ren.stats().shaded_samples > 0
+            ren.close()
+        assert np.array_equal(frames[0], frames[1]) and np.isfinite(frames[0]).all()

@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# profiling helper run ON the GPU box: bash tools_prof.sh <tag> <bench args...>
+# profiling helper run ON the GPU box: bash tools/prof.sh <tag> <bench args...>
 set -uo pipefail
 tag=$1; shift
 export TMPDIR=/tmp

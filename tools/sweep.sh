@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# camera/config sweep ON the GPU box: bash tools_sweep.sh <out-file> [configs...]
+# camera/config sweep ON the GPU box: bash tools/sweep.sh <out-file> [configs...]
 out=$1; shift
 cfgs=${@:-"c2 c3g c3"}
 for c in $cfgs; do for cam in front oblique; do
