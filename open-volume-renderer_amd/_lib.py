@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libovr_hip.so")
+# OVR_HIP_LIBRARY: development override (A/B runs of differently built kernels); the default is the in-tree build
+LIB_PATH = os.environ.get("OVR_HIP_LIBRARY") or os.path.join(_HERE, "libovr_hip.so")
 
 # numeric values of ovr::ValueType (ovr/scene.h:32-53)
 TYPE_UINT8, TYPE_INT8 = 100, 101

@@ -158,6 +158,12 @@ struct ovr_hip_renderer {
   size_t trace_words = 0;
   unsigned long long* h_counters = nullptr; // pinned
 
+  // launch order of the march's 8x8-pixel workgroups (dense mode): owned blocks, longest rays first
+  unsigned int* d_sched_src = nullptr; // owned blocks in image order (host-built: framebuffer size and shard)
+  unsigned int* d_sched = nullptr;     // sorted on the device whenever the camera or the volume's box changes
+  unsigned int n_sched = 0;
+  bool sched_list_dirty = true, sched_dirty = true;
+
   // request pool of the pooled shading pipeline
   PoolDesc pool{};
   size_t pool_tiles = 0;
@@ -191,6 +197,11 @@ int free_framebuffers(ovr_hip_renderer* r)
   r->d_spp_rgba = r->d_spp_grad = nullptr;
   if (r->d_block_counters) HIP_TRY(hipFree(r->d_block_counters));
   r->d_block_counters = nullptr;
+  if (r->d_sched_src) HIP_TRY(hipFree(r->d_sched_src));
+  if (r->d_sched) HIP_TRY(hipFree(r->d_sched));
+  r->d_sched_src = r->d_sched = nullptr;
+  r->n_sched = 0;
+  r->sched_list_dirty = r->sched_dirty = true;
   if (r->pool.tile_first) HIP_TRY(hipFree(r->pool.tile_first));
   if (r->pool.tile_count) HIP_TRY(hipFree(r->pool.tile_count));
   if (r->pool.pix_state) HIP_TRY(hipFree(r->pool.pix_state));
@@ -408,6 +419,41 @@ int update_macrocells(ovr_hip_renderer* r, hipStream_t st)
   return 0;
 }
 
+// the 8x8-pixel blocks of the image this renderer draws (all of them, or those holding a pixel of one of its tiles),
+// in image order; the device sorts them by ray length (launch_schedule) before the next frame
+int build_schedule_list(ovr_hip_renderer* r)
+{
+  const int W = r->fbsize.current.w, H = r->fbsize.current.h;
+  const ShardP& s = r->shard.current;
+  const int bw = (W + 7) / 8, bh = (H + 7) / 8;
+  if (bw > 0xffff || bh > 0xffff) return fail(OVR_HIP_EINVAL, "[hip] framebuffer larger than 524280 pixels on a side");
+  std::vector<unsigned int> list;
+  list.reserve((size_t)bw * bh / (size_t)std::max(1, s.world) + 64);
+  for (int by = 0; by < bh; ++by)
+    for (int bx = 0; bx < bw; ++bx) {
+      bool mine = s.world <= 1;
+      if (!mine) {
+        const int tx0 = (bx * 8) / s.tw, tx1 = std::min(bx * 8 + 7, W - 1) / s.tw;
+        const int ty0 = (by * 8) / s.th, ty1 = std::min(by * 8 + 7, H - 1) / s.th;
+        for (int ty = ty0; ty <= ty1 && !mine; ++ty)
+          for (int tx = tx0; tx <= tx1 && !mine; ++tx) mine = ((tx + ty) % s.world) == s.rank;
+      }
+      if (mine) list.push_back((unsigned int)bx | ((unsigned int)by << 16));
+    }
+  if (r->d_sched_src) HIP_TRY(hipFree(r->d_sched_src));
+  if (r->d_sched) HIP_TRY(hipFree(r->d_sched));
+  r->d_sched_src = r->d_sched = nullptr;
+  r->n_sched = (unsigned int)list.size();
+  if (!list.empty()) {
+    HIP_TRY(hipMalloc((void**)&r->d_sched_src, list.size() * sizeof(unsigned int)));
+    HIP_TRY(hipMalloc((void**)&r->d_sched, list.size() * sizeof(unsigned int)));
+    HIP_TRY(hipMemcpy(r->d_sched_src, list.data(), list.size() * sizeof(unsigned int), hipMemcpyHostToDevice));
+  }
+  r->sched_list_dirty = false;
+  r->sched_dirty = true;
+  return 0;
+}
+
 // Impl::render up to and including the launch (device_impl.cpp:199-262); no host synchronisation
 int enqueue_frame(ovr_hip_renderer* r)
 {
@@ -477,6 +523,18 @@ int enqueue_frame(ovr_hip_renderer* r)
   P.trace = r->d_trace;
   P.sparse_xy = nullptr;
   P.sparse_count = nullptr;
+  P.schedule = nullptr;
+  P.n_schedule = 0;
+  if (!sparse) {
+    if (r->sched_list_dirty)
+      if (int e = build_schedule_list(r)) return e;
+    if (r->sched_dirty) {
+      HIP_TRY(launch_schedule(P, r->d_sched_src, r->n_sched, r->d_sched, st));
+      r->sched_dirty = false;
+    }
+    P.schedule = r->d_sched;
+    P.n_schedule = r->n_sched;
+  }
   if (sparse) { // createSparseSamples, device_impl.cpp:304-342
     if (!r->d_noise) return fail(OVR_HIP_ESTATE, "[hip] sparse sampling enabled but no noise tile was set (ovr_hip_set_noise_tile)");
     if (int e = ensure_sparse_buffers(r)) return e;
@@ -710,6 +768,7 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
   r->mc_ranges_valid = r->mc_majorant_valid = false;
   update_volume_params(r);
   update_tfn_range(r);
+  r->sched_dirty = true;
   r->fb_reset = true;
   return 0;
 }
@@ -836,6 +895,7 @@ int ovr_hip_commit(ovr_hip_renderer* r)
       update_camera(r);
       r->camera_dirty = false;
     }
+    r->sched_dirty = true;
     r->fb_reset = true;
   }
   if (r->tfn.update()) { // :146-153
@@ -846,6 +906,7 @@ int ovr_hip_commit(ovr_hip_renderer* r)
   }
   if (r->grid_convention.update()) {
     if (r->have_volume) update_volume_params(r);
+    r->sched_dirty = true;
     r->fb_reset = true;
   }
   if (r->focus.update()) r->fb_reset = true;      // :155-168
@@ -856,7 +917,10 @@ int ovr_hip_commit(ovr_hip_renderer* r)
   if (r->shading.update()) r->fb_reset = true;
   (void)r->pipeline.update(); // both pipelines produce the same frame: no accumulation reset
   (void)r->skipping.update(); // skipping does not change the frame either
-  if (r->shard.update()) r->fb_reset = true;
+  if (r->shard.update()) {
+    r->sched_list_dirty = true;
+    r->fb_reset = true;
+  }
   return 0;
 }
 

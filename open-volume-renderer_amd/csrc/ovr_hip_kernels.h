@@ -77,6 +77,9 @@ struct RayMarchParams {
   int shading;                // OVR_HIP_SHADE_*
   // image-plane shard
   int rank, world, tile_w, tile_h;
+  // dense mode: the 8x8-pixel blocks this renderer draws, bx | by << 16, longest rays first (launch_schedule)
+  const unsigned int* schedule;
+  unsigned int n_schedule;
   // sparse sampling: compacted (x,y) list + device-side count (2 * pixels), null in dense mode
   const int32_t* sparse_xy;
   const unsigned long long* sparse_count;
@@ -95,8 +98,10 @@ size_t pool_shade_blocks();
 
 // dynamic LDS bytes the ray-march kernel needs for this TF (0 when the TF stays in global memory)
 size_t raymarch_lds_bytes(int n_color, int n_alpha);
-// number of workgroups launch_raymarch will use (size of the block_counters workspace / 5)
+// number of workgroups launch_raymarch will use (size of the block_counters workspace / 7)
 size_t raymarch_grid_blocks(const RayMarchParams& p);
+// sorts the n owned blocks of src (bx | by << 16, any order) by descending ray length into dst; uses p's camera and box
+hipError_t launch_schedule(const RayMarchParams& p, const unsigned int* src, unsigned int n, unsigned int* dst, hipStream_t stream);
 
 // linear (x fastest) -> bricked layout; src may be any reference ValueType, dst is the VoxelType chosen by
 // device_voxel_type().  z0/nz_chunk allow chunked uploads from host staging.

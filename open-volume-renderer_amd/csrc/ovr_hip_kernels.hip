@@ -44,9 +44,19 @@ __device__ __forceinline__ f3 normalize3_exact(f3 v)
   return mk3(v.x / l, v.y / l, v.z / l);
 }
 
-// opacity correction, shaders_raymarching.cu:118-122: 1 - __powf(1 - a, base*dt); __powf == exp2(y * log2(x))
+// opacity correction, shaders_raymarching.cu:118-122: 1 - __powf(1 - a, base*dt); __powf == exp2(y * log2(x)).
+// BF: branch-free form (bit select instead of the exec-mask branch the compiler builds around the two transcendentals);
+// same value - adj == 1 keeps a exactly as the reference's branch does.  Only the skipping shadow march gains from it
+// (0.85 -> 0.71 ms on C3); the other kernels are measurably slower with it, so they keep the branch.
+template <bool BF>
 __device__ __forceinline__ float opacity_correction(float a, float adj)
 {
+  if (BF) {
+    const float pw = __builtin_amdgcn_exp2f(adj * __builtin_amdgcn_logf(1.f - a));
+    const float c = clamp01(1.f - pw);
+    const unsigned int m = (fabsf(adj - 1.f) < 1e-7f) ? 0u : ~0u;
+    return __uint_as_float((__float_as_uint(c) & m) | (__float_as_uint(a) & ~m));
+  }
   if (!(fabsf(adj - 1.f) < 1e-7f)) {
     const float pw = __builtin_amdgcn_exp2f(adj * __builtin_amdgcn_logf(1.f - a));
     a = clamp01(1.f - pw);
@@ -360,7 +370,7 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
       // serialise the taps again (seen in the ISA); dead lanes just compute a value that is not used
       const float s = tap_finish<VT>(vc, taps[k]);
       float a = tf_alpha(tf, tf_coord(tf, s));
-      a = opacity_correction(a, mc.base * dts[k]);
+      a = opacity_correction<SKIP>(a, mc.base * dts[k]);
       if (SKIP) a = mj[k] > 0.f ? a : 0.f; // a macrocell whose majorant is 0 holds no sample with opacity > 0
       live = live && valid[k] && (alpha < 0.9999f);
       alpha = live ? fmaf(1.f - alpha, a, alpha) : alpha;
@@ -480,25 +490,6 @@ __device__ __forceinline__ void stage_tf(const RayMarchParams& P, unsigned char*
   tf.lower = P.tf_lower; tf.upper = P.tf_upper; tf.scale = P.tf_scale;
 }
 
-// which pixel does this lane own? (compute_screen_position, shaders_common.h:394-451)
-__device__ __forceinline__ bool assign_pixel(const RayMarchParams& P, int lane, int wave, int& ix, int& iy)
-{
-  bool active;
-  if (P.sparse_xy) {
-    const unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
-    active = (2ull * i) < *P.sparse_count;
-    ix = active ? P.sparse_xy[2 * i] : 0;
-    iy = active ? P.sparse_xy[2 * i + 1] : 0;
-  }
-  else {
-    ix = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    iy = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    active = ix < P.width && iy < P.height;
-  }
-  if (P.world > 1 && active) active = ((ix / P.tile_w + iy / P.tile_h) % P.world) == P.rank;
-  return active;
-}
-
 // accumulation + framebuffer write, shaders_raymarching.cu:389-409
 __device__ __forceinline__ void write_pixel(const RayMarchParams& P, unsigned int pixel_index, f3 o_c, float o_a, f3 o_g)
 {
@@ -615,7 +606,7 @@ __device__ __forceinline__ void store_block_counters(const RayMarchParams& P, un
   }
   __syncthreads();
   if (threadIdx.x < kNC) {
-    const unsigned int bid = blockIdx.x + blockIdx.y * gridDim.x;
+    const unsigned int bid = blockIdx.x;
     unsigned int sum = 0;
     for (int w = 0; w < kWaves; ++w) sum += red[w * kNC + threadIdx.x];
     P.block_counters[(size_t)bid * kNC + threadIdx.x] = sum;
@@ -642,6 +633,9 @@ __device__ __forceinline__ float quad_bcast(float x) // value of lane B of this 
 __device__ __forceinline__ float sel4(float a0, float a1, float a2, float a3, int sub) { return sub == 0 ? a0 : sub == 1 ? a1 : sub == 2 ? a2 : a3; }
 
 // which pixel does this QUAD own?  (4x4 pixels per wave, 8x8 per workgroup; sparse mode: 64 list entries per workgroup)
+// Dense mode: workgroup s of the 1-D grid renders the 8x8 block P.schedule[s] = bx | by << 16 - the blocks this rank owns,
+// longest rays first (schedule_kernel) - compute_screen_position of the reference (shaders_common.h:394-451) is the
+// identity on the launch index, which fixes neither an order nor a grouping.
 __device__ __forceinline__ bool assign_pixel_quad(const RayMarchParams& P, int lane, int wave, int& ix, int& iy)
 {
   const int ray = lane >> 2;
@@ -653,8 +647,9 @@ __device__ __forceinline__ bool assign_pixel_quad(const RayMarchParams& P, int l
     iy = active ? P.sparse_xy[2 * i + 1] : 0;
   }
   else {
-    ix = blockIdx.x * 8 + (wave & 1) * 4 + (ray & 3);
-    iy = blockIdx.y * 8 + (wave >> 1) * 4 + (ray >> 2);
+    const unsigned int e = P.schedule[blockIdx.x];
+    ix = (int)(e & 0xffffu) * 8 + (wave & 1) * 4 + (ray & 3);
+    iy = (int)(e >> 16) * 8 + (wave >> 1) * 4 + (ray >> 2);
     active = ix < P.width && iy < P.height;
   }
   if (P.world > 1 && active) active = ((ix / P.tile_w + iy / P.tile_h) % P.world) == P.rank;
@@ -669,8 +664,13 @@ template <int SHADE, bool POOLED> struct QCfg {
   static constexpr int QCAP = SHADE == 0 ? 0 : (POOLED ? 128 : 256);       // pooled: spills after every instruction
 };
 
+// Register budget: at most 3 waves per SIMD (up to 168 VGPRs).  Left alone the compiler squeezes the kernel into 128 VGPRs
+// for a 4th wave by serialising the K tap groups it is supposed to keep in flight - measured 1.98 instead of 1.53 ms on C3.
+#ifndef OVR_MARCH_WPE
+#define OVR_MARCH_WPE 3
+#endif
 template <int VT, int SHADE, int AM, bool POOLED, bool SKIP>
-__global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_MARCH_WPE))) void raymarch_kernel(const RayMarchParams P)
 {
   using Cfg = QCfg<SHADE, POOLED>;
   constexpr int K = Cfg::K;
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
     }
   }
   const PoolDesc& Q = P.pool;
-  const unsigned int tile = (blockIdx.x + blockIdx.y * gridDim.x) * kWaves + wave;
+  const unsigned int tile = blockIdx.x * kWaves + wave;
 
   const float rsx = 1.f / (float)P.width, rsy = 1.f / (float)P.height;
   const float scx = ((float)ix + .5f) * rsx, scy = ((float)iy + .5f) * rsy;
@@ -724,7 +724,10 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
 
   float o_a = 0.f;
   f3 o_c = mk3(0, 0, 0), o_g = mk3(0, 0, 0);
-  const int spp = POOLED ? 1 : P.spp; // pooled: one launch per sample-per-pixel generation (P.spp_index), in place: all here
+  // pooled: one launch per sample-per-pixel generation (P.spp_index), in place: all here.  min(P.spp, 1) is 1, but as a
+  // run-time value: with a constant trip count of 1 the compiler restructures the kernel into a schedule that keeps fewer
+  // taps in flight (126 instead of 153 VGPRs) and the C3 march takes 1.98 instead of 1.53 ms
+  const int spp = POOLED ? min(P.spp, 1) : P.spp;
   if (POOLED && P.spp > 1)
     for (int i = 0; i < P.spp_index; ++i) tea16(v0, v1); // RandomTEA state of this generation (random.h:146-188)
   // wave-uniform queue cursors (stream positions; slot = position & (QCAP - 1))
@@ -860,11 +863,34 @@ __global__ __launch_bounds__(kBlock) void raymarch_kernel(const RayMarchParams P
       for (int k = 0; k < K; ++k) {
         sa[k] = tap_finish<VT>(vc, taps[k]);
         va[k] = tf_coord(tf, sa[k]);
-        aa[k] = opacity_correction(tf_alpha(tf, va[k]), mc.base * dts[k]);
+        aa[k] = opacity_correction<false>(tf_alpha(tf, va[k]), mc.base * dts[k]);
         if (SKIP) aa[k] = mj[k] > 0.f ? aa[k] : 0.f; // a macrocell whose majorant is 0 holds no sample with opacity > 0
         if (SHADE == 0) {
           const f3 rgb = tf_color(tf, va[k]);
           ca[k] = mk3(clamp01(rgb.x), clamp01(rgb.y), clamp01(rgb.z));
+        }
+      }
+      // ---- (3b) transparent round (wave-uniform; ~9 of 10 rounds with a sparse transfer function): no live sample of any
+      //      ray of the wave has opacity > 0, so every step adds exactly 0 to alpha and colour (fma(tr, 0, x) == x) and
+      //      pushes nothing - only liveness and the counters move.  The validity bits are monotone (once ty == tx == t1 it
+      //      stays), so step i is live iff the ray was live at the start of the round, alpha < 0.9999 and bit i is set.
+#ifndef OVR_FAST_SKIP
+#define OVR_FAST_SKIP 0 /* the skipping kernels have their own, earlier fast path; this one costs them 30 VGPRs */
+#endif
+      if (OVR_FAST_SKIP || !SKIP) {
+        bool opaque = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) opaque = opaque || (aa[k] > 0.f);
+        if (__ballot(opaque && live) == 0ull) {
+          const bool go = live && (alpha < 0.9999f);
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const bool ml = go && ((vmask >> (4 * k + sub)) & 1u) != 0u;
+            n_samples += (ml && (!SKIP || mj[k] > 0.f)) ? 1u : 0u;
+            if (SKIP) n_skipped += (ml && !(mj[k] > 0.f)) ? 1u : 0u;
+          }
+          live = go && ((vmask >> (4 * K - 1)) & 1u) != 0u;
+          continue;
         }
       }
       // ---- (4) the ray's alpha recurrence over the 4K steps, in order; every lane of the quad computes all of it
@@ -1040,7 +1066,7 @@ __global__ __launch_bounds__(kBlock) void composite_kernel(const RayMarchParams 
   const bool active = assign_pixel_quad(P, lane, wave, ix, iy) && (lane & 3) == 0; // one owner lane per ray, as in the march
   const PoolDesc& Q = P.pool;
   if (Q.ctrl[0] > Q.capacity) return; // pool overflow: the host re-renders this frame with a larger pool, nothing may be written
-  const unsigned int tile = (blockIdx.x + blockIdx.y * gridDim.x) * kWaves + wave;
+  const unsigned int tile = blockIdx.x * kWaves + wave;
   const unsigned int pixel_index = (unsigned int)ix + (unsigned int)iy * (unsigned int)P.width;
   float alpha = 0.f;
   unsigned int first = 0;
@@ -1122,6 +1148,70 @@ __global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned int
   __syncthreads();
   if (threadIdx.x < kNC) atomicAdd(&counters[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+// ------------------------------------------------------------------------------------------------------------------
+// launch order of the march workgroups: longest rays first
+// A wave needs as long as its longest ray (~1700 dependent steps through the volume's diagonal), however empty the machine
+// is; in launch-index order those waves sit in the middle of the grid and the kernel ends with a tail of a few hundred
+// microseconds at a fraction of the occupancy (per-wave trace: the last 15 % of the march's time ran < 1/3 of the waves;
+// on an image shard, where the kernel is 4-8 x shorter, the tail was half of it).  Sorting the owned 8x8 blocks by the
+// length of their rays' box intersection (counting sort, 64 classes, descending) starts the long ones first and lets the
+// short ones fill the gaps.  One workgroup; runs when the camera, the framebuffer size, the volume's box or the shard changes.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kSchedClasses = 64;
+__device__ __forceinline__ unsigned int schedule_class(const RayMarchParams& P, const MarchConsts& mc, unsigned int e)
+{
+  const f3 c0 = ld3(P.cam_dir), h0 = ld3(P.cam_hor), v0 = ld3(P.cam_ver);
+  const f3 oo = to_object(mc, ld3(P.cam_pos));
+  const int bx = (int)(e & 0xffffu) * 8, by = (int)(e >> 16) * 8;
+  float longest = -1.f;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { // the block's centre and corners
+    const int ix = min(bx + (k == 0 ? 4 : (k & 1) ? 0 : 7), P.width - 1), iy = min(by + (k == 0 ? 4 : (k & 2) ? 0 : 7), P.height - 1);
+    const float ux = ((float)ix + .5f) / (float)P.width - 0.5f, uy = ((float)iy + .5f) / (float)P.height - 0.5f;
+    const f3 d = normalize3_exact(mk3(c0.x + ux * h0.x + uy * v0.x, c0.y + ux * h0.y + uy * v0.y, c0.z + ux * h0.z + uy * v0.z));
+    float a = 0.f, b = FLT_MAX;
+    if (intersect_unit_box(a, b, oo, mk3(d.x * mc.inv_scale.x, d.y * mc.inv_scale.y, d.z * mc.inv_scale.z))) longest = fmaxf(longest, b - a);
+  }
+  if (!(longest >= 0.f)) return 0u; // no ray of the block meets the volume: last
+  const float rel = longest / (P.long_ray_steps * P.step); // 1 = the volume's diagonal
+  return (unsigned int)min(kSchedClasses - 1, 1 + (int)(rel * (float)(kSchedClasses - 2)));
+}
+
+__global__ __launch_bounds__(1024) void schedule_kernel(const RayMarchParams P, const unsigned int* __restrict__ src, unsigned int n,
+                                                        unsigned int* __restrict__ dst)
+{
+  __shared__ unsigned int count[kSchedClasses], cursor[kSchedClasses];
+  VolConsts vc;
+  MarchConsts mc;
+  setup_consts(P, vc, mc);
+  if (threadIdx.x < kSchedClasses) count[threadIdx.x] = 0u;
+  __syncthreads();
+  for (unsigned int i = threadIdx.x; i < n; i += 1024u) atomicAdd(&count[schedule_class(P, mc, src[i])], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int at = 0u;
+    for (int c = kSchedClasses - 1; c >= 0; --c) { cursor[c] = at; at += count[c]; }
+  }
+  __syncthreads();
+  // 1024 entries at a time, in list order: inside a class the blocks stay within 1024 slots of their image order
+  // (neighbouring blocks run at about the same time and share their bricks in L2 / Infinity Cache)
+  for (unsigned int c = 0; c < n; c += 1024u) {
+    const unsigned int i = c + threadIdx.x;
+    if (i < n) {
+      const unsigned int e = src[i];
+      dst[atomicAdd(&cursor[schedule_class(P, mc, e)], 1u)] = e;
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_schedule(const RayMarchParams& p, const unsigned int* src, unsigned int n, unsigned int* dst, hipStream_t stream)
+{
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, stream, p, src, n, dst);
+  return hipGetLastError();
+}
+
 constexpr int kReduceBlocks = 64;
 
 size_t raymarch_lds_bytes(int n_color, int n_alpha)
@@ -1134,13 +1224,12 @@ size_t raymarch_lds_bytes(int n_color, int n_alpha)
 size_t raymarch_grid_blocks(const RayMarchParams& p)
 {
   if (p.sparse_xy) return ((size_t)p.width * p.height + kBlock / 4 - 1) / (kBlock / 4);
-  return (size_t)((p.width + 7) / 8) * (size_t)((p.height + 7) / 8);
+  return p.n_schedule;
 }
 
 static dim3 raymarch_grid(const RayMarchParams& p)
 {
-  if (p.sparse_xy) return dim3((unsigned)(((size_t)p.width * p.height + kBlock / 4 - 1) / (kBlock / 4)));
-  return dim3((unsigned)((p.width + 7) / 8), (unsigned)((p.height + 7) / 8));
+  return dim3((unsigned)raymarch_grid_blocks(p));
 }
 
 template <typename KernT>
@@ -1157,6 +1246,7 @@ static hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
 {
   const size_t tf_lds = raymarch_lds_bytes(p.n_color, p.n_alpha);
   if (tf_lds == 0) return hipErrorInvalidValue;
+  if (!p.sparse_xy && p.n_schedule > 0 && !p.schedule) return hipErrorInvalidValue;
   const dim3 grid = raymarch_grid(p), block(kBlock);
   hipError_t e;
   const bool pooled = (SHADE != 0) && p.pool.reqs != nullptr;
@@ -1164,7 +1254,7 @@ static hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
     const size_t lds = std::max<size_t>(tf_lds + table_lds_bytes(p, AM) + (size_t)kWaves * QCfg<SHADE, false>::QCAP * sizeof(ShadeReq), 64); // >= 64 B: the counter reduction reuses it
     auto kern = raymarch_kernel<VT, SHADE, AM, false, SKIP>;
     if ((e = set_lds(kern, lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
+    if (grid.x > 0) hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (ev) { (void)hipEventRecord(ev[1], stream); (void)hipEventRecord(ev[2], stream); }
     if (p.block_counters && p.counters) {
@@ -1186,7 +1276,7 @@ static hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
       const size_t lds = (size_t)kWaves * QCfg<SH, true>::QCAP * sizeof(ShadeReq) + table_lds_bytes(p, AM) + (size_t)p.n_alpha * sizeof(float) + 64;
       auto kern = raymarch_kernel<VT, SH, AM, true, SKIP>;
       if ((e = set_lds(kern, lds)) != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, grid, block, lds, stream, q);
+      if (grid.x > 0) hipLaunchKernelGGL(kern, grid, block, lds, stream, q);
       if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (ev && g == p.spp - 1) (void)hipEventRecord(ev[1], stream);
@@ -1198,7 +1288,7 @@ static hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
       if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (ev && g == p.spp - 1) (void)hipEventRecord(ev[2], stream);
-    hipLaunchKernelGGL(composite_kernel, grid, block, 0, stream, q);
+    if (grid.x > 0) hipLaunchKernelGGL(composite_kernel, grid, block, 0, stream, q);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (p.block_counters && p.counters)
       hipLaunchKernelGGL(reduce_counters_kernel, dim3(kReduceBlocks), dim3(256), 0, stream, p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)p.pool.shade_counters,

@@ -1,0 +1,50 @@
+"""Per-rank render time of an image-sharded frame, all 'ranks' run one after the other on ONE card: how well does the
+tile -> rank assignment balance the work?  usage: python tools/shard_balance.py [n] [tile ...]"""
+import sys
+sys.path[:0] = ['/root/repo', '/root/repo/tests']
+import numpy as np, torch, ovr_amd as ovr
+from test_full_size_gpu import _setup
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+tiles = [int(a) for a in sys.argv[2:]] or [64, 32, 16]
+size = (1920, 1080)
+vol = ovr.synth.make_volume_torch(n, torch.device('cuda', 0), 'float32')
+
+
+def kernel_ms(ren, frames=6):
+    best = 1e9
+    for _ in range(frames):
+        ren.render()
+        best = min(best, ren.stats().kernel_ms)
+    return best
+
+
+full = _setup(ovr, ovr.create_renderer('hip'), vol, n, size, 2, accumulate=True)
+t_full = kernel_ms(full)
+print(f'unsharded: {t_full:.3f} ms')
+for world in (2, 4, 8):
+    for tile in tiles:
+        ms, work = [], []
+        ren = ovr.create_renderer('hip')
+        for rank in range(world):
+            _setup(ovr, ren, vol, n, size, 2, accumulate=True, shard=(rank, world, tile, tile)) if rank == 0 else (ren.set_image_shard(rank, world, tile, tile), ren.commit())
+            ms.append(kernel_ms(ren))
+            st = ren.stats()
+            work.append(st.samples + st.shadow_samples)
+        ren.close()
+        ms, work = np.array(ms), np.array(work, float)
+        print(f'world {world} tile {tile:3d}: ms max {ms.max():.3f} mean {ms.mean():.3f} sum {ms.sum():.3f}  eff(render only) {t_full / (world * ms.max()):.3f}'
+              f'  work max/mean {work.max() / work.mean():.3f}  ms: ' + ' '.join(f'{m:.2f}' for m in ms))
+
+print('phases (march / shade / composite+reduce / total kernel ms), tile 16:')
+for world in (1, 2, 4, 8):
+    ren = ovr.create_renderer('hip')
+    _setup(ovr, ren, vol, n, size, 2, accumulate=True, shard=(0, world, 16, 16))
+    rows = []
+    for _ in range(6):
+        ren.render()
+        st = ren.stats()
+        rows.append((st.kernel_ms, st.march_ms, st.shade_ms, st.composite_ms, st.render_ms))
+    k, m, s, c, r = min(rows)
+    print(f'world {world}: march {m:.3f} shade {s:.3f} composite {c:.3f} kernel {k:.3f} blocking render() {r:.3f}  samples {st.samples} shadow {st.shadow_samples} chunks {st.pool_chunks}')
+    ren.close()
