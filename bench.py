@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--tf", default=None, choices=["sparse", "dense", "bumps"])
     ap.add_argument("--shading", type=int, default=None, choices=[0, 1, 2])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--tile", type=int, default=16, help="image-shard tile size in pixels (16: best balance over 8 ranks, tools/shard_balance.py)")
     ap.add_argument("--skip-empty", action="store_true", help="enable macrocell empty-space skipping (not the headline: fewer samples are fetched)")
     args = ap.parse_args()
 
@@ -168,8 +168,8 @@ def main():
         if world == 1:
             ren.render()          # blocking, like the reference's render() (optix7/device.cpp:35-43)
         else:
-            # one frame = march/shade/composite of this rank's tiles, then the gather of all tiles to rank 0; everything is
-            # ordered on one stream, the host waits once per frame
+            # one frame = march/shade/composite of this rank's tiles, then the gather of all tiles to rank 0.  The gather of
+            # frame i runs on its own stream while frame i+1 renders (tiles.TileGather); the host waits once per frame
             ren.render_async()
             gatherer.run()
             ren.sync()
@@ -193,6 +193,8 @@ def main():
         phase_ms[1] += st.shade_ms
         phase_ms[2] += st.composite_ms
         last_stats = st
+    if gatherer is not None:
+        gatherer.flush()   # the last frame's tiles reach rank 0's frame inside the timed region
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -169,6 +169,10 @@ int ovr_hip_owned_tiles(const ovr_hip_renderer* r, int32_t rank, int32_t* n_tile
 int ovr_hip_pack_tiles(ovr_hip_renderer* r, float* dst_device, size_t dst_bytes);
 int ovr_hip_unpack_tiles(ovr_hip_renderer* r, int32_t src_rank, const float* src_device, size_t src_bytes,
                          float* frame_device, size_t frame_bytes);
+/* all ranks' payloads in one launch: rank k's payload starts at src_device + k * rank_stride_bytes (the receive
+ * buffer of the gather as one allocation); rank_stride_bytes is a multiple of 16 and >= the largest payload */
+int ovr_hip_unpack_all_tiles(ovr_hip_renderer* r, const float* src_device, size_t rank_stride_bytes, size_t src_bytes,
+                             float* frame_device, size_t frame_bytes);
 
 /* stand-alone pieces of the path, exposed for known-answer tests through the same ABI (device buffers) */
 /* ovr/common/generate_mask.cu:100-120: compacted (x,y) list for this frame; returns the int32 count in *n_out */

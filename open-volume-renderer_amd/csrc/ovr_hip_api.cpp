@@ -1054,7 +1054,23 @@ int ovr_hip_unpack_tiles(ovr_hip_renderer* r, int32_t src_rank, const float* src
   const size_t need = (size_t)count_owned_tiles(W, H, s.tw, s.th, src_rank, s.world) * s.tw * s.th * 4 * sizeof(float);
   if (src_bytes < need) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_unpack_tiles: source too small");
   if (frame_bytes < (size_t)W * H * 4 * sizeof(float)) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_unpack_tiles: frame too small");
-  HIP_TRY(launch_unpack_tiles(src, frame, W, H, s.tw, s.th, src_rank, s.world, r->stream()));
+  HIP_TRY(launch_unpack_tiles(src, frame, W, H, s.tw, s.th, src_rank, s.world, 0, r->stream()));
+  return 0;
+}
+
+int ovr_hip_unpack_all_tiles(ovr_hip_renderer* r, const float* src, size_t rank_stride_bytes, size_t src_bytes, float* frame, size_t frame_bytes)
+{
+  if (!r || !src || !frame) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_unpack_all_tiles: null argument");
+  if (int e = set_device(r)) return e;
+  const ShardP& s = r->shard.current;
+  const int W = r->fbsize.current.w, H = r->fbsize.current.h;
+  size_t need = 0;
+  for (int k = 0; k < s.world; ++k)
+    need = std::max(need, (size_t)count_owned_tiles(W, H, s.tw, s.th, k, s.world) * s.tw * s.th * 4 * sizeof(float));
+  if (rank_stride_bytes % 16 != 0 || rank_stride_bytes < need) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_unpack_all_tiles: rank stride too small or not a multiple of 16");
+  if (src_bytes < rank_stride_bytes * (size_t)(s.world - 1) + need) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_unpack_all_tiles: source too small");
+  if (frame_bytes < (size_t)W * H * 4 * sizeof(float)) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_unpack_all_tiles: frame too small");
+  HIP_TRY(launch_unpack_tiles(src, frame, W, H, s.tw, s.th, -1, s.world, rank_stride_bytes / sizeof(float), r->stream()));
   return 0;
 }
 

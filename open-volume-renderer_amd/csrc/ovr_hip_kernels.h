@@ -133,8 +133,9 @@ hipError_t launch_macrocell_majorants(const float* minmax, unsigned int count, c
 // tile pack/unpack for the RCCL gather payload
 hipError_t launch_pack_tiles(const float* frame, float* dst, int width, int height, int tile_w, int tile_h, int rank, int world,
                              hipStream_t stream);
+// rank >= 0: scatter that rank's payload; rank < 0: scatter all ranks' payloads, rank r's at src + r * rank_stride_floats
 hipError_t launch_unpack_tiles(const float* src, float* frame, int width, int height, int tile_w, int tile_h, int rank, int world,
-                               hipStream_t stream);
+                               size_t rank_stride_floats, hipStream_t stream);
 int count_owned_tiles(int width, int height, int tile_w, int tile_h, int rank, int world);
 
 } // namespace ovrhip

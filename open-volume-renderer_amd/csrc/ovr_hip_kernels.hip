@@ -1694,21 +1694,30 @@ int count_owned_tiles(int width, int height, int tw, int th, int rank, int world
   return n;
 }
 
+// slot of tile (tx, ty) in its owner's payload.  `world` consecutive tile rows hold every column exactly once per rank, so
+// a rank owns tiles_x tiles per full period of rows; only the rows of the last, partial period are summed
+__host__ __device__ inline int tile_slot(int tiles_x, int tx, int ty, int rank, int world)
+{
+  int slot = (ty / world) * tiles_x;
+  for (int r = ty - ty % world; r < ty; ++r) slot += owned_in_row(tiles_x, r, rank, world);
+  const int first = ((rank - ty) % world + world) % world;
+  return slot + (tx - first) / world;
+}
+
+// one thread per frame pixel.  PACK: frame -> this rank's payload (pixels of foreign tiles exit).  !PACK: payload -> frame;
+// rank >= 0 scatters that rank's payload, rank < 0 scatters ALL ranks' payloads, laid out `rank_stride` float4 apart
 template <bool PACK>
 __global__ __launch_bounds__(256) void tiles_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int width, int height,
-                                                   int tw, int th, int rank, int world)
+                                                   int tw, int th, int rank, int world, size_t rank_stride)
 {
-  // one thread per frame pixel; pixels of foreign tiles exit
   const int ix = blockIdx.x * 64 + (threadIdx.x & 63), iy = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (ix >= width || iy >= height) return;
   const int tx = ix / tw, ty = iy / th;
-  if ((tx + ty) % world != rank) return;
+  const int owner = (tx + ty) % world;
+  if (rank >= 0 && owner != rank) return;
   const int tiles_x = (width + tw - 1) / tw;
-  int slot = 0;
-  for (int r = 0; r < ty; ++r) slot += owned_in_row(tiles_x, r, rank, world);
-  const int first = ((rank - ty) % world + world) % world;
-  slot += (tx - first) / world;
-  const size_t pi = (size_t)slot * tw * th + (size_t)(iy - ty * th) * tw + (size_t)(ix - tx * tw);
+  const int slot = tile_slot(tiles_x, tx, ty, owner, world);
+  const size_t pi = (size_t)slot * tw * th + (size_t)(iy - ty * th) * tw + (size_t)(ix - tx * tw) + (rank < 0 ? (size_t)owner * rank_stride : 0);
   const size_t fi = (size_t)iy * width + ix;
   if (PACK) dst[pi] = src[fi];
   else dst[fi] = src[pi];
@@ -1717,13 +1726,15 @@ __global__ __launch_bounds__(256) void tiles_kernel(const float4* __restrict__ s
 hipError_t launch_pack_tiles(const float* frame, float* dst, int width, int height, int tw, int th, int rank, int world, hipStream_t stream)
 {
   dim3 grid((unsigned)((width + 63) / 64), (unsigned)((height + 3) / 4));
-  hipLaunchKernelGGL((tiles_kernel<true>), grid, dim3(256), 0, stream, (const float4*)frame, (float4*)dst, width, height, tw, th, rank, world);
+  hipLaunchKernelGGL((tiles_kernel<true>), grid, dim3(256), 0, stream, (const float4*)frame, (float4*)dst, width, height, tw, th, rank, world, (size_t)0);
   return hipGetLastError();
 }
-hipError_t launch_unpack_tiles(const float* src, float* frame, int width, int height, int tw, int th, int rank, int world, hipStream_t stream)
+hipError_t launch_unpack_tiles(const float* src, float* frame, int width, int height, int tw, int th, int rank, int world, size_t rank_stride_floats,
+                               hipStream_t stream)
 {
   dim3 grid((unsigned)((width + 63) / 64), (unsigned)((height + 3) / 4));
-  hipLaunchKernelGGL((tiles_kernel<false>), grid, dim3(256), 0, stream, (const float4*)src, (float4*)frame, width, height, tw, th, rank, world);
+  hipLaunchKernelGGL((tiles_kernel<false>), grid, dim3(256), 0, stream, (const float4*)src, (float4*)frame, width, height, tw, th, rank, world,
+                     rank_stride_floats / 4);
   return hipGetLastError();
 }
 

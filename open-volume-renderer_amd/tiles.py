@@ -69,33 +69,73 @@ def gather_frame(local_payload, width, height, tile_w, tile_h, rank, world, unpa
 
 
 class TileGather:
-    """Per-frame gather of a sharded frame with no host synchronisation inside the frame: the renderer is put on a torch stream,
-    so pack -> gather (RCCL) -> unpack are ordered by that one stream; the caller synchronises once per frame (ren.sync())."""
+    """Per-frame gather of a sharded frame, pipelined over two HIP streams and with no host synchronisation of its own.
+
+    The renderer is put on `render_stream`; the collective runs on `comm_stream`:
+
+        render_stream:  render(i)  pack(i)              wait G(i-1)  unpack(i-1)   render(i+1)  pack(i+1)  wait G(i) ...
+        comm_stream:               wait P(i)  gather(i) -> G(i)                                wait P(i+1)  gather(i+1) ...
+
+    so the gather of frame i (RCCL over xGMI) overlaps the rendering of frame i+1 - payloads and receive buffers are
+    double-buffered - and rank `dst` scatters frame i's tiles one call later.  Call `run()` after every
+    `ren.render_async()`, `flush()` after the last frame; the caller's `ren.sync()` is the only host wait per frame.
+    The reference keeps two framebuffer sets for the same reason (`swap`, device_impl.cpp:102-111)."""
 
     def __init__(self, ren, width, height, tile, rank, world, device, dst=0):
         import ctypes as C
         import torch
         self.C, self.torch = C, torch
         self.ren, self.rank, self.world, self.dst = ren, rank, world, dst
-        self.stream = torch.cuda.Stream(device=device)
-        ren.set_stream(self.stream.cuda_stream)
+        self.render_stream = torch.cuda.Stream(device=device)
+        self.comm_stream = torch.cuda.Stream(device=device)
+        self.stream = self.render_stream
+        ren.set_stream(self.render_stream.cuda_stream)
         slots = max_owned_tiles(width, height, tile, tile, world)
-        with torch.cuda.stream(self.stream):
-            self.payload = torch.zeros((slots, tile, tile, 4), dtype=torch.float32, device=device)
-            self.bufs = [torch.zeros_like(self.payload) for _ in range(world)] if rank == dst else None
-            self.frame = torch.zeros((height, width, 4), dtype=torch.float32, device=device) if rank == dst else None
-        self.stream.synchronize()
+        root = rank == dst
+        with torch.cuda.stream(self.render_stream):
+            self.payload = [torch.zeros((slots, tile, tile, 4), dtype=torch.float32, device=device) for _ in range(2)]
+            # receive side: one allocation per buffer set, rank k's payload at [k] - a single kernel scatters all of them
+            self.recv = [torch.zeros((world,) + tuple(self.payload[0].shape), dtype=torch.float32, device=device) for _ in range(2)] if root else [None, None]
+            self.bufs = [[r[k] for k in range(world)] for r in self.recv] if root else [None, None]
+            self.frame = torch.zeros((height, width, 4), dtype=torch.float32, device=device) if root else None
+        for t in self.payload + [r for r in self.recv if r is not None]:
+            t.record_stream(self.comm_stream)   # allocated on one stream, used on both
+        self.packed = [torch.cuda.Event() for _ in range(2)]
+        self.gathered = [torch.cuda.Event() for _ in range(2)]
+        self.index = 0
+        self.outstanding = None   # buffer whose gather was enqueued and whose tiles are not scattered yet
+        self.render_stream.synchronize()
+
+    def _scatter_outstanding(self):
+        from . import _lib as L
+        C, ren, b = self.C, self.ren, self.outstanding
+        if b is None:
+            return
+        self.render_stream.wait_event(self.gathered[b])   # also frees payload[b] for the next pack into it
+        if self.rank == self.dst:
+            with self.torch.cuda.stream(self.render_stream):
+                recv = self.recv[b]
+                L.check(ren._lib.ovr_hip_unpack_all_tiles(ren._h, C.c_void_p(recv.data_ptr()), recv[0].numel() * 4, recv.numel() * 4,
+                                                           C.c_void_p(self.frame.data_ptr()), self.frame.numel() * 4))
+        self.outstanding = None
 
     def run(self):
-        """enqueue pack, gather and (on dst) unpack behind the frame that was just enqueued with ren.render_async()"""
+        """enqueue pack + gather of the frame just enqueued with ren.render_async(), and the scatter of the frame before it"""
         import torch.distributed as dist
         from . import _lib as L
-        C, ren = self.C, self.ren
-        with self.torch.cuda.stream(self.stream):
-            L.check(ren._lib.ovr_hip_pack_tiles(ren._h, C.c_void_p(self.payload.data_ptr()), self.payload.numel() * 4))
-            dist.gather(self.payload, gather_list=self.bufs, dst=self.dst)
-            if self.rank == self.dst:
-                for src in range(self.world):
-                    b = self.bufs[src]
-                    L.check(ren._lib.ovr_hip_unpack_tiles(ren._h, src, C.c_void_p(b.data_ptr()), b.numel() * 4,
-                                                           C.c_void_p(self.frame.data_ptr()), self.frame.numel() * 4))
+        C, ren, torch = self.C, self.ren, self.torch
+        b = self.index & 1
+        with torch.cuda.stream(self.render_stream):
+            L.check(ren._lib.ovr_hip_pack_tiles(ren._h, C.c_void_p(self.payload[b].data_ptr()), self.payload[b].numel() * 4))
+            self.packed[b].record(self.render_stream)
+        self._scatter_outstanding()
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(self.packed[b])
+            dist.gather(self.payload[b], gather_list=self.bufs[b], dst=self.dst)
+            self.gathered[b].record(self.comm_stream)
+        self.outstanding = b
+        self.index += 1
+
+    def flush(self):
+        """scatter the last frame's tiles (enqueued on the renderer's stream; ren.sync() or a device sync completes it)"""
+        self._scatter_outstanding()
