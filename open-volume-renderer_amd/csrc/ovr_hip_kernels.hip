@@ -1076,15 +1076,32 @@ __global__ __launch_bounds__(kBlock) void composite_kernel(const RayMarchParams 
     alpha = st.x; first = __float_as_uint(st.y); pend = __float_as_int(st.z);
   }
   f3 color = mk3(0, 0, 0), gradient = mk3(0, 0, 0);
+  // The tile's chunks come in runs of kRun consecutive, kRun-aligned pool slots (the march reserves them that way), so
+  // inside a run the next chunk is c + 1 and only the run-to-run link (chunk_next of the run's last slot) is chased - it
+  // is fetched when the run is entered, a whole run ahead of its use.  The next chunk's requests are loaded before the
+  // current ones are applied, so the walk no longer pays two dependent memory latencies per chunk.
   const unsigned int total = Q.tile_count[tile];
-  int c = Q.tile_first[tile];
-  for (unsigned int base = 0; base < total; base += 64u) {
-    const unsigned int n = min(total - base, 64u);
+  auto load_chunk = [&](int c, unsigned int n) {
     ShadeReq r;
     r.px = r.py = r.pz = r.s = r.v = r.tr = r.a = 0.f; r.next = 0;
     if ((unsigned int)lane < n) r = Q.reqs[(size_t)c * 64 + lane];
-    const int c_next = Q.chunk_next[c];
+    return r;
+  };
+  int c = total > 0u ? Q.tile_first[tile] : 0;
+  int link = total > 0u ? Q.chunk_next[c | (kRun - 1)] : 0;
+  ShadeReq r = load_chunk(c, min(total, 64u));
+  for (unsigned int base = 0; base < total; base += 64u) {
+    const unsigned int n = min(total - base, 64u);
+    const bool more = base + 64u < total;
+    const bool run_end = (c & (kRun - 1)) == kRun - 1;
+    const int c_next = run_end ? link : c + 1;
+    ShadeReq r_next = r;
+    if (more) {
+      r_next = load_chunk(c_next, min(total - base - 64u, 64u));
+      if (run_end) link = Q.chunk_next[c_next | (kRun - 1)];
+    }
     apply_batch(r, base, n, lane, pend, first, color, gradient);
+    r = r_next;
     c = c_next;
   }
   if (active) {
