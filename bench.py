@@ -30,6 +30,10 @@ CONFIGS = {
                 workload="1024^3 f32 volume, 1920x1080, gradient shading (no shadow march) + ERT"),
     "c4": dict(n=2048, dtype="uint16", width=1920, height=1080, shading=2, tf="sparse", cam="oblique", rate=1.0, spp=1,
                workload="2048^3 u16 volume (native u16 in HBM), 1920x1080, gradient shading + shadow march + ERT"),
+    "c1": dict(n=256, dtype="uint8", width=512, height=512, shading=2, tf="sparse", cam="oblique", rate=1.0, spp=1,
+               workload="256^3 u8 volume, 512x512 (the sample-scene shape of BASELINE C1; renderbatch defaults)"),
+    "c5": dict(n=1024, dtype="float32", width=3840, height=2160, shading=2, tf="sparse", cam="oblique", rate=1.0, spp=4,
+               workload="1024^3 f32 volume, 3840x2160, 4 jittered samples per pixel per frame, progressive accumulation (16 frames = 64 spp)"),
     "tiny": dict(n=64, dtype="float32", width=256, height=256, shading=2, tf="sparse", cam="oblique", rate=1.0, spp=1,
                  workload="64^3 f32 volume, 256x256 (plumbing check, not a benchmark)"),
 }
@@ -93,6 +97,7 @@ def main():
     ap.add_argument("--shading", type=int, default=None, choices=[0, 1, 2])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile", type=int, default=16, help="image-shard tile size in pixels (16: best balance over 8 ranks, tools/shard_balance.py)")
+    ap.add_argument("--no-skip-leg", action="store_true", help="do not time the extra leg with empty-space skipping (N = 1 only)")
     ap.add_argument("--skip-empty", action="store_true", help="enable macrocell empty-space skipping (not the headline: fewer samples are fetched)")
     args = ap.parse_args()
 
@@ -200,6 +205,36 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
 
+    # extra leg (N = 1): the same frames with empty-space skipping over the reference's macrocell grids; reported
+    # beside the headline, never as `value`.  Same number of accumulated frames after a reset, so the frames must be equal bit for bit
+    skip_leg = None
+    if world == 1 and not args.skip_empty and not args.no_skip_leg:
+        fb = ovr.FrameBufferData()
+        ren.set_camera(*cam)   # any camera commit resets the accumulation (device_impl.cpp:125-144)
+        ren.commit()
+        for _ in range(args.warmup + args.steps):
+            ren.render()
+        ren.mapframe(fb, device=True)
+        plain = fb.rgba.data().clone()
+        ren.set_empty_space_skipping(True)
+        ren.set_camera(*cam)
+        ren.commit()
+        for _ in range(args.warmup):
+            ren.render()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ren.render()
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+        ren.mapframe(fb, device=True)
+        st1 = ren.stats()
+        skip_leg = {"fps": args.steps / dt1, "ms_per_step": dt1 / args.steps * 1e3, "frames_bit_identical": bool(torch.equal(plain, fb.rgba.data())),
+                    "samples_fetched_per_frame": int(st1.samples), "samples_skipped_per_frame": int(st1.skipped_samples),
+                    "shadow_samples_skipped_per_frame": int(st1.skipped_shadow_samples)}
+        ren.set_empty_space_skipping(False)
+        ren.commit()
+
     # max over ranks of the elapsed time, sum over ranks of the work
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -227,15 +262,38 @@ def main():
         nbytes = nominal_bytes(cfg, per_launch, pixels_per_launch)
         achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         # measured HBM traffic (rocprofv3 PMC) of this exact configuration, if a profile of it is committed under profiles/
-        traffic = None
+        traffic, traffic_by_kernel = None, {}
         try:
             with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
                 key = f"{args.config}|{cfg['cam']}|{cfg['tf']}|{cfg['shading']}|{world}"
                 ent = json.load(f).get(key)
                 if ent and not args.skip_empty:
                     traffic = ent["traffic_bytes_per_launch"]
+                    for kname, kib in ent.get("fetch_size_kib", {}).items():
+                        traffic_by_kernel[kname] = (2 * kib + ent.get("write_size_kib", {}).get(kname, 0)) * 1024
         except OSError:
             pass
+        # per kernel: algorithmic bytes of the taps that kernel executes / its own mean launch duration (HIP events around
+        # each kernel, recorded inside libovr_hip.so on the renderer's stream; profiles/r01_c3/kernel_stats.csv agrees)
+        tap = 8 * VOXEL_BYTES[cfg["dtype"]]
+        fb_bytes = pixels_per_launch * (16 + 32 + 12)
+        pooled = last_stats.pipeline == 2
+        ph = [p / steps for p in phase_ms]
+        kern = {}
+        if pooled and cfg["spp"] > 1:
+            # one march/shade/composite pass per sample-per-pixel generation: the events bracket the whole sequence
+            parts = [("raymarch pipeline (%d generations of march -> shade -> composite)" % cfg["spp"], abytes, k_ms)]
+        elif pooled:
+            parts = [("raymarch_kernel", per_launch["samples"] * tap, ph[0]),
+                     ("shade_pool_kernel", (3 * per_launch["shaded_samples"] + per_launch["shadow_samples"]) * tap, ph[1]),
+                     ("composite_kernel", fb_bytes, ph[2])]
+        else:
+            parts = [("raymarch_kernel", abytes, ph[0])]
+        for kname, kb, kms in parts:
+            if kms > 0:
+                kern[kname] = {"ms": kms, "algorithmic_bytes_per_launch": kb, "achieved": kb / (kms * 1e-3) / 1e9,
+                               "frac": kb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_by_kernel.get(kname)}
+        dom = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
         out = {
             "metric": "Msamples/s (primary ray-march samples after ERT); fps alongside",
             "value": tot["samples"] / dt / 1e6,
@@ -255,13 +313,20 @@ def main():
                        "spp": cfg["spp"], "shading": ["none", "gradient", "gradient+shadow"][cfg["shading"]],
                        "frame_accumulation": True, "empty_space_skipping": bool(args.skip_empty), "parallelism": f"image tiles {args.tile}x{args.tile} over {world} rank(s)"},
             "per_frame": {k: per_step[k] for k in sorted(per_step)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "raymarch pipeline (march + shade + composite)" if last_stats.pipeline == 2 else "raymarch_kernel",
-                         "kernel_ms": k_ms, "phase_ms_rank0": {"march": phase_ms[0] / steps, "shade": phase_ms[1] / steps, "composite": phase_ms[2] / steps},
-                         "pool_chunks": int(last_stats.pool_chunks), "algorithmic_bytes_per_launch": abytes,
-                         "nominal_frac_survey_F4": (nbytes / (k_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if k_ms > 0 else 0.0},
+            # the dominant kernel of the frame (longest mean launch); the whole pipeline and the other kernels beside it
+            "roofline": {"bound": "hbm", "achieved": kern[dom]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": kern[dom]["frac"], "traffic": kern[dom]["traffic"],
+                         "kernel": dom + ("" if "pipeline" in dom else " (pooled pipeline: march -> shade -> composite)" if pooled else " (in-place pipeline)"),
+                         "kernel_ms": kern[dom]["ms"], "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes_per_launch"],
+                         "kernels": kern,
+                         "pipeline": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms,
+                                      "algorithmic_bytes_per_launch": abytes,
+                                      "nominal_frac_survey_F4": (nbytes / (k_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if k_ms > 0 else 0.0},
+                         "phase_ms_rank0": {"march": ph[0], "shade": ph[1], "composite": ph[2]},
+                         "pool_chunks": int(last_stats.pool_chunks)},
         }
+        if skip_leg is not None:
+            out["with_empty_space_skipping"] = skip_leg
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, vol_host, colors, alphas, vr, cam)
         print(json.dumps(out))
