@@ -140,3 +140,47 @@ def test_c2_and_c4_sizes(ovr, oracle, hip_renderer_factory):
             assert ren.stats().shaded_samples > 0
             ren.close()
         assert np.array_equal(frames[0], frames[1]) and np.isfinite(frames[0]).all()
+
+
+def test_c5_size_spp_pipelines(ovr, oracle, hip_renderer_factory, c3_volume):
+    """C5's frame size (3840x2160) with jittered samples per pixel and progressive accumulation: the pooled pipeline (one
+    march/shade/composite pass per generation) equals the in-place pipeline bit for bit, counters included"""
+    n, size = 1024, (3840, 2160)
+    frames, stats = [], []
+    for pipeline in (2, 1):
+        ren = hip_renderer_factory()
+        ren.set_sample_per_pixel(2)
+        _setup(ovr, ren, c3_volume, n, size, 2, pipeline=pipeline, accumulate=True)
+        ren.render()
+        ren.render()
+        frames.append(_frame(ovr, ren))
+        stats.append(ren.stats())
+        ren.close()
+    assert np.array_equal(frames[0], frames[1])
+    assert np.isfinite(frames[0]).all() and frames[0][..., 3].max() <= 1.0
+    a, b = stats
+    assert (a.rays, a.samples, a.shaded_samples, a.shadow_samples) == (b.rays, b.samples, b.shaded_samples, b.shadow_samples)
+    assert a.rays == 2 * size[0] * size[1] and a.frame_index == 2
+
+
+def test_c1_full_frame_vs_oracle(ovr, oracle, hip_renderer_factory):
+    """C1's shape (256^3 uint8, 512x512 - renderbatch's default frame) in full: every pixel against the CPU oracle, reference
+    shading incl. the shadow march; sample counters equal exactly"""
+    import torch
+    n, size = 256, (512, 512)
+    vol = ovr.synth.make_volume_torch(n, torch.device("cuda", 0), "uint8")
+    ren = _setup(ovr, hip_renderer_factory(), vol, n, size, 2, dtype=np.uint8)
+    ren.render()
+    got, st = _frame(ovr, ren), ren.stats()
+    colors, alphas, vr = ovr.synth.make_tfn("sparse", 1024, np.uint8)
+    cam = ovr.synth.make_camera("oblique", n)
+    sc = oracle.OracleScene(vol.cpu().numpy(), colors, alphas, vr, cam, size[0], size[1], shading=oracle.SHADE_FULL)
+    ref, _, cnt = sc.render()
+    # the oracle marches a shadow ray for every sample like the reference; those of samples with opacity > 0 are the GPU's.
+    # Primary counts are exact; a shadow ray may end one iteration apart when its alpha sits on the 0.9999 threshold (the
+    # GPU's v_exp(y * v_log(x)) for __powf differs from the oracle's powf in the last bit): 1 of 5.67 M here
+    assert (st.samples, st.shaded_samples) == (cnt.samples, cnt.shaded_samples)
+    assert abs(int(st.shadow_samples) - int(cnt.shadow_samples_visible)) <= 8
+    d8 = np.abs(oracle.rgba8(got, flip=False).astype(int) - oracle.rgba8(ref, flip=False).astype(int))
+    assert d8.max() <= 1
+    assert np.abs(got - ref).max() <= 2e-4
