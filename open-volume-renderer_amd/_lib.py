@@ -93,6 +93,13 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found - build it with `make -C open-volume-renderer_amd/csrc` "
             "(or __graft_entry__.build()); this backend has no CPU fallback")
+    # torch ships its own copy of the HIP runtime: if libovr_hip.so brings up /opt/rocm's first, a later torch.cuda
+    # initialisation in the same process finds "No HIP GPUs" (seen on the GPU box).  Loading torch's libraries first makes
+    # both share one runtime; hosts without torch (the C++ plugin) have only one runtime anyway.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         try:

@@ -18,6 +18,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 #include <algorithm>
 
 namespace ovrhip {
@@ -137,6 +138,7 @@ struct VolConsts {
   // per-axis offset tables in LDS (AM 0 / 1): tx[x] = X(x), ty[y] = Y(y), tz[z] = Z(z), bytes (AM 0) or elements (AM 1);
   // ty / tz hold one extra entry equal to the last one, so (i, i + 1) is clamp-to-edge without a select
   const unsigned int *tab_x, *tab_y, *tab_z;
+  const unsigned long long* tab_z64; // AM 2: z offsets need 64 bits (>= 2^32 stored voxels)
   int nx1, ny1, nz1; // n - 1
   const float* majorant; // per-macrocell max TF opacity (null: empty-space skipping off)
   int mcx1, mcy1, mcz1;  // macrocell grid dims - 1
@@ -193,12 +195,21 @@ __device__ __forceinline__ void tap_loads(const VolConsts& vc, Tap& t)
   const int x0 = t.x0, y0 = t.y0, z0 = t.z0;
   const int y1 = min(y0 + 1, vc.ny1), z1 = min(z0 + 1, vc.nz1);
   P p00, p10, p01, p11;
-  if (AM == 2) { // > 2^32 elements: 64-bit element offsets, computed arithmetically
+  if (AM == 3) { // > 2^32 elements and axis tables too large for LDS: 64-bit element offsets, computed arithmetically
     const unsigned ox = M::X((unsigned)x0);
     const unsigned o0 = ox + M::Y((unsigned)y0, vc.macro_y), o1 = ox + M::Y((unsigned)y1, vc.macro_y);
     const T* base = static_cast<const T*>(vc.data);
     const unsigned long long oz0 = (unsigned long long)M::Zlo((unsigned)z0) + (unsigned long long)((unsigned)z0 >> 5) * vc.macro_z;
     const unsigned long long oz1 = (unsigned long long)M::Zlo((unsigned)z1) + (unsigned long long)((unsigned)z1 >> 5) * vc.macro_z;
+    p00 = *reinterpret_cast<const P*>(base + (oz0 + o0)); p10 = *reinterpret_cast<const P*>(base + (oz0 + o1));
+    p01 = *reinterpret_cast<const P*>(base + (oz1 + o0)); p11 = *reinterpret_cast<const P*>(base + (oz1 + o1));
+  }
+  else if (AM == 2) { // > 2^32 elements: x and y offsets (inside one macro layer) stay 32-bit, the z table is 64-bit
+    (void)y1; (void)z1;
+    const unsigned ox = vc.tab_x[x0];
+    const unsigned o0 = ox + vc.tab_y[y0], o1 = ox + vc.tab_y[y0 + 1];
+    const unsigned long long oz0 = vc.tab_z64[z0], oz1 = vc.tab_z64[z0 + 1];
+    const T* base = static_cast<const T*>(vc.data);
     p00 = *reinterpret_cast<const P*>(base + (oz0 + o0)); p10 = *reinterpret_cast<const P*>(base + (oz0 + o1));
     p01 = *reinterpret_cast<const P*>(base + (oz1 + o0)); p11 = *reinterpret_cast<const P*>(base + (oz1 + o1));
   }
@@ -453,7 +464,22 @@ template <int VT, int AM>
 __device__ __forceinline__ size_t stage_tables(const RayMarchParams& P, unsigned char* base, VolConsts& vc)
 {
   typedef BrickMap<VT> M;
-  if (AM == 2) { vc.tab_x = vc.tab_y = vc.tab_z = nullptr; return 0; }
+  vc.tab_x = vc.tab_y = vc.tab_z = nullptr;
+  vc.tab_z64 = nullptr;
+  if (AM == 3) return 0;
+  if (AM == 2) { // [z: nz + 1 x u64][x: nx x u32][y: ny + 1 x u32], element offsets
+    unsigned long long* tz = reinterpret_cast<unsigned long long*>(base);
+    unsigned int* tx = reinterpret_cast<unsigned int*>(tz + P.vol.nz + 1);
+    unsigned int* ty = tx + P.vol.nx;
+    for (int i = threadIdx.x; i < P.vol.nx; i += kBlock) tx[i] = M::X((unsigned)i);
+    for (int i = threadIdx.x; i <= P.vol.ny; i += kBlock) ty[i] = M::Y((unsigned)min(i, P.vol.ny - 1), vc.macro_y);
+    for (int i = threadIdx.x; i <= P.vol.nz; i += kBlock) {
+      const unsigned z = (unsigned)min(i, P.vol.nz - 1);
+      tz[i] = (unsigned long long)M::Zlo(z) + (unsigned long long)(z >> 5) * vc.macro_z;
+    }
+    vc.tab_x = tx; vc.tab_y = ty; vc.tab_z64 = tz;
+    return (size_t)(P.vol.nz + 1) * sizeof(unsigned long long) + (size_t)(P.vol.nx + P.vol.ny + 1) * sizeof(unsigned int);
+  }
   unsigned int* tx = reinterpret_cast<unsigned int*>(base);
   unsigned int* ty = tx + P.vol.nx;
   unsigned int* tz = ty + P.vol.ny + 1;
@@ -469,7 +495,9 @@ __device__ __forceinline__ size_t stage_tables(const RayMarchParams& P, unsigned
 }
 __host__ inline size_t table_lds_bytes(const RayMarchParams& p, int am)
 {
-  return am == 2 ? 0 : (((size_t)(p.vol.nx + p.vol.ny + p.vol.nz + 2) * sizeof(unsigned int) + 15) & ~(size_t)15);
+  if (am == 3) return 0;
+  if (am == 2) return ((size_t)(p.vol.nz + 1) * sizeof(unsigned long long) + (size_t)(p.vol.nx + p.vol.ny + 1) * sizeof(unsigned int) + 15) & ~(size_t)15;
+  return ((size_t)(p.vol.nx + p.vol.ny + p.vol.nz + 2) * sizeof(unsigned int) + 15) & ~(size_t)15;
 }
 
 // stage the transfer function in LDS (all threads of the workgroup); color may be skipped by alpha-only kernels
@@ -710,6 +738,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
     else {
       tf = TfConsts{};
       vc.tab_x = vc.tab_y = vc.tab_z = nullptr;
+      vc.tab_z64 = nullptr;
     }
   }
   const PoolDesc& Q = P.pool;
@@ -1326,10 +1355,17 @@ template <int VT, int SHADE>
 static hipError_t launch_vs(const RayMarchParams& p, hipStream_t stream, const hipEvent_t* ev)
 {
   // addressing mode: 0 = 32-bit byte offsets (volume <= 4 GiB; largest byte offset = bytes - sizeof(voxel)),
-  //                  1 = 32-bit element offsets (< 2^32 stored voxels), 2 = 64-bit
-  if (p.vol.bytes <= 0x100000000ull) return launch_vsb<VT, SHADE, 0>(p, stream, ev);
-  if (p.vol.bytes / voxel_size(p.vol.type) < 0xffffffffull) return launch_vsb<VT, SHADE, 1>(p, stream, ev);
-  return launch_vsb<VT, SHADE, 2>(p, stream, ev);
+  //                  1 = 32-bit element offsets (< 2^32 stored voxels), 2 = 64-bit z table in LDS,
+  //                  3 = 64-bit, computed (axis tables would not fit in LDS next to the queues: a dimension beyond ~8000)
+  int am = p.vol.bytes <= 0x100000000ull ? 0 : (p.vol.bytes / voxel_size(p.vol.type) < 0xffffffffull) ? 1 : 2;
+  if (const char* f = getenv("OVR_HIP_ADDRESSING")) am = std::max(am, atoi(f)); // diagnostic: a more general mode than needed (tests)
+  if (am == 2 && table_lds_bytes(p, 2) > 64 * 1024) am = 3;
+  switch (am) {
+  case 0: return launch_vsb<VT, SHADE, 0>(p, stream, ev);
+  case 1: return launch_vsb<VT, SHADE, 1>(p, stream, ev);
+  case 2: return launch_vsb<VT, SHADE, 2>(p, stream, ev);
+  default: return launch_vsb<VT, SHADE, 3>(p, stream, ev);
+  }
 }
 
 template <int VT>

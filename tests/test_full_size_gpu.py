@@ -184,3 +184,52 @@ def test_c1_full_frame_vs_oracle(ovr, oracle, hip_renderer_factory):
     d8 = np.abs(oracle.rgba8(got, flip=False).astype(int) - oracle.rgba8(ref, flip=False).astype(int))
     assert d8.max() <= 1
     assert np.abs(got - ref).max() <= 2e-4
+
+
+def test_64bit_addressing_vs_oracle(ovr, oracle, hip_renderer_factory):
+    """a volume with more than 2^32 stored voxels (2048 x 2048 x 1100 uint8: 5.3 G with the x-apron) takes the 64-bit z-table
+    addressing mode; the CPU oracle checks a subset of its tiles, both pipelines must agree bit for bit"""
+    import torch
+    dims = (2048, 2048, 1100)
+    dev = torch.device("cuda", 0)
+    z = torch.arange(dims[2], device=dev, dtype=torch.float32).view(-1, 1, 1)
+    y = torch.arange(dims[1], device=dev, dtype=torch.float32).view(1, -1, 1)
+    x = torch.arange(dims[0], device=dev, dtype=torch.float32).view(1, 1, -1)
+    # smooth blobs + a high-frequency term that depends on all three coordinates (an addressing slip must show)
+    vol = torch.empty(dims[::-1], dtype=torch.uint8, device=dev)
+    for z0 in range(0, dims[2], 100):
+        zz = z[z0:z0 + 100]
+        r2 = ((x - 1024) / 900) ** 2 + ((y - 1000) / 800) ** 2 + ((zz - 550) / 500) ** 2
+        v = 200.0 * torch.exp(-2.5 * r2) + 30.0 * torch.sin(0.37 * x + 0.23 * y + 0.41 * zz)
+        vol[z0:z0 + 100] = v.clamp_(0, 255).to(torch.uint8)
+        del r2, v
+    colors, alphas, vr = ovr.synth.make_tfn("sparse", 1024, np.uint8)
+    c = (dims[0] / 2, dims[1] / 2, dims[2] / 2)
+    cam = ((c[0] - 2600.0, c[1] + 1500.0, c[2] + 1900.0), c, (0.0, 1.0, 0.0))
+    size, tile = (640, 360), 40
+    frames = []
+    for pipeline in (2, 1):
+        ren = hip_renderer_factory()
+        ren.set_fbsize(size)
+        ren.set_shading(2)
+        ren.set_shading_pipeline(pipeline)
+        ren.set_transfer_function(colors, alphas, vr)
+        ren.init(ovr.Scene(volume=vol, transfer_function=None), ovr.Camera(*cam))
+        ren.commit()
+        ren.render()
+        frames.append(_frame(ovr, ren))
+        st = ren.stats()
+        ren.close()
+    assert np.array_equal(frames[0], frames[1]) and st.shaded_samples > 10000
+    vol_host = vol.cpu().numpy()
+    del vol
+    torch.cuda.empty_cache()
+    sc = oracle.OracleScene(vol_host, colors, alphas, vr, cam, size[0], size[1], shading=oracle.SHADE_FULL, shard=(0, 12, tile, tile))
+    ref, _, cnt = sc.render()
+    mask = np.zeros((size[1], size[0]), bool)
+    for tx, ty in ovr.tiles.owned_tiles(size[0], size[1], tile, tile, 0, 12):
+        mask[ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile] = True
+    assert cnt.samples > 1e6 and cnt.shaded_samples > 1000
+    d8 = np.abs(oracle.rgba8(frames[0], flip=False).astype(int) - oracle.rgba8(ref, flip=False).astype(int))[mask]
+    assert d8.max() <= 1
+    assert np.abs(frames[0] - ref)[mask].max() <= 2e-4

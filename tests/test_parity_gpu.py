@@ -330,3 +330,25 @@ def test_sparse_mask_tile_sizes(ovr, oracle, hip_renderer_factory, xy, size):
     ren.commit()
     for frame in (1, 63, 64, 129):
         assert np.array_equal(ren.sparse_mask(frame), oracle.sparse_mask(frame, size[0], size[1], focus[0], focus[1], focus[2], noise))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint16, np.uint8])
+def test_addressing_modes_bit_identical(ovr, oracle, hip_renderer_factory, monkeypatch, dtype):
+    """the four addressing modes of the brick fetch (32-bit byte offsets / 32-bit element offsets / 64-bit z table in LDS /
+    64-bit computed) are chosen by volume size; forced on one small volume (OVR_HIP_ADDRESSING) they must agree bit for bit, in
+    both pipelines and with skipping"""
+    case = make_case(ovr, oracle, n=40, tf="bumps", cam="oblique", size=(72, 56), shading=2, dtype=dtype)
+    frames = []
+    for am in (0, 1, 2, 3):
+        monkeypatch.setenv("OVR_HIP_ADDRESSING", str(am))
+        for pipeline, skip in ((2, False), (1, False), (2, True)):
+            ren = hip_setup(ovr, hip_renderer_factory(), case, pipeline=pipeline)
+            ren.set_empty_space_skipping(skip)
+            ren.commit()
+            ren.render()
+            frames.append(hip_frame(ovr, ren)[0].copy())
+            ren.close()
+    for f in frames[1:]:
+        assert np.array_equal(f, frames[0])
+    ref, _, _ = oracle_scene(oracle, case).render()
+    compare(oracle, frames[0], ref, name="addressing")
