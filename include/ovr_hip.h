@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OVR_HIP_ABI_VERSION 3
+#define OVR_HIP_ABI_VERSION 4
 
 /* error codes */
 #define OVR_HIP_OK 0
@@ -155,6 +155,12 @@ int ovr_hip_sync(ovr_hip_renderer* r);
  * of the same set.  rgba = W*H*4 floats, row 0 = bottom; grad = W*H*3 floats (may be NULL to skip). */
 int ovr_hip_mapframe(ovr_hip_renderer* r, int mem_kind, const float** rgba, size_t* rgba_bytes, const float** grad,
                      size_t* grad_bytes);
+/* frame output: image_to_rgba8 of the reference (ovr/common/imageio.cpp:146-181: clamp to [0,1], * 255,
+ * truncate; `flip_vertical` as renderbatch passes it, apps/main_batch.cpp save_image) applied to the CURRENT framebuffer
+ * set on the device - the host copy of a saved or displayed frame is 4 bytes per pixel instead of 16.  The pointer
+ * stays valid until the next call of this function or a framebuffer resize. */
+int ovr_hip_mapframe_rgba8(ovr_hip_renderer* r, int mem_kind, int flip_vertical, const uint32_t** rgba8, size_t* bytes);
+
 /* replaces Impl::swap (device_impl.cpp:102-111): waits for the current set's stream, flips to the other set */
 int ovr_hip_swap(ovr_hip_renderer* r);
 

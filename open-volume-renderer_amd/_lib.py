@@ -76,6 +76,7 @@ SYMBOLS = {
     "ovr_hip_owned_tiles": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_int32)]),
     "ovr_hip_pack_tiles": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
     "ovr_hip_unpack_tiles": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "ovr_hip_mapframe_rgba8": (C.c_int, [_H, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ovr_hip_unpack_all_tiles": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t]),
     "ovr_hip_sparse_mask": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]),
     "ovr_hip_tea_floats": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int64]),

@@ -135,6 +135,8 @@ struct ovr_hip_renderer {
   float* h_rgba[2] = { nullptr, nullptr };
   float* h_grad[2] = { nullptr, nullptr };
   float* d_accum = nullptr;
+  uint32_t* d_rgba8 = nullptr; // mapframe_rgba8: device and pinned host copy of the 8-bit frame
+  uint32_t* h_rgba8 = nullptr;
   float* d_spp_rgba = nullptr; // pooled pipeline, spp > 1: sums over the sample-per-pixel generations
   float* d_spp_grad = nullptr;
   size_t fb_pixels = 0;
@@ -192,6 +194,9 @@ int free_framebuffers(ovr_hip_renderer* r)
   }
   if (r->d_accum) HIP_TRY(hipFree(r->d_accum));
   r->d_accum = nullptr;
+  if (r->d_rgba8) HIP_TRY(hipFree(r->d_rgba8));
+  if (r->h_rgba8) HIP_TRY(hipHostFree(r->h_rgba8));
+  r->d_rgba8 = nullptr; r->h_rgba8 = nullptr;
   if (r->d_spp_rgba) HIP_TRY(hipFree(r->d_spp_rgba));
   if (r->d_spp_grad) HIP_TRY(hipFree(r->d_spp_grad));
   r->d_spp_rgba = r->d_spp_grad = nullptr;
@@ -982,6 +987,29 @@ int ovr_hip_mapframe(ovr_hip_renderer* r, int mem_kind, const float** rgba, size
   *rgba_bytes = n * 4 * sizeof(float);
   if (grad) *grad = r->h_grad[c];
   if (grad_bytes) *grad_bytes = n * 3 * sizeof(float);
+  return 0;
+}
+
+int ovr_hip_mapframe_rgba8(ovr_hip_renderer* r, int mem_kind, int flip_vertical, const uint32_t** rgba8, size_t* bytes)
+{
+  if (!r || !rgba8 || !bytes) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_mapframe_rgba8: null argument");
+  if (mem_kind != OVR_HIP_MEM_DEVICE && mem_kind != OVR_HIP_MEM_HOST) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_mapframe_rgba8: bad mem_kind");
+  if (int e = set_device(r)) return e;
+  if (int e = finish_frame(r)) return e;
+  const size_t n = r->fb_pixels;
+  *rgba8 = nullptr;
+  *bytes = 0;
+  if (n == 0) return 0;
+  hipStream_t st = r->stream();
+  if (!r->d_rgba8) HIP_TRY(hipMalloc((void**)&r->d_rgba8, n * sizeof(uint32_t)));
+  HIP_TRY(launch_rgba8(r->d_rgba[r->cur], r->d_rgba8, r->fbsize.current.w, r->fbsize.current.h, flip_vertical ? 1 : 0, st));
+  if (mem_kind == OVR_HIP_MEM_HOST) {
+    if (!r->h_rgba8) HIP_TRY(hipHostMalloc((void**)&r->h_rgba8, n * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(r->h_rgba8, r->d_rgba8, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  *rgba8 = mem_kind == OVR_HIP_MEM_HOST ? r->h_rgba8 : r->d_rgba8;
+  *bytes = n * sizeof(uint32_t);
   return 0;
 }
 

@@ -136,6 +136,8 @@ hipError_t launch_pack_tiles(const float* frame, float* dst, int width, int heig
 // rank >= 0: scatter that rank's payload; rank < 0: scatter all ranks' payloads, rank r's at src + r * rank_stride_floats
 hipError_t launch_unpack_tiles(const float* src, float* frame, int width, int height, int tile_w, int tile_h, int rank, int world,
                                size_t rank_stride_floats, hipStream_t stream);
+// image_to_rgba8 (imageio.cpp:146-181): RGBA32F frame -> packed RGBA8, optionally flipped vertically
+hipError_t launch_rgba8(const float* rgba, uint32_t* out, int width, int height, int flip, hipStream_t stream);
 int count_owned_tiles(int width, int height, int tile_w, int tile_h, int rank, int world);
 
 } // namespace ovrhip

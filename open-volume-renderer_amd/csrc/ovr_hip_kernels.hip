@@ -1791,4 +1791,26 @@ hipError_t launch_unpack_tiles(const float* src, float* frame, int width, int he
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// frame output: image_to_rgba8 of the reference (ovr/common/imageio.cpp:146-181, 4 channels), on the device so that the
+// host copy of a displayed / saved frame is 4 bytes per pixel instead of 16
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rgba8_kernel(const float4* __restrict__ rgba, uint32_t* __restrict__ out, int width, int height, int flip)
+{
+  const int ix = blockIdx.x * 64 + (threadIdx.x & 63), iy = blockIdx.y * 4 + (threadIdx.x >> 6); // output position
+  if (ix >= width || iy >= height) return;
+  const int sy = flip ? height - 1 - iy : iy;
+  const float4 v = rgba[(size_t)sy * width + ix];
+  // std::clamp(v, 0.f, 1.f) * 255.f, truncated (a NaN, undefined in the reference's cast, becomes 0)
+  auto q = [](float x) -> uint32_t { return (uint32_t)(((x < 0.f) ? 0.f : (1.f < x) ? 1.f : x) * 255.f); };
+  out[(size_t)iy * width + ix] = q(v.x) | (q(v.y) << 8) | (q(v.z) << 16) | (q(v.w) << 24);
+}
+hipError_t launch_rgba8(const float* rgba, uint32_t* out, int width, int height, int flip, hipStream_t stream)
+{
+  if (width <= 0 || height <= 0) return hipSuccess;
+  dim3 grid((unsigned)((width + 63) / 64), (unsigned)((height + 3) / 4));
+  hipLaunchKernelGGL(rgba8_kernel, grid, dim3(256), 0, stream, (const float4*)rgba, out, width, height, flip);
+  return hipGetLastError();
+}
+
 } // namespace ovrhip

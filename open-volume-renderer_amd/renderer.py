@@ -307,6 +307,18 @@ class DeviceHIP:
             fb.grad.set_data(a_grad, nb_grad.value, CrossDeviceBuffer.DEVICE_CPU)
         return fb
 
+    def mapframe_rgba8(self, flip_vertical=True, device=False):
+        """the current frame as packed RGBA8, converted on the GPU exactly like the reference's image_to_rgba8
+        (imageio.cpp:146-181; renderbatch saves its PNG from this, flipped).  Returns a (H, W, 4) uint8 numpy array (host) or
+        torch tensor (device=True); valid until the next call."""
+        ptr, nb = C.c_void_p(), C.c_size_t()
+        L.check(self._lib.ovr_hip_mapframe_rgba8(self._h, L.MEM_DEVICE if device else L.MEM_HOST, 1 if flip_vertical else 0, C.byref(ptr), C.byref(nb)))
+        w, h = self._fbsize
+        if device:
+            import torch
+            return torch.as_tensor(_DevicePtr(ptr.value, (h, w, 4), typestr="|u1"), device=torch.device("cuda", self.device_id))
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(h, w, 4))
+
     # ---- getters ------------------------------------------------------------------------------------------------
     @property
     def render_time(self):

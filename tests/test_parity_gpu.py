@@ -352,3 +352,20 @@ def test_addressing_modes_bit_identical(ovr, oracle, hip_renderer_factory, monke
         assert np.array_equal(f, frames[0])
     ref, _, _ = oracle_scene(oracle, case).render()
     compare(oracle, frames[0], ref, name="addressing")
+
+
+def test_mapframe_rgba8_equals_reference_conversion(ovr, oracle, hip_renderer_factory):
+    """f4 frame output on the device: ovr_hip_mapframe_rgba8 == image_to_rgba8 (the oracle's restatement is pinned bit-exactly
+    against the reference's compiled function, tests/test_oracle_vs_ref.py), flipped and not, host and device memory"""
+    case = make_case(ovr, oracle, n=32, tf="dense", cam="oblique", size=(70, 45), shading=2)
+    ren = hip_setup(ovr, hip_renderer_factory(), case)
+    ren.render()
+    rgba, _ = hip_frame(ovr, ren)
+    assert rgba.max() > 0.5
+    for flip in (True, False):
+        want = oracle.rgba8(rgba, flip=flip)
+        got = np.array(ren.mapframe_rgba8(flip_vertical=flip), copy=True)
+        assert got.shape == (45, 70, 4) and got.dtype == np.uint8
+        assert np.array_equal(got.reshape(want.shape), want)
+        dev = ren.mapframe_rgba8(flip_vertical=flip, device=True)
+        assert np.array_equal(dev.cpu().numpy().reshape(want.shape), want)
