@@ -369,3 +369,60 @@ def test_mapframe_rgba8_equals_reference_conversion(ovr, oracle, hip_renderer_fa
         assert np.array_equal(got.reshape(want.shape), want)
         dev = ren.mapframe_rgba8(flip_vertical=flip, device=True)
         assert np.array_equal(dev.cpu().numpy().reshape(want.shape), want)
+
+
+def test_state_changes_on_one_renderer(ovr, oracle, hip_renderer_factory):
+    """one renderer through the transitions an interactive app makes - camera move, resize, transfer-function edit, shading
+    and pipeline switch, shard on and off, new volume - every frame against the oracle.  Guards the commit logic
+    (device_impl.cpp:113-197) and everything cached per camera / size / shard (the workgroup schedule)."""
+    case = make_case(ovr, oracle, n=36, tf="bumps", cam="oblique", size=(88, 56), shading=2)
+    ren = hip_setup(ovr, hip_renderer_factory(), case, accumulate=True)
+
+    def check(name, frames=1, **kw):
+        for _ in range(frames):
+            ren.render()
+        ref, _, cnt = oracle_scene(oracle, case, **kw).render(frames=frames, accumulate=True)
+        got = hip_frame(ovr, ren)[0]
+        st = ren.stats()
+        assert st.frame_index == frames, name
+        assert st.samples == cnt.samples, name
+        return got, ref
+
+    compare(oracle, *check("initial", frames=2), name="initial")
+    # camera move: accumulation restarts, the schedule is re-sorted
+    case["cam"] = tuple(ovr.synth.make_camera("front", 36))
+    ren.set_camera(ovr.Camera(*case["cam"], case["fovy"]))
+    ren.commit()
+    compare(oracle, *check("camera"), name="camera")
+    # resize (odd size: partial 8x8 blocks on both edges)
+    case["size"] = (61, 83)
+    ren.set_fbsize(case["size"])
+    ren.commit()
+    compare(oracle, *check("resize", frames=2), name="resize")
+    # transfer-function edit and shading mode
+    case["colors"], case["alphas"], case["vr"] = ovr.synth.make_tfn("dense", 64)
+    case["shading"] = 1
+    ren.set_transfer_function(case["colors"], case["alphas"], case["vr"])
+    ren.set_shading(1)
+    ren.set_shading_pipeline(1)
+    ren.commit()
+    compare(oracle, *check("tfn+shading"), name="tfn+shading")
+    # shard on: only the owned tiles are drawn (the others keep what they had), then off again
+    ren.set_shading_pipeline(2)
+    ren.set_image_shard(1, 3, 16, 8)
+    ren.commit()
+    got, ref = check("shard", shard=(1, 3, 16, 8))
+    mask = np.zeros(got.shape[:2], bool)
+    for tx, ty in ovr.tiles.owned_tiles(case["size"][0], case["size"][1], 16, 8, 1, 3):
+        mask[ty * 8:(ty + 1) * 8, tx * 16:(tx + 1) * 16] = True
+    compare(oracle, np.where(mask[..., None], got, 0.0).astype(np.float32), np.where(mask[..., None], ref, 0.0).astype(np.float32), name="shard")
+    ren.set_image_shard(0, 1, 16, 8)
+    ren.commit()
+    compare(oracle, *check("unshard"), name="unshard")
+    # a new volume of another shape and type on the same renderer
+    case.update(make_case(ovr, oracle, n=24, dtype=np.uint8, tf="bumps", cam="oblique", size=case["size"], shading=1, dims=(40, 24, 31)))
+    ren.set_transfer_function(case["colors"], case["alphas"], case["vr"])
+    eye, at, up = case["cam"]
+    ren.init(ovr.Scene(volume=case["vol"], transfer_function=None), ovr.Camera(eye, at, up, case["fovy"]))
+    ren.commit()
+    compare(oracle, *check("volume"), name="volume")
