@@ -160,7 +160,8 @@ def main():
     ren.set_sparse_sampling(False)
     ren.commit()
     vol_host = None
-    if rank == 0 and not args.no_cpu_baseline:
+    want_cpu = world == 1 and not args.no_cpu_baseline   # rank 0 at N = 1 only
+    if want_cpu:
         vol_host = vol.cpu().numpy() if cfg["dtype"] != "uint16" or hasattr(torch, "uint16") else vol.cpu().numpy().view(np.uint16)
     del vol
     torch.cuda.empty_cache()
@@ -327,7 +328,7 @@ def main():
         }
         if skip_leg is not None:
             out["with_empty_space_skipping"] = skip_leg
-        if not args.no_cpu_baseline:
+        if want_cpu:
             out["cpu_baseline"] = cpu_baseline(cfg, vol_host, colors, alphas, vr, cam)
         print(json.dumps(out))
     if dist is not None:
