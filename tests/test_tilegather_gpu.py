@@ -69,9 +69,10 @@ def _worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_pipelined_gather_rebuilds_the_accumulated_frame(tmp_path, ovr):
+@pytest.mark.parametrize("world", [2, 4])   # + this process: at most 5 processes on the card
+def test_pipelined_gather_rebuilds_the_accumulated_frame(tmp_path, ovr, world):
     out = str(tmp_path / "frame.npy")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     got, prev = np.load(out), np.load(out + ".prev.npy")
     ren = _renderer(ovr)
     fb = ovr.FrameBufferData()
