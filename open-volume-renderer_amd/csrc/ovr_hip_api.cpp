@@ -120,6 +120,7 @@ struct ovr_hip_renderer {
   // macrocells (empty-space skipping)
   float* d_mc_minmax = nullptr;
   float* d_mc_majorant = nullptr;
+  unsigned char* d_mc_occupancy = nullptr; // coarse, dilated occupancy (skip intervals of the march)
   size_t mc_cells = 0;
   bool mc_ranges_valid = false, mc_majorant_valid = false;
 
@@ -404,8 +405,10 @@ int update_macrocells(ovr_hip_renderer* r, hipStream_t st)
     HIP_TRY(hipDeviceSynchronize());
     if (r->d_mc_minmax) HIP_TRY(hipFree(r->d_mc_minmax));
     if (r->d_mc_majorant) HIP_TRY(hipFree(r->d_mc_majorant));
+    if (r->d_mc_occupancy) HIP_TRY(hipFree(r->d_mc_occupancy));
     HIP_TRY(hipMalloc((void**)&r->d_mc_minmax, cells * 2 * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&r->d_mc_majorant, cells * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&r->d_mc_occupancy, cells));
     r->mc_cells = cells;
     r->mc_ranges_valid = r->mc_majorant_valid = false;
   }
@@ -419,6 +422,7 @@ int update_macrocells(ovr_hip_renderer* r, hipStream_t st)
   if (!r->mc_majorant_valid) {
     // tfn.value_range / range_rcp_norm of the reference (volume.cpp:147-153) - the TF range, normalised like the data
     HIP_TRY(launch_macrocell_majorants(r->d_mc_minmax, (unsigned int)cells, r->d_tf_alpha, r->n_alpha, r->P.tf_lower, r->P.tf_upper, r->d_mc_majorant, st));
+    HIP_TRY(launch_macrocell_coarse(r->d_mc_majorant, r->vd.nx, r->vd.ny, r->vd.nz, r->d_mc_occupancy, st));
     r->mc_majorant_valid = true;
   }
   return 0;
@@ -520,9 +524,11 @@ int enqueue_frame(ovr_hip_renderer* r)
   P.tile_h = r->shard.current.th;
   P.counters = r->d_counters;
   P.majorant = nullptr;
+  P.occupancy = nullptr;
   if (r->skipping.current) {
     if (int e = update_macrocells(r, st)) return e;
     P.majorant = r->d_mc_majorant;
+    P.occupancy = r->d_mc_occupancy;
   }
   P.block_counters = r->d_block_counters;
   P.trace = r->d_trace;
@@ -685,6 +691,7 @@ void ovr_hip_destroy(ovr_hip_renderer* r)
   if (r->d_noise) (void)hipFree(r->d_noise);
   if (r->d_mc_minmax) (void)hipFree(r->d_mc_minmax);
   if (r->d_mc_majorant) (void)hipFree(r->d_mc_majorant);
+  if (r->d_mc_occupancy) (void)hipFree(r->d_mc_occupancy);
   if (r->d_counters) (void)hipFree(r->d_counters);
   if (r->d_sparse_count) (void)hipFree(r->d_sparse_count);
   if (r->h_counters) (void)hipHostFree(r->h_counters);

@@ -86,6 +86,7 @@ struct RayMarchParams {
   // counters: [0] rays [1] samples [2] shaded samples [3] shadow samples [4] active pixels [5] skipped samples [6] skipped shadow samples
   unsigned long long* counters;
   const float* majorant;        // per-macrocell max TF opacity: empty-space skipping (null = off)
+  const unsigned char* occupancy; // per 4^3 macrocells: majorant > 0 in one of them or next to them (set with majorant)
   unsigned long long* trace;    // diagnostic (OVR_HIP_TRACE=1): 4 words per wave, null otherwise
   unsigned int* block_counters; // workspace: raymarch_grid_blocks() * 7 per-workgroup partial sums
   PoolDesc pool;
@@ -129,6 +130,9 @@ hipError_t launch_tea(uint32_t* v0v1, float* out, int64_t n, hipStream_t stream)
 hipError_t launch_macrocell_ranges(const VolumeDesc& vd, float* out_minmax, hipStream_t stream);
 hipError_t launch_macrocell_majorants(const float* minmax, unsigned int count, const float* alphas, int n_alpha, float vr_lo, float vr_hi, float* out,
                                       hipStream_t stream);
+
+// coarse occupancy (one byte per 4^3 macrocells, dilated by one macrocell) for the march's per-ray skip intervals
+hipError_t launch_macrocell_coarse(const float* majorant, int nx, int ny, int nz, unsigned char* out, hipStream_t stream);
 
 // tile pack/unpack for the RCCL gather payload
 hipError_t launch_pack_tiles(const float* frame, float* dst, int width, int height, int tile_w, int tile_h, int rank, int world,

@@ -141,6 +141,7 @@ struct VolConsts {
   const unsigned long long* tab_z64; // AM 2: z offsets need 64 bits (>= 2^32 stored voxels)
   int nx1, ny1, nz1; // n - 1
   const float* majorant; // per-macrocell max TF opacity (null: empty-space skipping off)
+  const unsigned char* occupancy; // per 4^3 macrocells: 1 if one of them, or a macrocell next to them, has majorant > 0
   int mcx1, mcy1, mcz1;  // macrocell grid dims - 1
   unsigned int macro_y;          // stored elements between macro rows: MV * macros_x
   unsigned long long macro_z;    // stored elements between macro layers: MV * macros_x * macros_y
@@ -452,6 +453,7 @@ __device__ __forceinline__ void setup_consts(const RayMarchParams& P, VolConsts&
   vc.cs = ld3(P.coord_scale); vc.cb = ld3(P.coord_bias);
   vc.vscale = P.vol.value_scale; vc.vmin = P.vol.value_min_clamp;
   vc.majorant = P.majorant;
+  vc.occupancy = P.occupancy;
   vc.mcx1 = (P.vol.nx + 15) / 16 - 1; vc.mcy1 = (P.vol.ny + 15) / 16 - 1; vc.mcz1 = (P.vol.nz + 15) / 16 - 1;
   mc.inv_scale = ld3(P.inv_scale); mc.wto_p = ld3(P.wto_p); mc.otw_it = ld3(P.otw_it); mc.light = ld3(P.light);
   mc.gstep = ld3(P.grad_step);
@@ -684,6 +686,54 @@ __device__ __forceinline__ bool assign_pixel_quad(const RayMarchParams& P, int l
   return active;
 }
 
+// Empty-space skipping, per ray: the t interval outside of which every sample lies in a macrocell with majorant 0.
+// The 4 lanes of the quad each walk a quarter of the ray's [t0, t1] through the coarse occupancy grid (3-D DDA; accel/dda.h is
+// the reference's walker for its path tracer) and keep the first entry / last exit of a set entry; min / max over the quad
+// gives the ray's interval.  Sample coordinates: x = p * cs + cb (tap_coords), macrocell = (floor(x) + 1) >> 4 (tap_cell),
+// i.e. the regular 16-voxel grid in w = x + 1; a coarse entry is 64 voxels of w.
+__device__ __forceinline__ void skip_interval(const VolConsts& vc, f3 oo, f3 od, float t0, float t1, int sub, bool live, float& t_first, float& t_last)
+{
+  float first = FLT_MAX, last = -FLT_MAX;
+  if (live) {
+    const float len = t1 - t0;
+    const float ta = fmaf((float)sub * 0.25f, len, t0), tb = sub == 3 ? t1 : fmaf((float)(sub + 1) * 0.25f, len, t0);
+    const float w0[3] = { fmaf(oo.x, vc.cs.x, vc.cb.x + 1.f), fmaf(oo.y, vc.cs.y, vc.cb.y + 1.f), fmaf(oo.z, vc.cs.z, vc.cb.z + 1.f) };
+    const float dw[3] = { od.x * vc.cs.x, od.y * vc.cs.y, od.z * vc.cs.z };
+    const int m1[3] = { vc.mcx1 >> 2, vc.mcy1 >> 2, vc.mcz1 >> 2 }; // coarse grid dims - 1
+    constexpr float G = 64.f;
+    int ci[3], st[3];
+    float tmax[3], tdel[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float w = fmaf(ta, dw[k], w0[k]);
+      ci[k] = min(max((int)floorf(w * (1.f / G)), 0), m1[k]);
+      st[k] = dw[k] > 0.f ? 1 : -1;
+      const bool moves = fabsf(dw[k]) > 1e-20f;
+      tdel[k] = moves ? G / fabsf(dw[k]) : FLT_MAX;
+      tmax[k] = moves ? ((float)(ci[k] + (dw[k] > 0.f ? 1 : 0)) * G - w0[k]) / dw[k] : FLT_MAX;
+    }
+    float t = ta;
+    const int limit = m1[0] + m1[1] + m1[2] + 8; // a ray crosses at most this many cells: every lane leaves the loop
+    for (int it = 0; it < limit && t < tb; ++it) {
+      const bool occ = vc.occupancy[(size_t)ci[0] + (size_t)(m1[0] + 1) * ((size_t)ci[1] + (size_t)(m1[1] + 1) * (size_t)ci[2])] != 0;
+      const int ax = (tmax[0] <= tmax[1]) ? (tmax[0] <= tmax[2] ? 0 : 2) : (tmax[1] <= tmax[2] ? 1 : 2);
+      const float tn = ax == 0 ? tmax[0] : ax == 1 ? tmax[1] : tmax[2];
+      if (occ) { first = fminf(first, t); last = fmaxf(last, fminf(tn, tb)); }
+      t = fmaxf(t, tn);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (k == ax) {
+          const int nxt = ci[k] + st[k];
+          if (nxt < 0 || nxt > m1[k]) tmax[k] = FLT_MAX; // the clamped coordinate stays in the border cell
+          else { ci[k] = nxt; tmax[k] += tdel[k]; }
+        }
+    }
+    if (t < tb) { first = fminf(first, t); last = tb; } // safety limit hit (never expected): treat the rest as occupied
+  }
+  t_first = fminf(fminf(quad_bcast<0>(first), quad_bcast<1>(first)), fminf(quad_bcast<2>(first), quad_bcast<3>(first)));
+  t_last = fmaxf(fmaxf(quad_bcast<0>(last), quad_bcast<1>(last)), fmaxf(quad_bcast<2>(last), quad_bcast<3>(last)));
+}
+
 template <int SHADE, bool POOLED> struct QCfg {
 #ifndef OVR_POOLED_K
 #define OVR_POOLED_K 4
@@ -718,7 +768,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
   setup_consts(P, vc, mc);
 
   // ---- LDS carve: [request queues][offset tables][TF colour (not needed by the pooled march)][TF alpha]
-  // A workgroup none of whose rays can hit the volume (most of the image outside the silhouette) stages nothing.
+  // A workgroup none of whose rays can hit the volume (most of the image outside the silhouette) stages nothing; with
+  // empty-space skipping, neither does one whose rays only cross empty macrocells.
   ShadeReq* const queue = reinterpret_cast<ShadeReq*>(lds_raw) + (size_t)wave * (QCAP > 0 ? QCAP : 1);
   TfConsts tf;
   {
@@ -728,7 +779,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
       const f3 c0 = ld3(P.cam_dir), h0 = ld3(P.cam_hor), v0 = ld3(P.cam_ver);
       const f3 d0 = normalize3_exact(mk3(c0.x + ux0 * h0.x + uy0 * v0.x, c0.y + ux0 * h0.y + uy0 * v0.y, c0.z + ux0 * h0.z + uy0 * v0.z));
       float a0 = 0.f, b0 = FLT_MAX;
-      need = intersect_unit_box(a0, b0, to_object(mc, ld3(P.cam_pos)), mk3(d0.x * mc.inv_scale.x, d0.y * mc.inv_scale.y, d0.z * mc.inv_scale.z));
+      const f3 oo0 = to_object(mc, ld3(P.cam_pos)), od0 = mk3(d0.x * mc.inv_scale.x, d0.y * mc.inv_scale.y, d0.z * mc.inv_scale.z);
+      need = intersect_unit_box(a0, b0, oo0, od0);
+      if (SKIP && need) { // skipping: a ray that meets no occupied macrocell never fetches a voxel or a TF entry either
+        float f0, l0;
+        skip_interval(vc, oo0, od0, a0, b0, sub, true, f0, l0);
+        need = f0 <= l0;
+      }
     }
     if (__syncthreads_or(need ? 1 : 0)) {
       unsigned char* base = lds_raw + (size_t)kWaves * QCAP * sizeof(ShadeReq);
@@ -814,6 +871,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
     gradient = mk3(0, 0, 0);
     bool live = active && intersect_unit_box(t0, t1, oo, od);
     if (active && owner) ++n_rays;
+    float skip_first = -FLT_MAX, skip_last = FLT_MAX; // samples outside [skip_first, skip_last] are in empty macrocells
+    if (SKIP) skip_interval(vc, oo, od, t0, t1, sub, live, skip_first, skip_last);
     float tx = t0, ty = fminf(t1, t0 + mc.step);
     pend = 0;
 
@@ -840,12 +899,35 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
       }
       if (!any_live) break;
 
+      // ---- (1b) empty-space skipping, bulk form: a round whose 4K steps all lie before (after) the ray's skip interval
+      //      needs neither the lanes' own sample positions nor per-step bookkeeping - only the (tx, ty) recurrence, which
+      //      has to be run step by step (its rounding is part of the result), and one validity test: the steps' midpoints
+      //      lie in [tx_0, tx_4K], and validity (ty > tx) is monotone, so the last step being valid makes all of them valid.
+      //      ~45 instructions per round instead of ~330 for the per-step form below.
+      if (SKIP) {
+        float ntx = tx, nty = ty, ptx = tx;
+#pragma unroll
+        for (int b = 0; b < 4 * K; ++b) {
+          ptx = ntx;
+          ntx = nty;
+          nty = fminf(ntx + mc.step, t1);
+        }
+        const bool all_valid = ntx > ptx;                       // the round's last step: ty_last (= ntx) > tx_last (= ptx)
+        const bool outside = (ntx < skip_first) || (tx > skip_last);
+        const bool go = live && (alpha < 0.9999f);
+        if (__ballot(live && !(outside && all_valid)) == 0ull) {
+          n_skipped += go ? (unsigned int)K : 0u;               // this lane's K steps of the round
+          live = go;
+          tx = ntx; ty = nty;
+          continue;
+        }
+      }
       // ---- (2) the ray's next 4K steps: every lane runs the (tx, ty) recurrence, keeps its own K steps and one validity
       //      bit per step (ty > tx, the first half of the reference's loop condition)
       unsigned int vmask = 0;
       Tap taps[K];
       f3 poss[K];
-      float dts[K], mj[K];
+      float dts[K], mj[K], tms[K];
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         float txq[4], tyq[4];
@@ -859,28 +941,39 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
         const float mtx = sel4(txq[0], txq[1], txq[2], txq[3], sub);
         const float mty = sel4(tyq[0], tyq[1], tyq[2], tyq[3], sub);
         dts[k] = mty - mtx;
-        const float tm = 0.5f * (mtx + mty);
-        poss[k] = mk3(fmaf(tm, dir.x, org.x), fmaf(tm, dir.y, org.y), fmaf(tm, dir.z, org.z));
+        tms[k] = 0.5f * (mtx + mty);
+      }
+      // empty-space fast path (wave-uniform): every sample of this round lies in a macrocell whose majorant is 0, so all
+      // opacities are exactly 0, alpha does not move and nothing is pushed - only liveness and the counters advance
+      auto skip_round = [&]() {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            live = live && ((vmask >> (4 * k + b)) & 1u) != 0u && (alpha < 0.9999f);
+            n_skipped += (live && sub == b) ? 1u : 0u;
+          }
+        }
+      };
+      if (SKIP) {
+        // (a) by the ray's skip interval: no coordinates, no majorant lookups
+        bool inside = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) inside = inside || (tms[k] >= skip_first && tms[k] <= skip_last);
+        if (__ballot(inside && live) == 0ull) { skip_round(); continue; }
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        poss[k] = mk3(fmaf(tms[k], dir.x, org.x), fmaf(tms[k], dir.y, org.y), fmaf(tms[k], dir.z, org.z));
         tap_coords(vc, to_object(mc, poss[k]), taps[k]);
         mj[k] = SKIP ? vc.majorant[tap_cell(vc, taps[k])] : 1.f; // empty-space skipping: the macrocell's max TF opacity
       }
       if (SKIP) {
-        // empty-space fast path (wave-uniform): every sample of this round lies in a macrocell whose majorant is 0, so all
-        // opacities are exactly 0, alpha does not move and nothing is pushed - only liveness and the counters advance
+        // (b) by the majorants of this round's own macrocells
         bool any = false;
 #pragma unroll
         for (int k = 0; k < K; ++k) any = any || (mj[k] > 0.f);
-        if (__ballot(any) == 0ull) {
-#pragma unroll
-          for (int k = 0; k < K; ++k) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              live = live && ((vmask >> (4 * k + b)) & 1u) != 0u && (alpha < 0.9999f);
-              n_skipped += (live && sub == b) ? 1u : 0u;
-            }
-          }
-          continue;
-        }
+        if (__ballot(any && live) == 0ull) { skip_round(); continue; }
       }
 #pragma unroll
       for (int k = 0; k < K; ++k)
@@ -1576,6 +1669,31 @@ hipError_t launch_macrocell_majorants(const float* minmax, unsigned int count, c
 {
   hipLaunchKernelGGL(macrocell_majorant_kernel, dim3((count + 255) / 256), dim3(256), (size_t)n_alpha * sizeof(float), stream, (const float2*)minmax, count, alphas,
                      n_alpha, vr_lo, vr_hi, out);
+  return hipGetLastError();
+}
+
+// occupancy for the per-ray skip interval (skip_interval): a coarse grid of 4^3 macrocells (64^3 voxels) per entry - small
+// enough (4 KiB at 1024^3) to stay in L1 while every ray walks it.  An entry is set if any of its macrocells, or any macrocell
+// next to one of them (dilation by one macrocell), can hold a sample with opacity > 0.  The dilation is the safety margin of the
+// walk: a ray's cell sequence is right to ~1e-4 voxel of position, the nearest non-empty sample is >= 16 voxels inside a set entry.
+__global__ __launch_bounds__(256) void macrocell_coarse_kernel(const float* __restrict__ majorant, int mcx, int mcy, int mcz, unsigned char* __restrict__ out)
+{
+  const int gx = (mcx + 3) / 4, gy = (mcy + 3) / 4, gz = (mcz + 3) / 4;
+  const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (unsigned int)(gx * gy * gz)) return;
+  const int cx = (int)(i % (unsigned int)gx) * 4, cy = (int)((i / (unsigned int)gx) % (unsigned int)gy) * 4, cz = (int)(i / (unsigned int)(gx * gy)) * 4;
+  bool any = false;
+  for (int z = max(cz - 1, 0); z <= min(cz + 4, mcz - 1); ++z)
+    for (int y = max(cy - 1, 0); y <= min(cy + 4, mcy - 1); ++y)
+      for (int x = max(cx - 1, 0); x <= min(cx + 4, mcx - 1); ++x)
+        any = any || (majorant[(size_t)x + (size_t)mcx * ((size_t)y + (size_t)mcy * (size_t)z)] > 0.f);
+  out[i] = any ? 1 : 0;
+}
+hipError_t launch_macrocell_coarse(const float* majorant, int nx, int ny, int nz, unsigned char* out, hipStream_t stream)
+{
+  const int mcx = (nx + 15) / 16, mcy = (ny + 15) / 16, mcz = (nz + 15) / 16;
+  const unsigned int cells = (unsigned int)(((mcx + 3) / 4) * ((mcy + 3) / 4) * ((mcz + 3) / 4));
+  hipLaunchKernelGGL(macrocell_coarse_kernel, dim3((cells + 255) / 256), dim3(256), 0, stream, majorant, mcx, mcy, mcz, out);
   return hipGetLastError();
 }
 
