@@ -344,6 +344,47 @@ __device__ __forceinline__ f3 to_object(const MarchConsts& mc, f3 p)
   return mk3(fmaf(p.x, mc.inv_scale.x, mc.wto_p.x), fmaf(p.y, mc.inv_scale.y, mc.wto_p.y), fmaf(p.z, mc.inv_scale.z, mc.wto_p.z));
 }
 
+// Empty-space skipping, per ray: the t interval outside of which every sample lies in a macrocell with majorant 0.
+// skip_walk: one lane walks the ray's [ta, tb] through the coarse occupancy grid (3-D DDA; accel/dda.h is the reference's
+// walker for its path tracer) and widens [first, last] by the entry / exit of every set entry it crosses.
+// Sample coordinates: x = p * cs + cb (tap_coords), macrocell = (floor(x) + 1) >> 4 (tap_cell), i.e. the regular 16-voxel
+// grid in w = x + 1; a coarse entry is 64 voxels of w.
+__device__ __forceinline__ void skip_walk(const VolConsts& vc, f3 oo, f3 od, float ta, float tb, float& first, float& last)
+{
+  const float w0[3] = { fmaf(oo.x, vc.cs.x, vc.cb.x + 1.f), fmaf(oo.y, vc.cs.y, vc.cb.y + 1.f), fmaf(oo.z, vc.cs.z, vc.cb.z + 1.f) };
+  const float dw[3] = { od.x * vc.cs.x, od.y * vc.cs.y, od.z * vc.cs.z };
+  const int m1[3] = { vc.mcx1 >> 2, vc.mcy1 >> 2, vc.mcz1 >> 2 }; // coarse grid dims - 1
+  constexpr float G = 64.f;
+  int ci[3], st[3];
+  float tmax[3], tdel[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float w = fmaf(ta, dw[k], w0[k]);
+    ci[k] = min(max((int)floorf(w * (1.f / G)), 0), m1[k]);
+    st[k] = dw[k] > 0.f ? 1 : -1;
+    const bool moves = fabsf(dw[k]) > 1e-20f;
+    tdel[k] = moves ? G / fabsf(dw[k]) : FLT_MAX;
+    tmax[k] = moves ? ((float)(ci[k] + (dw[k] > 0.f ? 1 : 0)) * G - w0[k]) / dw[k] : FLT_MAX;
+  }
+  float t = ta;
+  const int limit = m1[0] + m1[1] + m1[2] + 8; // a ray crosses at most this many entries: every lane leaves the loop
+  for (int it = 0; it < limit && t < tb; ++it) {
+    const bool occ = vc.occupancy[(size_t)ci[0] + (size_t)(m1[0] + 1) * ((size_t)ci[1] + (size_t)(m1[1] + 1) * (size_t)ci[2])] != 0;
+    const int ax = (tmax[0] <= tmax[1]) ? (tmax[0] <= tmax[2] ? 0 : 2) : (tmax[1] <= tmax[2] ? 1 : 2);
+    const float tn = ax == 0 ? tmax[0] : ax == 1 ? tmax[1] : tmax[2];
+    if (occ) { first = fminf(first, t); last = fmaxf(last, fminf(tn, tb)); }
+    t = fmaxf(t, tn);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (k == ax) {
+        const int nxt = ci[k] + st[k];
+        if (nxt < 0 || nxt > m1[k]) tmax[k] = FLT_MAX; // the clamped coordinate stays in the border entry
+        else { ci[k] = nxt; tmax[k] += tdel[k]; }
+      }
+  }
+  if (t < tb) { first = fminf(first, t); last = tb; } // safety limit hit (never expected): treat the rest as occupied
+}
+
 // raymarching_shadow, shaders_raymarching.cu:44-85 (+ :205-229): alpha-only march toward the light.
 // KS taps are issued before the first one is consumed; taps past the end of the march or past the early-termination
 // point are speculative (their coordinates are clamped, so the loads are always in bounds) and simply dropped.
@@ -358,20 +399,38 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
   if (!intersect_unit_box(t0, t1, oo, od)) return alpha;
   float tx = t0, ty = fminf(t1, t0 + mc.shadow_stride);
   bool live = true;
+  // empty-space skipping: the shadow ray's own skip interval (a handful of coarse entries: the ray is a few hundred voxels)
+  float skip_first = FLT_MAX, skip_last = -FLT_MAX;
+  if (SKIP) skip_walk(vc, oo, od, t0, t1, skip_first, skip_last);
   while (live) {
     Tap taps[KS];
     float dts[KS], mj[KS];
     bool valid[KS];
+    bool any_inside = false;
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
       valid[k] = ty > tx;
       dts[k] = ty - tx;
       const float tm = 0.5f * (tx + ty);
-      const f3 pos = mk3(fmaf(tm, mc.light.x, org.x), fmaf(tm, mc.light.y, org.y), fmaf(tm, mc.light.z, org.z));
-      tap_coords(vc, to_object(mc, pos), taps[k]);
-      mj[k] = SKIP ? vc.majorant[tap_cell(vc, taps[k])] : 1.f; // empty-space skipping: max TF opacity of the macrocell
+      const bool inside = !SKIP || (tm >= skip_first && tm <= skip_last);
+      if (SKIP) taps[k] = Tap{};
+      mj[k] = SKIP ? 0.f : 1.f;
+      if (inside) {
+        const f3 pos = mk3(fmaf(tm, mc.light.x, org.x), fmaf(tm, mc.light.y, org.y), fmaf(tm, mc.light.z, org.z));
+        tap_coords(vc, to_object(mc, pos), taps[k]);
+        if (SKIP) mj[k] = vc.majorant[tap_cell(vc, taps[k])]; // empty-space skipping: max TF opacity of the macrocell
+      }
+      any_inside = any_inside || (mj[k] > 0.f);
       tx = ty;
       ty = fminf(tx + mc.shadow_stride, t1);
+    }
+    if (SKIP && __ballot(any_inside) == 0ull) { // nothing to fetch for any lane of the wave: bookkeeping only
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        live = live && valid[k] && (alpha < 0.9999f);
+        n_shadow_skipped += live ? 1u : 0u;
+      }
+      continue;
     }
 #pragma unroll
     for (int k = 0; k < KS; ++k)
@@ -686,49 +745,14 @@ __device__ __forceinline__ bool assign_pixel_quad(const RayMarchParams& P, int l
   return active;
 }
 
-// Empty-space skipping, per ray: the t interval outside of which every sample lies in a macrocell with majorant 0.
-// The 4 lanes of the quad each walk a quarter of the ray's [t0, t1] through the coarse occupancy grid (3-D DDA; accel/dda.h is
-// the reference's walker for its path tracer) and keep the first entry / last exit of a set entry; min / max over the quad
-// gives the ray's interval.  Sample coordinates: x = p * cs + cb (tap_coords), macrocell = (floor(x) + 1) >> 4 (tap_cell),
-// i.e. the regular 16-voxel grid in w = x + 1; a coarse entry is 64 voxels of w.
+// the primary rays' form: the 4 lanes of the quad each walk a quarter of [t0, t1]; min / max over the quad
 __device__ __forceinline__ void skip_interval(const VolConsts& vc, f3 oo, f3 od, float t0, float t1, int sub, bool live, float& t_first, float& t_last)
 {
   float first = FLT_MAX, last = -FLT_MAX;
   if (live) {
     const float len = t1 - t0;
     const float ta = fmaf((float)sub * 0.25f, len, t0), tb = sub == 3 ? t1 : fmaf((float)(sub + 1) * 0.25f, len, t0);
-    const float w0[3] = { fmaf(oo.x, vc.cs.x, vc.cb.x + 1.f), fmaf(oo.y, vc.cs.y, vc.cb.y + 1.f), fmaf(oo.z, vc.cs.z, vc.cb.z + 1.f) };
-    const float dw[3] = { od.x * vc.cs.x, od.y * vc.cs.y, od.z * vc.cs.z };
-    const int m1[3] = { vc.mcx1 >> 2, vc.mcy1 >> 2, vc.mcz1 >> 2 }; // coarse grid dims - 1
-    constexpr float G = 64.f;
-    int ci[3], st[3];
-    float tmax[3], tdel[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float w = fmaf(ta, dw[k], w0[k]);
-      ci[k] = min(max((int)floorf(w * (1.f / G)), 0), m1[k]);
-      st[k] = dw[k] > 0.f ? 1 : -1;
-      const bool moves = fabsf(dw[k]) > 1e-20f;
-      tdel[k] = moves ? G / fabsf(dw[k]) : FLT_MAX;
-      tmax[k] = moves ? ((float)(ci[k] + (dw[k] > 0.f ? 1 : 0)) * G - w0[k]) / dw[k] : FLT_MAX;
-    }
-    float t = ta;
-    const int limit = m1[0] + m1[1] + m1[2] + 8; // a ray crosses at most this many cells: every lane leaves the loop
-    for (int it = 0; it < limit && t < tb; ++it) {
-      const bool occ = vc.occupancy[(size_t)ci[0] + (size_t)(m1[0] + 1) * ((size_t)ci[1] + (size_t)(m1[1] + 1) * (size_t)ci[2])] != 0;
-      const int ax = (tmax[0] <= tmax[1]) ? (tmax[0] <= tmax[2] ? 0 : 2) : (tmax[1] <= tmax[2] ? 1 : 2);
-      const float tn = ax == 0 ? tmax[0] : ax == 1 ? tmax[1] : tmax[2];
-      if (occ) { first = fminf(first, t); last = fmaxf(last, fminf(tn, tb)); }
-      t = fmaxf(t, tn);
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-        if (k == ax) {
-          const int nxt = ci[k] + st[k];
-          if (nxt < 0 || nxt > m1[k]) tmax[k] = FLT_MAX; // the clamped coordinate stays in the border cell
-          else { ci[k] = nxt; tmax[k] += tdel[k]; }
-        }
-    }
-    if (t < tb) { first = fminf(first, t); last = tb; } // safety limit hit (never expected): treat the rest as occupied
+    skip_walk(vc, oo, od, ta, tb, first, last);
   }
   t_first = fminf(fminf(quad_bcast<0>(first), quad_bcast<1>(first)), fminf(quad_bcast<2>(first), quad_bcast<3>(first)));
   t_last = fmaxf(fmaxf(quad_bcast<0>(last), quad_bcast<1>(last)), fmaxf(quad_bcast<2>(last), quad_bcast<3>(last)));
