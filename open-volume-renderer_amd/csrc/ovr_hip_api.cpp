@@ -661,12 +661,16 @@ int ovr_hip_create(ovr_hip_renderer** out, int device_id)
     return fail(OVR_HIP_EDEVICE, std::string("[hip] device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
   ovr_hip_renderer* r = new ovr_hip_renderer();
   r->device = device_id;
-  HIP_TRY(hipStreamCreate(&r->own_stream[0]));
-  HIP_TRY(hipStreamCreate(&r->own_stream[1]));
-  for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&r->ev[i]));
-  HIP_TRY(hipMalloc((void**)&r->d_counters, 8 * sizeof(unsigned long long)));
-  HIP_TRY(hipMalloc((void**)&r->d_sparse_count, sizeof(unsigned long long)));
-  HIP_TRY(hipHostMalloc((void**)&r->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+  auto acquire = [&]() -> int {
+    HIP_TRY(hipStreamCreate(&r->own_stream[0]));
+    HIP_TRY(hipStreamCreate(&r->own_stream[1]));
+    for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&r->ev[i]));
+    HIP_TRY(hipMalloc((void**)&r->d_counters, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&r->d_sparse_count, sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc((void**)&r->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+    return 0;
+  };
+  if (int e = acquire()) { ovr_hip_destroy(r); return e; } // nothing half-built leaks
   std::memset(r->h_counters, 0, 8 * sizeof(unsigned long long));
   // defaults of the reference's parameter block (params.h:55-99, renderer.h:255-285)
   r->spp.current = r->spp.queued = 1;
