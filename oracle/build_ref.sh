@@ -6,6 +6,8 @@
 # Products:
 #   oracle/_ref/renderbatch        the reference's headless app (apps/main_batch.cpp:240-318), no built-in devices;
 #                                  it resolves `--device hip` through dlopen("libdevice_hip.so") (ovr/renderer.cpp:55-58)
+#   oracle/_ref/plugin_probe       oracle/plugin_probe.cpp: drives libdevice_hip.so through the reference's MainRenderer interface
+#                                  (sparse sampling, spp, accumulation, camera change, swap)
 #   oracle/_ref/libovr_refhost.so  scene.cpp + serializer + imageio + colormaps, used by tests to pin the
 #                                  oracle's scene/TF/PNG-quantisation restatement against the real reference code
 #
@@ -40,4 +42,5 @@ $CXX -shared -o "$OUT/libovr_refhost.so" $hostobjs -ldl -lpthread
 $CXX -o "$OUT/renderbatch" $objs -rdynamic -ldl -lpthread
 $CXX $FLAGS "$HERE/ref_probe.cpp" -o "$OUT/ref_probe" -L"$OUT" -lovr_refhost -Wl,-rpath,'$ORIGIN' -ldl -lpthread
 $CXX $FLAGS "$HERE/ref_scene_probe.cpp" -o "$OUT/ref_scene_probe" -L"$OUT" -lovr_refhost -Wl,-rpath,'$ORIGIN' -ldl -lpthread
-echo "[build_ref] built $OUT/renderbatch, $OUT/libovr_refhost.so, $OUT/ref_probe and $OUT/ref_scene_probe"
+$CXX $FLAGS "$HERE/plugin_probe.cpp" -o "$OUT/plugin_probe" -L"$OUT" -lovr_refhost -Wl,-rpath,'$ORIGIN' -rdynamic -ldl -lpthread
+echo "[build_ref] built $OUT/renderbatch, $OUT/libovr_refhost.so, $OUT/ref_probe, $OUT/ref_scene_probe and $OUT/plugin_probe"

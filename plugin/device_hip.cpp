@@ -12,14 +12,52 @@
 #include "../include/ovr_hip.h"
 
 #include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 namespace {
 
 void check(int code)
 {
   if (code != 0) throw std::runtime_error(ovr_hip_last_error()); // the reference reports device errors as std::runtime_error
+}
+
+// The reference links its noise tile into the CUDA device's translation unit (ovr/CMakeLists.txt:67-72, blue_noise.h:74-79),
+// out of a plugin's reach.  The same files ship in the reference's data/noise/: the tile is read from $OVR_HIP_NOISE_TILE or,
+// failing that, from the names the reference's own (commented-out) file loader used, next to the executable.
+// Layout [y][x][t] float32, t = 64 (blue_noise.h:95-99); xy follows from the file size.
+bool load_noise_tile(ovr_hip_renderer* h)
+{
+  std::vector<std::string> candidates;
+  if (const char* e = std::getenv("OVR_HIP_NOISE_TILE")) candidates.push_back(e);
+  for (const char* name : { "stbn_128x128x64.bin", "blue_64x64x64.bin" }) { // STBN is the reference's default (generate_mask.h:9)
+    candidates.push_back(std::string("./") + name);
+    candidates.push_back(std::string("./data/noise/") + name);
+    if (const char* root = std::getenv("OVR_ROOT")) candidates.push_back(std::string(root) + "/data/noise/" + name);
+  }
+  for (const std::string& path : candidates) {
+    std::FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) continue;
+    std::fseek(f, 0, SEEK_END);
+    const long bytes = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    const long xy = bytes > 0 ? std::lround(std::sqrt((double)bytes / (64.0 * sizeof(float)))) : 0;
+    std::vector<float> tile;
+    bool ok = xy > 0 && (long)(xy * xy * 64 * sizeof(float)) == bytes;
+    if (ok) {
+      tile.resize((size_t)xy * xy * 64);
+      ok = std::fread(tile.data(), 1, (size_t)bytes, f) == (size_t)bytes;
+    }
+    std::fclose(f);
+    if (!ok) throw std::runtime_error("[hip] " + path + " is not an xy*xy*64 float32 noise tile");
+    check(ovr_hip_set_noise_tile(h, tile.data(), (int32_t)xy));
+    return true;
+  }
+  return false;
 }
 
 class DeviceHIP : public ovr::MainRenderer {
@@ -69,7 +107,15 @@ public:
     if (params.sample_per_pixel.update()) check(ovr_hip_set_sample_per_pixel(h, params.sample_per_pixel.ref()));
     if (params.path_tracing.update() && params.path_tracing.ref())
       throw std::runtime_error("[hip] path tracing is not part of the ray-marching backend");
-    if (params.sparse_sampling.update()) check(ovr_hip_set_sparse_sampling(h, params.sparse_sampling.ref()));
+    if (params.sparse_sampling.update()) {
+      if (params.sparse_sampling.ref() && !have_noise) {
+        if (!load_noise_tile(h))
+          throw std::runtime_error("[hip] sparse sampling needs the reference's noise tile: set OVR_HIP_NOISE_TILE to data/noise/stbn_128x128x64.bin "
+                                   "(or blue_64x64x64.bin), or run next to it");
+        have_noise = true;
+      }
+      check(ovr_hip_set_sparse_sampling(h, params.sparse_sampling.ref()));
+    }
     if (params.frame_accumulation.update()) check(ovr_hip_set_frame_accumulation(h, params.frame_accumulation.ref()));
     if (params.volume_sampling_rate.update()) check(ovr_hip_set_volume_sampling_rate(h, params.volume_sampling_rate.get()));
     check(ovr_hip_commit(h));
@@ -99,6 +145,7 @@ public:
 
 private:
   ovr_hip_renderer* h = nullptr;
+  bool have_noise = false;
 };
 
 } // namespace

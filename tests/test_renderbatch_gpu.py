@@ -50,3 +50,61 @@ def test_renderbatch_device_hip(tmp_path, ovr, oracle, dtype):
     # ulp, hence <= 1 on the 8-bit channels
     assert d.max() <= 1, f"max 8-bit difference {d.max()}"
     assert (ref8[..., 3] > 0).mean() > 0.02
+
+
+def test_plugin_sparse_spp_swap_through_the_reference_interface(tmp_path, ovr, hip_renderer_factory):
+    """oracle/_ref/plugin_probe (oracle/plugin_probe.cpp, compiled against the reference's headers and host code) drives
+    libdevice_hip.so through MainRenderer: sparse sampling with a focus window (the plugin reads the reference's noise-tile file),
+    2 samples per pixel, progressive accumulation, then dense frames from a moved camera with a swap in between.  The same calls
+    made from the Python host must give the same frames: both end in the same C ABI, so this pins the plugin's forwarding."""
+    probe = os.path.join(ROOT, "oracle", "_ref", "plugin_probe")
+    if not (os.path.exists(probe) and os.path.exists(PLUGIN)):
+        pytest.skip("oracle/_ref/plugin_probe or plugin/libdevice_hip.so missing (built by __graft_entry__.build() where the reference tree is present)")
+    n, W, H = 40, 112, 72
+    vol = ovr.synth.make_volume(n, np.float32)
+    colors, alphas, vr = ovr.synth.make_tfn("bumps", 256)
+    cam = ovr.synth.make_camera("oblique", n)
+    scene_path = ovr.vidi3d.write_scene(str(tmp_path), "synthetic", vol, ovr.synth._RAINBOW, alphas[1::2].copy(), (0.0, 1.0), cam, fovy=45.0,
+                                        sample_distance=0.5)
+    tile = np.random.default_rng(7).random((32, 32, 64), dtype=np.float32)
+    tile.tofile(str(tmp_path / "noise.bin"))
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.dirname(PLUGIN), os.path.join(ROOT, "open-volume-renderer_amd"), env.get("LD_LIBRARY_PATH", "")])
+    env["OVR_HIP_NOISE_TILE"] = str(tmp_path / "noise.bin")
+    out = subprocess.run([probe, scene_path, str(W), str(H), str(tmp_path / "frames.f32")], env=env, cwd=str(tmp_path), capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = np.fromfile(str(tmp_path / "frames.f32"), dtype=np.float32).reshape(2, H, W, 4)
+
+    scene, camera = ovr.vidi3d.scene_from_file(scene_path)
+    ren = hip_renderer_factory()
+    ren.set_fbsize((W, H))
+    ren.set_frame_accumulation(True)
+    ren.set_sample_per_pixel(2)
+    ren.set_volume_sampling_rate(scene.volume_sampling_rate)
+    ren.set_noise_tile(tile)
+    ren.init(scene, camera)
+    ren.commit()
+    ren.set_sparse_sampling(True)
+    ren.set_focus((0.4, 0.6), 0.3, 0.05)
+    ren.commit()
+    for _ in range(3):
+        ren.render()
+    fb = ovr.FrameBufferData()
+    ren.mapframe(fb)
+    sparse = np.array(fb.rgba.data(), copy=True)
+    ren.set_sparse_sampling(False)
+    eye = tuple(float(np.float32(c) * np.float32(1.1)) for c in camera.eye)
+    ren.set_camera(eye, camera.at, camera.up)
+    ren.commit()
+    ren.render()
+    ren.swap()
+    ren.render()
+    ren.mapframe(fb)
+    dense = np.array(fb.rgba.data(), copy=True)
+    # the sparse pixel set is integer work: identical; values: the two hosts rasterise the transfer function separately
+    # (tfn::updateColorMap vs vidi3d.rasterize_transfer_function, equal to a few ulp - tests/test_scene_ingest.py)
+    assert np.array_equal(got[0][..., 3] > 0, sparse[..., 3] > 0)
+    assert 0.02 < (sparse[..., 3] > 0).mean() < 0.9
+    assert np.abs(got[0] - sparse).max() <= 2e-5
+    assert np.abs(got[1] - dense).max() <= 2e-5 and (dense[..., 3] > 0).mean() > 0.03
