@@ -566,15 +566,17 @@ static void* worker(void* p)
   worker_arg* w = (worker_arg*)p;
   const ovr_oracle_scene* s = w->fc->s;
   memset(&w->cnt, 0, sizeof(w->cnt));
-  if (w->sparse_xy) {
-    for (int64_t i = w->tid; i < w->n_sparse; i += w->nthreads)
-      render_pixel(w->fc, w->sparse_xy[2 * i], w->sparse_xy[2 * i + 1], w->frame_index, w->frame_accumulation, w->accum,
-                   w->out_rgba, w->out_grad, &w->cnt);
-    return NULL;
-  }
   const int tw = s->tile_w > 0 ? s->tile_w : s->width, th = s->tile_h > 0 ? s->tile_h : s->height;
   const int tiles_x = (s->width + tw - 1) / tw;
   const int world = s->world > 0 ? s->world : 1;
+  if (w->sparse_xy) { /* the sparse pixel list, restricted to this rank's tiles when the image is sharded */
+    for (int64_t i = w->tid; i < w->n_sparse; i += w->nthreads) {
+      const int ix = w->sparse_xy[2 * i], iy = w->sparse_xy[2 * i + 1];
+      if (world > 1 && ovr_oracle_tile_owner(ix / tw, iy / th, tiles_x, world) != s->rank) continue;
+      render_pixel(w->fc, ix, iy, w->frame_index, w->frame_accumulation, w->accum, w->out_rgba, w->out_grad, &w->cnt);
+    }
+    return NULL;
+  }
   /* pixels are interleaved over the threads (any split gives the same frame: pixels are independent) */
   const long long npix = (long long)s->width * s->height;
   for (long long i = w->tid; i < npix; i += w->nthreads) {
