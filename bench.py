@@ -120,7 +120,10 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     dist = None
-    if world > 1:
+    # OVR_BENCH_FORCE_GATHER=1 (under torch.distributed.run with ONE rank): take the N > 1 frame path - process group, image shard of
+    # world 1, pack, RCCL gather on the communication stream, scatter - on a single GPU; a smoke test of the RCCL plumbing
+    multi = world > 1 or (os.environ.get("OVR_BENCH_FORCE_GATHER") == "1" and "RANK" in os.environ)
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # "nccl" IS RCCL on ROCm.  OVR_BENCH_BACKEND=gloo + OVR_BENCH_ONE_GPU=1 rehearse the N > 1 path on a one-GPU box
@@ -152,7 +155,7 @@ def main():
     ren.set_shading(cfg["shading"])
     ren.set_empty_space_skipping(args.skip_empty)
     ren.set_transfer_function(colors, alphas, vr)
-    if world > 1:
+    if multi:
         ren.set_image_shard(rank, world, args.tile, args.tile)
     scene = ovr.Scene(volume=vol, transfer_function=None, volume_sampling_rate=cfg["rate"])
     ren.init(scene, ovr.Camera(*cam))
@@ -167,11 +170,11 @@ def main():
     torch.cuda.empty_cache()
 
     gatherer = None
-    if world > 1:
+    if multi:
         gatherer = ovr.tiles.TileGather(ren, W, H, args.tile, rank, world, dev)
 
     def step():
-        if world == 1:
+        if not multi:
             ren.render()          # blocking, like the reference's render() (optix7/device.cpp:35-43)
         else:
             # one frame = march/shade/composite of this rank's tiles, then the gather of all tiles to rank 0.  The gather of
@@ -205,11 +208,19 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if multi and world == 1:
+        # forced single-rank gather: the gathered frame must be the renderer's own frame
+        fb = ovr.FrameBufferData()
+        ren.mapframe(fb, device=True)
+        ok = bool(torch.equal(gatherer.frame, fb.rgba.data()))
+        print(f"[bench] forced gather on one rank over '{dist.get_backend()}': gathered frame == rendered frame: {ok}", file=sys.stderr)
+        if not ok:
+            raise SystemExit("gathered frame differs from the rendered frame")
 
     # extra leg (N = 1): the same frames with empty-space skipping over the reference's macrocell grids; reported
     # beside the headline, never as `value`.  Same number of accumulated frames after a reset, so the frames must be equal bit for bit
     skip_leg = None
-    if world == 1 and not args.skip_empty and not args.no_skip_leg:
+    if not multi and not args.skip_empty and not args.no_skip_leg:
         fb = ovr.FrameBufferData()
         ren.set_camera(*cam)   # any camera commit resets the accumulation (device_impl.cpp:125-144)
         ren.commit()
