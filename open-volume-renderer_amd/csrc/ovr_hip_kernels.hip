@@ -455,8 +455,9 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
 // ------------------------------------------------------------------------------------------------------------------
 // the ray-march kernels
 //
-// Work decomposition: one lane per pixel, one wave64 per 8x8 pixel tile, four waves per workgroup.
-//  * primary march: K samples per round, all their voxel loads in flight before the first is consumed.
+// Work decomposition: four lanes per ray (a quad = 4 consecutive steps), 16 rays = a 4x4 pixel tile per wave64, four waves
+// = 8x8 pixels per workgroup; workgroups are launched longest rays first (schedule_kernel).  Details at raymarch_kernel.
+//  * primary march: K instructions x 4 steps per round, all their voxel loads in flight before the first is consumed.
 //  * deferred, compacted shading (SHADE != 0): a sample whose opacity is > 0 is not shaded by its own lane; the lane
 //    pushes a 32-byte request into its wave's queue in LDS (slot = tail + prefix-of-ballot, v_mbcnt) and keeps
 //    marching - alpha does not depend on shading, so early termination is unaffected.  Requests are shaded 64 at a
@@ -466,7 +467,7 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
 //  * two ways to shade a batch:
 //      in place   (raymarch_kernel)  the wave that owns the tile shades its own batches and gets the contributions
 //                                    back with ds_bpermute.  Used when shading is off and as the reference pipeline.
-//      pooled     (march_spill_kernel -> shade_pool_kernel -> composite_kernel)  the tile's wave spills each full
+//      pooled     (raymarch_kernel<POOLED> -> shade_pool_kernel -> composite_kernel)  the tile's wave spills each full
 //                                    batch as a 2 KiB chunk into a global pool; a second, persistent kernel shades
 //                                    chunks from ALL tiles with perfect load balance (the shadow work of a frame sits in
 //                                    a few hundred tiles: in place, their waves ran alone for 10 ms of a 13 ms kernel);
@@ -476,13 +477,10 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 
-template <int SHADE> struct MarchCfg;
-template <> struct MarchCfg<0> { static constexpr int K = 4, QCAP = 0, KS = 1; };
-template <> struct MarchCfg<1> { static constexpr int K = 3, QCAP = 256, KS = 1; };
 #ifndef OVR_SHADOW_K
 #define OVR_SHADOW_K 4
 #endif
-template <> struct MarchCfg<2> { static constexpr int K = 3, QCAP = 256, KS = OVR_SHADOW_K; };
+constexpr int kShadowTaps = OVR_SHADOW_K; // shadow-march taps in flight per lane
 // chunks a tile reserves at a time: consecutive chunks of one tile are shaded by ONE workgroup, one chunk per wave
 // (L1/L2 reuse: measured 2.4 -> 1.5 ms for the shading kernel at C3; 8 / 16 / 32 are slower - imbalance)
 constexpr int kRun = 4;
@@ -633,7 +631,7 @@ __device__ __forceinline__ void shade_request(const RayMarchParams& P, const Vol
                          fmaf(n_w.x, m[2], fmaf(n_w.y, m[5], n_w.z * m[8]))));
   }
   float shadow = 0.f;
-  if (SHADE == 2) shadow = march_shadow<VT, AM, MarchCfg<2>::KS, SKIP>(vc, tf, mc, pos, n_shadow, n_shadow_skipped);
+  if (SHADE == 2) shadow = march_shadow<VT, AM, kShadowTaps, SKIP>(vc, tf, mc, pos, n_shadow, n_shadow_skipped);
   const float cosNL = fabsf(dot3(mc.light, n_w));
   const float shade = 0.5f + 0.5f * cosNL * 2.f * (1.f - shadow); // shaders_raymarching.cu:156-157
   const float tr = r.tr;
