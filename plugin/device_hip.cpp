@@ -82,6 +82,11 @@ public:
     check(ovr_hip_set_volume(h, v.data->data(), OVR_HIP_MEM_HOST, (int)v.data->type, dims, origin, spacing));
     check(ovr_hip_set_volume_sampling_rate(h, current_scene.volume_sampling_rate)); // device_impl.cpp:298
     check(ovr_hip_set_shading(h, OVR_HIP_SHADE_FULL));                             // what the reference's marcher does
+    // The reference builds its macrocell grids for every volume / transfer function (accel/sp_singlemc.cu) but only its path
+    // tracer walks them; here the ray marcher skips empty space with them - the frames are bit-identical, so the drop-in
+    // device has it on (OVR_HIP_SKIP_EMPTY=0 switches it off, e.g. to count every sample like the reference)
+    const char* skip = std::getenv("OVR_HIP_SKIP_EMPTY");
+    check(ovr_hip_set_empty_space_skipping(h, (skip && skip[0] == '0') ? 0 : 1));
     commit();
   }
 
