@@ -794,6 +794,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
   // empty-space skipping, neither does one whose rays only cross empty macrocells.
   ShadeReq* const queue = reinterpret_cast<ShadeReq*>(lds_raw) + (size_t)wave * (QCAP > 0 ? QCAP : 1);
   TfConsts tf;
+  float pro_first = FLT_MAX, pro_last = -FLT_MAX; // skipping, spp == 1: the ray's skip interval, found here once
   {
     bool need = active;
     if (P.spp == 1 && active) { // spp == 1: the (unjittered) ray is known - test it
@@ -804,9 +805,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
       const f3 oo0 = to_object(mc, ld3(P.cam_pos)), od0 = mk3(d0.x * mc.inv_scale.x, d0.y * mc.inv_scale.y, d0.z * mc.inv_scale.z);
       need = intersect_unit_box(a0, b0, oo0, od0);
       if (SKIP && need) { // skipping: a ray that meets no occupied macrocell never fetches a voxel or a TF entry either
-        float f0, l0;
-        skip_interval(vc, oo0, od0, a0, b0, sub, true, f0, l0);
-        need = f0 <= l0;
+        skip_interval(vc, oo0, od0, a0, b0, sub, true, pro_first, pro_last);
+        need = pro_first <= pro_last;
       }
     }
     if (__syncthreads_or(need ? 1 : 0)) {
@@ -894,7 +894,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
     bool live = active && intersect_unit_box(t0, t1, oo, od);
     if (active && owner) ++n_rays;
     float skip_first = -FLT_MAX, skip_last = FLT_MAX; // samples outside [skip_first, skip_last] are in empty macrocells
-    if (SKIP) skip_interval(vc, oo, od, t0, t1, sub, live, skip_first, skip_last);
+    if (SKIP) {
+      if (P.spp == 1) { skip_first = pro_first; skip_last = pro_last; } // same ray, same [t0, t1] as in the prologue
+      else skip_interval(vc, oo, od, t0, t1, sub, live, skip_first, skip_last);
+    }
     float tx = t0, ty = fminf(t1, t0 + mc.step);
     pend = 0;
 
