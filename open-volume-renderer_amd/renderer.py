@@ -319,6 +319,12 @@ class DeviceHIP:
             return torch.as_tensor(_DevicePtr(ptr.value, (h, w, 4), typestr="|u1"), device=torch.device("cuda", self.device_id))
         return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(h, w, 4))
 
+    def save_image(self, path, flip_vertical=True):
+        """ovr::save_image of the reference (imageio.cpp:264-284: image_to_rgba8, rows flipped on write, PNG) for the
+        current frame; the 8-bit conversion runs on the GPU (mapframe_rgba8), Pillow writes the file."""
+        from PIL import Image
+        Image.fromarray(np.array(self.mapframe_rgba8(flip_vertical=flip_vertical), copy=True), "RGBA").save(path)
+
     # ---- getters ------------------------------------------------------------------------------------------------
     @property
     def render_time(self):

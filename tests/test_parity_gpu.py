@@ -369,6 +369,13 @@ def test_mapframe_rgba8_equals_reference_conversion(ovr, oracle, hip_renderer_fa
         assert np.array_equal(got.reshape(want.shape), want)
         dev = ren.mapframe_rgba8(flip_vertical=flip, device=True)
         assert np.array_equal(dev.cpu().numpy().reshape(want.shape), want)
+    # save_image: what renderbatch's ovr::save_image writes for this frame (flipped rows)
+    from PIL import Image
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        ren.save_image(os.path.join(d, "frame.png"))
+        png = np.asarray(Image.open(os.path.join(d, "frame.png")).convert("RGBA"))
+    assert np.array_equal(png, oracle.rgba8(rgba, flip=True))
 
 
 def test_state_changes_on_one_renderer(ovr, oracle, hip_renderer_factory):
