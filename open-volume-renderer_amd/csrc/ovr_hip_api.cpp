@@ -438,17 +438,23 @@ int build_schedule_list(ovr_hip_renderer* r)
   if (bw > 0xffff || bh > 0xffff) return fail(OVR_HIP_EINVAL, "[hip] framebuffer larger than 524280 pixels on a side");
   std::vector<unsigned int> list;
   list.reserve((size_t)bw * bh / (size_t)std::max(1, s.world) + 64);
-  for (int by = 0; by < bh; ++by)
-    for (int bx = 0; bx < bw; ++bx) {
-      bool mine = s.world <= 1;
-      if (!mine) {
-        const int tx0 = (bx * 8) / s.tw, tx1 = std::min(bx * 8 + 7, W - 1) / s.tw;
-        const int ty0 = (by * 8) / s.th, ty1 = std::min(by * 8 + 7, H - 1) / s.th;
-        for (int ty = ty0; ty <= ty1 && !mine; ++ty)
-          for (int tx = tx0; tx <= tx1 && !mine; ++tx) mine = ((tx + ty) % s.world) == s.rank;
+  // listed supertile by supertile (4x4 blocks = 32x32 pixels, row-major inside): 16 consecutive entries are a compact square,
+  // which the schedule kernel keeps together on one XCD
+  const int sw = (bw + 3) / 4, sh = (bh + 3) / 4;
+  for (int sy = 0; sy < sh; ++sy)
+    for (int sx = 0; sx < sw; ++sx)
+      for (int k = 0; k < 16; ++k) {
+        const int bx = sx * 4 + (k & 3), by = sy * 4 + (k >> 2);
+        if (bx >= bw || by >= bh) continue;
+        bool mine = s.world <= 1;
+        if (!mine) {
+          const int tx0 = (bx * 8) / s.tw, tx1 = std::min(bx * 8 + 7, W - 1) / s.tw;
+          const int ty0 = (by * 8) / s.th, ty1 = std::min(by * 8 + 7, H - 1) / s.th;
+          for (int ty = ty0; ty <= ty1 && !mine; ++ty)
+            for (int tx = tx0; tx <= tx1 && !mine; ++tx) mine = ((tx + ty) % s.world) == s.rank;
+        }
+        if (mine) list.push_back((unsigned int)bx | ((unsigned int)by << 16));
       }
-      if (mine) list.push_back((unsigned int)bx | ((unsigned int)by << 16));
-    }
   if (r->d_sched_src) HIP_TRY(hipFree(r->d_sched_src));
   if (r->d_sched) HIP_TRY(hipFree(r->d_sched));
   r->d_sched_src = r->d_sched = nullptr;

@@ -1357,13 +1357,48 @@ __global__ __launch_bounds__(1024) void schedule_kernel(const RayMarchParams P, 
     for (int c = kSchedClasses - 1; c >= 0; --c) { cursor[c] = at; at += count[c]; }
   }
   __syncthreads();
-  // 1024 entries at a time, in list order: inside a class the blocks stay within 1024 slots of their image order
-  // (neighbouring blocks run at about the same time and share their bricks in L2 / Infinity Cache)
-  for (unsigned int c = 0; c < n; c += 1024u) {
-    const unsigned int i = c + threadIdx.x;
-    if (i < n) {
-      const unsigned int e = src[i];
-      dst[atomicAdd(&cursor[schedule_class(P, mc, e)], 1u)] = e;
+  // Stable scatter, 1024 entries at a time: inside a class the blocks keep their list order (the host lists them supertile
+  // by supertile, 4x4 blocks = 32x32 pixels), so blocks that run at the same time are compact squares of the image and
+  // share their bricks in L2 / Infinity Cache.
+  // OVR_SCHED_XCD=1 (experiment, off): transpose the final slot inside aligned groups of 128 so that the 16 blocks of a
+  // supertile land on ONE XCD (workgroup s -> XCD s % 8, each XCD has its own L2): sorted position g*128 + x*16 + j -> slot
+  // g*128 + j*8 + x.  Measured: C3 march 1.63 instead of 1.57 ms - the march is bound by L1 lookups, not by L2 misses.
+#ifndef OVR_SCHED_XCD
+#define OVR_SCHED_XCD 0
+#endif
+  __shared__ unsigned int wave_count[16][kSchedClasses];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned int n_full = n & ~127u; // the transposition is applied to whole groups only
+  for (unsigned int c0 = 0; c0 < n; c0 += 1024u) {
+    for (int k = threadIdx.x; k < 16 * kSchedClasses; k += 1024) (&wave_count[0][0])[k] = 0u;
+    __syncthreads();
+    const unsigned int i = c0 + threadIdx.x;
+    const bool valid = i < n;
+    const unsigned int e = valid ? src[i] : 0u;
+    const unsigned int cls = valid ? schedule_class(P, mc, e) : 0u;
+    // rank among the lanes of this wave with the same class (lower lanes first), wave totals to LDS
+    unsigned int rank = 0u;
+    unsigned long long todo = __ballot(valid);
+    while (todo != 0ull) {
+      const int leader = __builtin_ctzll(todo);
+      const unsigned int lc = (unsigned int)__builtin_amdgcn_readlane((int)cls, leader);
+      const unsigned long long same = __ballot(valid && cls == lc);
+      if (valid && cls == lc) rank = (unsigned int)__popcll(same & ((1ull << lane) - 1ull));
+      if (lane == leader) wave_count[wave][lc] = (unsigned int)__popcll(same);
+      todo &= ~same;
+    }
+    __syncthreads();
+    // exclusive prefix over the 16 waves, per class; the class cursor moves on by the chunk's total
+    if (threadIdx.x < kSchedClasses) {
+      unsigned int run = cursor[threadIdx.x];
+      for (int w = 0; w < 16; ++w) { const unsigned int t = wave_count[w][threadIdx.x]; wave_count[w][threadIdx.x] = run; run += t; }
+      cursor[threadIdx.x] = run;
+    }
+    __syncthreads();
+    if (valid) {
+      unsigned int pos = wave_count[wave][cls] + rank;
+      if (OVR_SCHED_XCD && pos < n_full) pos = (pos & ~127u) | ((pos & 15u) << 3) | ((pos >> 4) & 7u);
+      dst[pos] = e;
     }
     __syncthreads();
   }
