@@ -10,10 +10,15 @@ of all ranks per second of wall time, with the volume already resident in HBM.  
 into tiles dealt over the ranks (one process per GPU, volume replicated) and every step ends with the gather of the
 tiles to rank 0 over RCCL - total work is fixed, so scaling is "strong".
 
-Prints ONE JSON line on rank 0."""
+`python bench.py --gpus N` starts its own N ranks (a child `python -m torch.distributed.run`, before this process touches
+the GPU); under an external launcher (WORLD_SIZE set) it is one of the ranks.  Prints ONE JSON line on rank 0."""
 import argparse
+import hashlib
+import itertools
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,13 +37,18 @@ CONFIGS = {
                workload="2048^3 u16 volume (native u16 in HBM), 1920x1080, gradient shading + shadow march + ERT"),
     "c1": dict(n=256, dtype="uint8", width=512, height=512, shading=2, tf="sparse", cam="oblique", rate=1.0, spp=1,
                workload="256^3 u8 volume, 512x512 (the sample-scene shape of BASELINE C1; renderbatch defaults)"),
-    "c5": dict(n=1024, dtype="float32", width=3840, height=2160, shading=2, tf="sparse", cam="oblique", rate=1.0, spp=4,
-               workload="1024^3 f32 volume, 3840x2160, 4 jittered samples per pixel per frame, progressive accumulation (16 frames = 64 spp)"),
+    "c5": dict(n=1024, dtype="float32", width=3840, height=2160, shading=2, tf="sparse", cam="oblique", rate=1.0, spp=1, jitter="blue",
+               workload="1024^3 f32 volume, 3840x2160, progressive: every step is one frame of 1 blue-noise-jittered sample per pixel, "
+                        "accumulated (64 steps = the 64-spp image; slice = frame % 64 of the noise tile)"),
+    "c5tea": dict(n=1024, dtype="float32", width=3840, height=2160, shading=2, tf="sparse", cam="oblique", rate=1.0, spp=4,
+                  workload="1024^3 f32 volume, 3840x2160, 4 TEA-jittered samples per pixel per frame (the reference's jitter), accumulated (16 steps = 64 spp)"),
     "tiny": dict(n=64, dtype="float32", width=256, height=256, shading=2, tf="sparse", cam="oblique", rate=1.0, spp=1,
                  workload="64^3 f32 volume, 256x256 (plumbing check, not a benchmark)"),
 }
 VOXEL_BYTES = {"float32": 4, "uint16": 2, "uint8": 1}
+DTYPE_NAME = {"float32": "f32", "uint16": "u16", "uint8": "u8"}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+CAMERAS = ["front", "oblique", "inside", "side", "top", "oblique_y", "oblique_z", "diagonal"]
 
 
 def algorithmic_bytes(cfg, st, pixels, accumulate=True, grad=True):
@@ -62,28 +72,91 @@ def nominal_bytes(cfg, st, pixels, accumulate=True, grad=True):
     return st["samples"] * f * tap + st["shadow_samples"] * tap + pixels * (16 + (32 if accumulate else 0) + (12 if grad else 0))
 
 
-def cpu_baseline(cfg, vol_host, colors, alphas, vr, cam, budget_s=12.0):
-    """The oracle (kind "port": this repo's CPU restatement of the reference's ray marcher - the reference's own CPU
-    device is OSPRay, which is not installed) timed on the host cores, on a bounded sample of the same workload:
-    the same scene rendered at 1/8 x 1/8 of the resolution (same camera and aspect: 1/64 of the rays)."""
+def kernels_hash():
+    """hash of the device + host sources of libovr_hip.so: a committed PMC traffic measurement is only quoted for the
+    kernels it was taken from"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "open-volume-renderer_amd", "csrc")
+    for name in ("ovr_hip_kernels.hip", "ovr_hip_kernels.h", "ovr_hip_api.cpp"):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(key):
+    """measured HBM traffic (rocprofv3 PMC: FETCH_SIZE x 2 + WRITE_SIZE, collected by tools/prof.sh + tools/traffic_json.py)
+    of this configuration - only if the committed profile was taken from the kernels that are running now"""
+    src = None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if name.endswith("_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    doc = json.load(f)
+            except (OSError, ValueError):
+                continue
+            if doc.get("kernels_hash") != kernels_hash():
+                src = src or f"null: profiles/{name} was measured for other kernels (hash {doc.get('kernels_hash')}), re-run tools/prof.sh"
+                continue
+            ent = doc.get("entries", {}).get(key)
+            if ent:
+                by_kernel = {k: (2 * kib + ent.get("write_size_kib", {}).get(k, 0)) * 1024 for k, kib in ent.get("fetch_size_kib", {}).items()}
+                return ent["traffic_bytes_per_launch"], by_kernel, f"profiles/{name} (rocprofv3 PMC of this configuration, kernels hash {doc['kernels_hash']})"
+            src = src or f"null: profiles/{name} has no entry for {key}"
+    return None, {}, src or "null: no committed PMC profile"
+
+
+def cpu_baseline(cfg, vol_host, colors, alphas, vr, cam, noise=None, budget_s=10.0):
+    """The oracle (kind "port": this repo's CPU restatement of the reference's ray marcher - the reference's own CPU device
+    is OSPRay, which is not installed) timed on the host cores on a bounded sample of the same workload: the same scene at
+    1/4 x 1/4 of the resolution (same camera and aspect: 1/16 of the rays), whole frames for >= 10 s, persistent thread
+    pool, 8x8-pixel work items.  `value` is measured doing the work the GPU does (gradient taps + shadow march only for
+    samples with opacity > 0 - bit-identical frames, tests/test_oracle_kat.py); `reference_work` is the reference's literal
+    loop (a shadow march for EVERY sample), one frame at 1/8 x 1/8."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
-    w, h = max(cfg["width"] // 8, 8), max(cfg["height"] // 8, 8)
-    sc = O.OracleScene(vol_host, colors, alphas, vr, cam, w, h, fovy=60.0, spp=cfg["spp"], rate=cfg["rate"], shading=cfg["shading"])
     cores = os.cpu_count() or 1
+    jitter = 1 if cfg.get("jitter") == "blue" else 0
+
+    def scene(div, skip):
+        w, h = max(cfg["width"] // div, 8), max(cfg["height"] // div, 8)
+        return O.OracleScene(vol_host, colors, alphas, vr, cam, w, h, fovy=60.0, spp=cfg["spp"], rate=cfg["rate"], shading=cfg["shading"],
+                             skip_zero_opacity=skip, jitter=jitter, noise=noise), w, h
+
+    sc, w, h = scene(4, True)
+    sc.render(frames=1, accumulate=False, nthreads=cores, want_grad=True)   # starts the pool, pages the volume in
     t0 = time.perf_counter()
-    frames = 0
-    cnt = None
+    frames, cnt = 0, None
     while True:
         _, _, cnt = sc.render(frames=1, accumulate=False, nthreads=cores, want_grad=True)
         frames += 1
-        if time.perf_counter() - t0 > budget_s or frames >= 256:   # 10-30 s of CPU work, whole frames
+        if time.perf_counter() - t0 > budget_s or frames >= 4096:
             break
     dt = time.perf_counter() - t0
-    return {"value": cnt.samples * frames / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "fps_equivalent_full_frame": frames / dt / 64.0,
-            "sample": f"{frames} frame(s) of the same scene at {w}x{h} (1/64 of the {cfg['width']}x{cfg['height']} rays), "
-                      f"{cores} host threads, {dt:.1f} s"}
+    out = {"value": cnt.samples * frames / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port", "work": "same as GPU",
+           "fps_equivalent_full_frame": frames / dt / 16.0,
+           "sample": f"{frames} frame(s) of the same scene at {w}x{h} (1/16 of the {cfg['width']}x{cfg['height']} rays), "
+                     f"{cores} host threads, {dt:.1f} s"}
+    if cfg["shading"] == 2:
+        sc2, w2, h2 = scene(8, False)
+        t1 = time.perf_counter()
+        _, _, c2 = sc2.render(frames=1, accumulate=False, nthreads=cores, want_grad=True)
+        dt2 = time.perf_counter() - t1
+        out["reference_work"] = {"value": c2.samples / dt2 / 1e6, "unit": "Msamples/s",
+                                 "sample": f"1 frame at {w2}x{h2}, shadow march for every sample like the reference's loop "
+                                           f"({c2.shadow_samples / max(c2.samples, 1):.0f} shadow iterations per sample), {dt2:.1f} s"}
+    return out
+
+
+def launch_ranks(args):
+    """parent of a multi-GPU run: start one process per GPU and wait.  Nothing here touches HIP or torch.cuda."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -92,15 +165,26 @@ def main():
     ap.add_argument("--steps", type=int, default=25)   # the reference's renderbatch times 25 frames ...
     ap.add_argument("--warmup", type=int, default=5)   # ... after 5 warm-up frames (apps/main_batch.cpp:278-289)
     ap.add_argument("--config", default=os.environ.get("OVR_BENCH_CONFIG", "c3"), choices=sorted(CONFIGS))
-    ap.add_argument("--camera", default=None, choices=["front", "oblique", "inside"])
+    ap.add_argument("--camera", default=None, choices=CAMERAS)
     ap.add_argument("--tf", default=None, choices=["sparse", "dense", "bumps"])
     ap.add_argument("--shading", type=int, default=None, choices=[0, 1, 2])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile", type=int, default=16, help="image-shard tile size in pixels (16: best balance over 8 ranks, tools/shard_balance.py)")
     ap.add_argument("--no-skip-leg", action="store_true", help="do not time the extra leg with empty-space skipping (N = 1 only)")
+    ap.add_argument("--no-views", action="store_true", help="do not time the camera x transfer-function matrix (N = 1 only)")
     ap.add_argument("--skip-empty", action="store_true", help="enable macrocell empty-space skipping (not the headline: fewer samples are fetched)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}")
+    worker(args, world)
 
+
+def worker(args, world):
     import numpy as np
     import torch
     import ovr_amd as ovr
@@ -113,12 +197,8 @@ def main():
     if args.shading is not None:
         cfg["shading"] = args.shading
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     dist = None
     # OVR_BENCH_FORCE_GATHER=1 (under torch.distributed.run with ONE rank): take the N > 1 frame path - process group, image shard of
     # world 1, pack, RCCL gather on the communication stream, scatter - on a single GPU; a smoke test of the RCCL plumbing
@@ -143,8 +223,10 @@ def main():
     n, W, H = cfg["n"], cfg["width"], cfg["height"]
     np_dtype = {"float32": np.float32, "uint16": np.uint16, "uint8": np.uint8}[cfg["dtype"]]
     vol = ovr.synth.make_volume_torch(n, dev, cfg["dtype"])
-    colors, alphas, vr = ovr.synth.make_tfn(cfg["tf"], 1024, np_dtype)
+    tfns = {cfg["tf"]: ovr.synth.make_tfn(cfg["tf"], 1024, np_dtype)}
+    colors, alphas, vr = tfns[cfg["tf"]]
     cam = ovr.synth.make_camera(cfg["cam"], n)
+    noise = ovr.synth.make_noise_tile(64) if cfg.get("jitter") == "blue" else None
 
     ren = ovr.create_renderer("hip", local_rank)
     # the call sequence of the reference's renderbatch (apps/main_batch.cpp:254-276)
@@ -155,6 +237,9 @@ def main():
     ren.set_shading(cfg["shading"])
     ren.set_empty_space_skipping(args.skip_empty)
     ren.set_transfer_function(colors, alphas, vr)
+    if noise is not None:
+        ren.set_noise_tile(noise)
+        ren.set_pixel_jitter(ovr.JITTER_BLUE_NOISE)
     if multi:
         ren.set_image_shard(rank, world, args.tile, args.tile)
     scene = ovr.Scene(volume=vol, transfer_function=None, volume_sampling_rate=cfg["rate"])
@@ -162,8 +247,9 @@ def main():
     ren.set_camera(*cam)  # fovy 60, as renderbatch ends up with (renderer.h:149-152)
     ren.set_sparse_sampling(False)
     ren.commit()
+    vinfo = ren.volume_info()
     vol_host = None
-    want_cpu = world == 1 and not args.no_cpu_baseline   # rank 0 at N = 1 only
+    want_cpu = world == 1 and not multi and not args.no_cpu_baseline   # rank 0 at N = 1 only
     if want_cpu:
         vol_host = vol.cpu().numpy() if cfg["dtype"] != "uint16" or hasattr(torch, "uint16") else vol.cpu().numpy().view(np.uint16)
     del vol
@@ -183,31 +269,61 @@ def main():
             gatherer.run()
             ren.sync()
 
-    for _ in range(args.warmup):
-        step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    tot = dict(samples=0, shaded_samples=0, shadow_samples=0, rays=0, active_pixels=0, skipped_samples=0, skipped_shadow_samples=0)
-    kernel_ms = 0.0
-    phase_ms = [0.0, 0.0, 0.0]
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        st = ren.stats()
-        for k in tot:
-            tot[k] += getattr(st, k)
-        kernel_ms += st.kernel_ms
-        phase_ms[0] += st.march_ms
-        phase_ms[1] += st.shade_ms
-        phase_ms[2] += st.composite_ms
-        last_stats = st
-    if gatherer is not None:
-        gatherer.flush()   # the last frame's tiles reach rank 0's frame inside the timed region
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    def timed_leg(steps, warmup):
+        """warmup untimed steps, then exactly `steps` steps between barrier + device-synchronise pairs"""
+        for _ in range(warmup):
+            step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tot = dict(samples=0, shaded_samples=0, shadow_samples=0, rays=0, active_pixels=0, skipped_samples=0, skipped_shadow_samples=0)
+        leg = dict(kernel_ms=0.0, phase_ms=[0.0, 0.0, 0.0], last=None)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+            st = ren.stats()
+            for k in tot:
+                tot[k] += getattr(st, k)
+            leg["kernel_ms"] += st.kernel_ms
+            leg["phase_ms"][0] += st.march_ms
+            leg["phase_ms"][1] += st.shade_ms
+            leg["phase_ms"][2] += st.composite_ms
+            leg["last"] = st
+        if gatherer is not None:
+            gatherer.flush()   # the last frame's tiles reach rank 0's frame inside the timed region
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        leg["dt"] = time.perf_counter() - t0
+        leg["tot"] = tot
+        return leg
+
+    def kernel_report(c, per_launch, ph, k_ms, pooled, traffic_by_kernel):
+        """per kernel: algorithmic bytes of the taps that kernel executes / its own mean launch duration (HIP events around
+        each kernel, recorded inside libovr_hip.so on the renderer's stream; profiles/*/kernel_stats.csv agrees)"""
+        tap = 8 * VOXEL_BYTES[c["dtype"]]
+        pixels = per_launch["active_pixels"]
+        abytes = algorithmic_bytes(c, per_launch, pixels)
+        fb_bytes = pixels * (16 + 32 + 12)
+        if pooled and c["spp"] > 1:
+            # one march/shade/composite pass per sample-per-pixel generation: the events bracket the whole sequence
+            parts = [("raymarch pipeline (%d generations of march -> shade -> composite)" % c["spp"], abytes, k_ms)]
+        elif pooled:
+            parts = [("raymarch_kernel", per_launch["samples"] * tap, ph[0]),
+                     ("shade_pool_kernel", (3 * per_launch["shaded_samples"] + per_launch["shadow_samples"]) * tap, ph[1]),
+                     ("composite_kernel", fb_bytes, ph[2])]
+        else:
+            parts = [("raymarch_kernel", abytes, ph[0])]
+        kern = {}
+        for kname, kb, kms in parts:
+            if kms > 0:
+                kern[kname] = {"ms": kms, "algorithmic_bytes_per_launch": kb, "achieved": kb / (kms * 1e-3) / 1e9,
+                               "frac": kb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_by_kernel.get(kname)}
+        dom = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
+        return kern, dom, abytes
+
+    main_leg = timed_leg(args.steps, args.warmup)
+    dt, tot, kernel_ms, phase_ms, last_stats = main_leg["dt"], main_leg["tot"], main_leg["kernel_ms"], main_leg["phase_ms"], main_leg["last"]
     if multi and world == 1:
         # forced single-rank gather: the gathered frame must be the renderer's own frame
         fb = ovr.FrameBufferData()
@@ -247,6 +363,36 @@ def main():
         ren.set_empty_space_skipping(False)
         ren.commit()
 
+    # view x transfer-function matrix (N = 1; SURVEY 8d: "both cameras and both TFs reported"): the headline cell is the timed
+    # region above, the other cells are short legs of the same renderer (3 warm-up + 10 timed frames each)
+    views = None
+    if not multi and not args.no_views and not args.skip_empty:
+        views = {}
+        for vcam, vtf in itertools.product(("front", "oblique"), ("sparse", "dense")):
+            if (vcam, vtf) == (cfg["cam"], cfg["tf"]):
+                leg, vsteps = main_leg, args.steps
+            else:
+                if vtf not in tfns:
+                    tfns[vtf] = ovr.synth.make_tfn(vtf, 1024, np_dtype)
+                ren.set_transfer_function(*tfns[vtf])
+                ren.set_camera(*ovr.synth.make_camera(vcam, n))
+                ren.commit()
+                vsteps = 10
+                leg = timed_leg(vsteps, 3)
+            pl = {k: v / vsteps for k, v in leg["tot"].items()}
+            ph = [p / vsteps for p in leg["phase_ms"]]
+            vc = dict(cfg, cam=vcam, tf=vtf)
+            kern, dom, abytes = kernel_report(vc, pl, ph, leg["kernel_ms"] / vsteps, leg["last"].pipeline == 2, {})
+            views[f"{vcam}/{vtf}"] = {
+                "ms_per_step": leg["dt"] / vsteps * 1e3, "fps": vsteps / leg["dt"], "gsamples_per_s": leg["tot"]["samples"] / leg["dt"] / 1e9,
+                "samples_per_frame": pl["samples"], "shaded_samples_per_frame": pl["shaded_samples"], "shadow_samples_per_frame": pl["shadow_samples"],
+                "phase_ms": {"march": ph[0], "shade": ph[1], "composite": ph[2]},
+                "kernel": dom, "frac": kern[dom]["frac"] if dom else None, "kernel_fracs": {k: v["frac"] for k, v in kern.items()},
+                "pipeline_frac": abytes / (leg["kernel_ms"] / vsteps * 1e-3) / 1e9 / HBM_PEAK_GBS if leg["kernel_ms"] > 0 else None}
+        ren.set_transfer_function(colors, alphas, vr)
+        ren.set_camera(*cam)
+        ren.commit()
+
     # max over ranks of the elapsed time, sum over ranks of the work
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -268,44 +414,18 @@ def main():
         # roofline of the dominant kernel (raymarch_kernel): algorithmic bytes per launch / mean launch duration
         # (HIP events recorded on the renderer's own stream around the launch, inside libovr_hip.so)
         k_ms = kernel_ms_max / steps
-        pixels_per_launch = per_step["active_pixels"] / world
         per_launch = {k: v / world for k, v in per_step.items()}
-        abytes = algorithmic_bytes(cfg, per_launch, pixels_per_launch)
+        pixels_per_launch = per_launch["active_pixels"]
         nbytes = nominal_bytes(cfg, per_launch, pixels_per_launch)
-        achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        # measured HBM traffic (rocprofv3 PMC) of this exact configuration, if a profile of it is committed under profiles/
-        traffic, traffic_by_kernel = None, {}
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                key = f"{args.config}|{cfg['cam']}|{cfg['tf']}|{cfg['shading']}|{world}"
-                ent = json.load(f).get(key)
-                if ent and not args.skip_empty:
-                    traffic = ent["traffic_bytes_per_launch"]
-                    for kname, kib in ent.get("fetch_size_kib", {}).items():
-                        traffic_by_kernel[kname] = (2 * kib + ent.get("write_size_kib", {}).get(kname, 0)) * 1024
-        except OSError:
-            pass
-        # per kernel: algorithmic bytes of the taps that kernel executes / its own mean launch duration (HIP events around
-        # each kernel, recorded inside libovr_hip.so on the renderer's stream; profiles/r01_c3/kernel_stats.csv agrees)
-        tap = 8 * VOXEL_BYTES[cfg["dtype"]]
-        fb_bytes = pixels_per_launch * (16 + 32 + 12)
+        traffic, traffic_by_kernel, traffic_source = (None, {}, "null: the empty-space skipping leg is not profiled") if args.skip_empty else \
+            load_traffic(f"{args.config}|{cfg['cam']}|{cfg['tf']}|{cfg['shading']}|{world}")
         pooled = last_stats.pipeline == 2
         ph = [p / steps for p in phase_ms]
-        kern = {}
-        if pooled and cfg["spp"] > 1:
-            # one march/shade/composite pass per sample-per-pixel generation: the events bracket the whole sequence
-            parts = [("raymarch pipeline (%d generations of march -> shade -> composite)" % cfg["spp"], abytes, k_ms)]
-        elif pooled:
-            parts = [("raymarch_kernel", per_launch["samples"] * tap, ph[0]),
-                     ("shade_pool_kernel", (3 * per_launch["shaded_samples"] + per_launch["shadow_samples"]) * tap, ph[1]),
-                     ("composite_kernel", fb_bytes, ph[2])]
-        else:
-            parts = [("raymarch_kernel", abytes, ph[0])]
-        for kname, kb, kms in parts:
-            if kms > 0:
-                kern[kname] = {"ms": kms, "algorithmic_bytes_per_launch": kb, "achieved": kb / (kms * 1e-3) / 1e9,
-                               "frac": kb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_by_kernel.get(kname)}
-        dom = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
+        kern, dom, abytes = kernel_report(cfg, per_launch, ph, k_ms, pooled, traffic_by_kernel)
+        achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        # compulsory floor: every resident brick of the volume once + the framebuffer traffic, at the HBM peak - an
+        # upper bound of the unique bytes a frame can touch; what the march alone has to read when rays are sparser than voxels
+        floor_bytes = int(vinfo.resident_bytes) + pixels_per_launch * (16 + 32 + 12)
         out = {
             "metric": "Msamples/s (primary ray-march samples after ERT); fps alongside",
             "value": tot["samples"] / dt / 1e6,
@@ -318,30 +438,39 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": DTYPE_NAME[cfg["dtype"]],
             "data": "synthetic",
             "config": {"workload": cfg["workload"], "name": args.config, "volume": f"{n}^3 {cfg['dtype']}", "image": f"{W}x{H}",
                        "transfer_function": cfg["tf"], "camera": cfg["cam"], "fovy": 60, "sampling_rate": cfg["rate"],
-                       "spp": cfg["spp"], "shading": ["none", "gradient", "gradient+shadow"][cfg["shading"]],
+                       "spp": cfg["spp"], "pixel_jitter": "blue-noise tile (synthetic 64x64x64), slice = frame % 64" if noise is not None else "RandomTEA iff spp > 1 (reference)",
+                       "shading": ["none", "gradient", "gradient+shadow"][cfg["shading"]],
                        "frame_accumulation": True, "empty_space_skipping": bool(args.skip_empty), "parallelism": f"image tiles {args.tile}x{args.tile} over {world} rank(s)"},
             "per_frame": {k: per_step[k] for k in sorted(per_step)},
             # the dominant kernel of the frame (longest mean launch); the whole pipeline and the other kernels beside it
             "roofline": {"bound": "hbm", "achieved": kern[dom]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kern[dom]["frac"], "traffic": kern[dom]["traffic"],
+                         "frac": kern[dom]["frac"], "traffic": kern[dom]["traffic"], "traffic_source": traffic_source,
                          "kernel": dom + ("" if "pipeline" in dom else " (pooled pipeline: march -> shade -> composite)" if pooled else " (in-place pipeline)"),
                          "kernel_ms": kern[dom]["ms"], "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes_per_launch"],
                          "kernels": kern,
                          "pipeline": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms,
                                       "algorithmic_bytes_per_launch": abytes,
                                       "nominal_frac_survey_F4": (nbytes / (k_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if k_ms > 0 else 0.0},
+                         "compulsory_floor_ms": floor_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
+                         "compulsory_floor_bytes": floor_bytes,
+                         "volume_resident_bytes": int(vinfo.resident_bytes),
                          "phase_ms_rank0": {"march": ph[0], "shade": ph[1], "composite": ph[2]},
                          "pool_chunks": int(last_stats.pool_chunks)},
         }
+        if multi:
+            out["rccl_ranks"] = dist.get_world_size()
+            out["backend"] = dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")
+        if views is not None:
+            out["roofline"]["views"] = views
         if skip_leg is not None:
             out["with_empty_space_skipping"] = skip_leg
         if want_cpu:
-            out["cpu_baseline"] = cpu_baseline(cfg, vol_host, colors, alphas, vr, cam)
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(cfg, vol_host, colors, alphas, vr, cam, noise)
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OVR_HIP_ABI_VERSION 4
+#define OVR_HIP_ABI_VERSION 5
 
 /* error codes */
 #define OVR_HIP_OK 0
@@ -129,6 +129,14 @@ int ovr_hip_set_shading_pipeline(ovr_hip_renderer* r, int32_t mode);
  * tracer uses them).  Samples whose cell has majorant 0 have opacity exactly 0: their voxel fetch is skipped, frames stay
  * bit-identical.  Off by default (the reference's ray marcher visits every sample). */
 int ovr_hip_set_empty_space_skipping(ovr_hip_renderer* r, int32_t enabled);
+/* extension (BASELINE C5, north_star "blue-noise jitter staged in LDS"): how the sub-pixel position of a sample is drawn.
+ * 0 (default) = the reference: RandomTEA(frame_index, pixel_index), applied iff sample_per_pixel > 1
+ * (shaders_raymarching.cu:336,351-357).  1 = blue-noise tile (ovr_hip_set_noise_tile; lookup as blue_noise.h:95-99): sample k
+ * of frame f uses slice ((f - 1) * spp + k) % 64, xi_x = tile[y % xy][x % xy][slice], xi_y = the slice shifted by half a tile
+ * in x and y; applied to EVERY sample, so 64 accumulated 1-spp frames give the 64-spp progressive image. */
+#define OVR_HIP_JITTER_TEA 0
+#define OVR_HIP_JITTER_BLUE_NOISE 1
+int ovr_hip_set_pixel_jitter(ovr_hip_renderer* r, int32_t mode);
 /* downloads the macrocell grids (for known-answer tests): dims = cells per axis; minmax = 2 floats per cell, majorant = 1 */
 int ovr_hip_get_macrocells(ovr_hip_renderer* r, int32_t dims[3], float* minmax_host, float* majorant_host, size_t capacity_cells);
 /* extension (multi-GPU): this renderer draws only the image tiles owned by `rank` of `world`;
@@ -161,12 +169,31 @@ int ovr_hip_mapframe(ovr_hip_renderer* r, int mem_kind, const float** rgba, size
  * stays valid until the next call of this function or a framebuffer resize. */
 int ovr_hip_mapframe_rgba8(ovr_hip_renderer* r, int mem_kind, int flip_vertical, const uint32_t** rgba8, size_t* bytes);
 
+/* frame output, EXR: the float -> half step of the reference's save_image(".exr") (ovr/common/imageio.cpp:15-83,
+ * 268-272: the flipped RGBA32F frame goes to tinyexr with requested_pixel_types = HALF; conversion rule
+ * extern/tinyexr/tinyexr.h:889-924 - nearest, ties away from zero) applied to the CURRENT framebuffer set on the device:
+ * W*H*4 IEEE binary16 bit patterns (R, G, B, A per pixel).  Valid until the next call or a framebuffer resize. */
+int ovr_hip_mapframe_rgba16f(ovr_hip_renderer* r, int mem_kind, int flip_vertical, const uint16_t** rgba16f, size_t* bytes);
+
 /* replaces Impl::swap (device_impl.cpp:102-111): waits for the current set's stream, flips to the other set */
 int ovr_hip_swap(ovr_hip_renderer* r);
 
 /* MainRenderer::render_time (ovr/renderer.h:87): accumulated milliseconds spent in ovr_hip_render */
 double ovr_hip_render_time_ms(const ovr_hip_renderer* r);
 int ovr_hip_get_stats(const ovr_hip_renderer* r, ovr_hip_stats* out);
+
+/* what load_from_array3d_scalar leaves behind (volume.cpp:181-191): the data range found by compute_scalar_range /
+ * cuda_scalar_range (array.cpp:27-66,92-108,297; integer-normalized for 8- and 32-bit integer volumes, raw otherwise), the
+ * transfer-function range in effect (set_value_range, volume.cpp:131-145: a range with hi < lo keeps the previous one, which is
+ * the data range after a load) and the bytes the re-laid-out volume occupies in HBM */
+typedef struct ovr_hip_volume_info {
+  int32_t dims[3];
+  int32_t value_type;      /* OVR_HIP_TYPE_* as passed to ovr_hip_set_volume */
+  uint64_t resident_bytes;
+  float data_lower, data_upper;
+  float tf_lower, tf_upper;
+} ovr_hip_volume_info;
+int ovr_hip_get_volume_info(const ovr_hip_renderer* r, ovr_hip_volume_info* out);
 
 /* multi-GPU helpers.  pack: copies this rank's tiles out of its W*H framebuffer into a compact
  * [n_owned_tiles][tile_h][tile_w][4] device buffer (the RCCL gather payload); unpack: scatters the gathered payload

@@ -18,6 +18,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 SHADE_NONE, SHADE_GRADIENT, SHADE_FULL = 0, 1, 2
 GRID_CELL_CENTRED, GRID_VERTEX_CENTRED = 0, 1
 PIPELINE_AUTO, PIPELINE_IN_PLACE, PIPELINE_POOLED = 0, 1, 2
+JITTER_TEA, JITTER_BLUE_NOISE = 0, 1
 
 
 class Stats(C.Structure):
@@ -37,6 +38,18 @@ class Stats(C.Structure):
         ("pool_chunks", C.c_uint64),
         ("skipped_samples", C.c_uint64),
         ("skipped_shadow_samples", C.c_uint64),
+    ]
+
+
+class VolumeInfo(C.Structure):
+    _fields_ = [
+        ("dims", C.c_int32 * 3),
+        ("value_type", C.c_int32),
+        ("resident_bytes", C.c_uint64),
+        ("data_lower", C.c_float),
+        ("data_upper", C.c_float),
+        ("tf_lower", C.c_float),
+        ("tf_upper", C.c_float),
     ]
 
 
@@ -80,6 +93,9 @@ SYMBOLS = {
     "ovr_hip_unpack_all_tiles": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t]),
     "ovr_hip_sparse_mask": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]),
     "ovr_hip_tea_floats": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int64]),
+    "ovr_hip_set_pixel_jitter": (C.c_int, [_H, C.c_int32]),
+    "ovr_hip_get_volume_info": (C.c_int, [_H, C.POINTER(VolumeInfo)]),
+    "ovr_hip_mapframe_rgba16f": (C.c_int, [_H, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
 }
 
 _lib = None

@@ -105,7 +105,7 @@ struct ovr_hip_renderer {
   Queued<CameraP> camera;
   Queued<TfnP> tfn;
   Queued<FocusP> focus;
-  Queued<int> spp, sparse, accumulate, shading, grid_convention, pipeline, skipping;
+  Queued<int> spp, sparse, accumulate, shading, grid_convention, pipeline, skipping, jitter;
   Queued<float> rate;
   Queued<ShardP> shard;
 
@@ -123,6 +123,8 @@ struct ovr_hip_renderer {
   unsigned char* d_mc_occupancy = nullptr; // coarse, dilated occupancy (skip intervals of the march)
   size_t mc_cells = 0;
   bool mc_ranges_valid = false, mc_majorant_valid = false;
+  float data_lower = 0.f, data_upper = 0.f; // the volume's data range as the voxel read returns it (array.cpp:297)
+  float* d_data_range = nullptr;
 
   // transfer function
   float* d_tf_color = nullptr;
@@ -138,6 +140,8 @@ struct ovr_hip_renderer {
   float* d_accum = nullptr;
   uint32_t* d_rgba8 = nullptr; // mapframe_rgba8: device and pinned host copy of the 8-bit frame
   uint32_t* h_rgba8 = nullptr;
+  uint16_t* d_rgba16f = nullptr; // mapframe_rgba16f: the half frame of the EXR writer
+  uint16_t* h_rgba16f = nullptr;
   float* d_spp_rgba = nullptr; // pooled pipeline, spp > 1: sums over the sample-per-pixel generations
   float* d_spp_grad = nullptr;
   size_t fb_pixels = 0;
@@ -198,6 +202,9 @@ int free_framebuffers(ovr_hip_renderer* r)
   if (r->d_rgba8) HIP_TRY(hipFree(r->d_rgba8));
   if (r->h_rgba8) HIP_TRY(hipHostFree(r->h_rgba8));
   r->d_rgba8 = nullptr; r->h_rgba8 = nullptr;
+  if (r->d_rgba16f) HIP_TRY(hipFree(r->d_rgba16f));
+  if (r->h_rgba16f) HIP_TRY(hipHostFree(r->h_rgba16f));
+  r->d_rgba16f = nullptr; r->h_rgba16f = nullptr;
   if (r->d_spp_rgba) HIP_TRY(hipFree(r->d_spp_rgba));
   if (r->d_spp_grad) HIP_TRY(hipFree(r->d_spp_grad));
   r->d_spp_rgba = r->d_spp_grad = nullptr;
@@ -322,6 +329,8 @@ void update_volume_params(ovr_hip_renderer* r)
   P.vol.data = r->d_volume;
 }
 
+// StructuredRegularVolume::set_value_range (volume.cpp:131-145): a valid range replaces the one in effect, an invalid one
+// (hi < lo, the default (1, -1)) keeps it - after a volume load that is the data range (array.cpp:297, volume.cpp:187-191)
 void update_tfn_range(ovr_hip_renderer* r)
 {
   RayMarchParams& P = r->P;
@@ -397,8 +406,8 @@ SparseMaskParams make_mask_params(ovr_hip_renderer* r, int frame_index, int32_t*
 
 int launch_frame(ovr_hip_renderer* r);
 
-// (re)build the macrocell grids when empty-space skipping is on: ranges once per volume, majorants per TF / range change
-int update_macrocells(ovr_hip_renderer* r, hipStream_t st)
+// the macrocell value ranges (sp.compute_value_range at load, volume.cpp:234-237): once per volume
+int update_macrocell_ranges(ovr_hip_renderer* r, hipStream_t st)
 {
   const size_t cells = (size_t)((r->vd.nx + 15) / 16) * ((r->vd.ny + 15) / 16) * ((r->vd.nz + 15) / 16);
   if (cells != r->mc_cells || !r->d_mc_minmax) {
@@ -406,6 +415,9 @@ int update_macrocells(ovr_hip_renderer* r, hipStream_t st)
     if (r->d_mc_minmax) HIP_TRY(hipFree(r->d_mc_minmax));
     if (r->d_mc_majorant) HIP_TRY(hipFree(r->d_mc_majorant));
     if (r->d_mc_occupancy) HIP_TRY(hipFree(r->d_mc_occupancy));
+    r->d_mc_minmax = r->d_mc_majorant = nullptr;
+    r->d_mc_occupancy = nullptr;
+    r->mc_cells = 0;
     HIP_TRY(hipMalloc((void**)&r->d_mc_minmax, cells * 2 * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&r->d_mc_majorant, cells * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&r->d_mc_occupancy, cells));
@@ -419,6 +431,14 @@ int update_macrocells(ovr_hip_renderer* r, hipStream_t st)
     r->mc_ranges_valid = true;
     r->mc_majorant_valid = false;
   }
+  return 0;
+}
+
+// (re)build the majorant grids when empty-space skipping is on: per TF / range change
+int update_macrocells(ovr_hip_renderer* r, hipStream_t st)
+{
+  if (int e = update_macrocell_ranges(r, st)) return e;
+  const size_t cells = r->mc_cells;
   if (!r->mc_majorant_valid) {
     // tfn.value_range / range_rcp_norm of the reference (volume.cpp:147-153) - the TF range, normalised like the data
     HIP_TRY(launch_macrocell_majorants(r->d_mc_minmax, (unsigned int)cells, r->d_tf_alpha, r->n_alpha, r->P.tf_lower, r->P.tf_upper, r->d_mc_majorant, st));
@@ -528,6 +548,11 @@ int enqueue_frame(ovr_hip_renderer* r)
   P.world = r->shard.current.world;
   P.tile_w = r->shard.current.tw;
   P.tile_h = r->shard.current.th;
+  P.jitter_mode = r->jitter.current;
+  P.jitter_noise = r->d_noise;
+  P.jitter_xy = r->noise_xy;
+  if (P.jitter_mode == 1 && !r->d_noise)
+    return fail(OVR_HIP_ESTATE, "[hip] blue-noise pixel jitter enabled but no noise tile was set (ovr_hip_set_noise_tile)");
   P.counters = r->d_counters;
   P.majorant = nullptr;
   P.occupancy = nullptr;
@@ -673,6 +698,7 @@ int ovr_hip_create(ovr_hip_renderer** out, int device_id)
     for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&r->ev[i]));
     HIP_TRY(hipMalloc((void**)&r->d_counters, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc((void**)&r->d_sparse_count, sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&r->d_data_range, 2 * sizeof(float)));
     HIP_TRY(hipHostMalloc((void**)&r->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
     return 0;
   };
@@ -704,6 +730,7 @@ void ovr_hip_destroy(ovr_hip_renderer* r)
   if (r->d_mc_occupancy) (void)hipFree(r->d_mc_occupancy);
   if (r->d_counters) (void)hipFree(r->d_counters);
   if (r->d_sparse_count) (void)hipFree(r->d_sparse_count);
+  if (r->d_data_range) (void)hipFree(r->d_data_range);
   if (r->h_counters) (void)hipHostFree(r->h_counters);
   for (int i = 0; i < 4; ++i) if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
   if (r->pool.reqs) (void)hipFree(r->pool.reqs);
@@ -789,6 +816,17 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
   r->have_volume = true;
   r->mc_ranges_valid = r->mc_majorant_valid = false;
   update_volume_params(r);
+  // load_from_array3d_scalar (volume.cpp:181-191, 234-237): the macrocell value ranges and, from them, the data range the
+  // reference finds with compute_scalar_range (array.cpp:27-66,297) - it is the transfer-function range until a valid one is set
+  if (int e = update_macrocell_ranges(r, st)) return e;
+  HIP_TRY(launch_minmax_reduce(r->d_mc_minmax, (unsigned long long)r->mc_cells, r->d_data_range, st));
+  float dr[2] = { 0.f, 0.f };
+  HIP_TRY(hipMemcpyAsync(dr, r->d_data_range, sizeof(dr), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  r->data_lower = dr[0];
+  r->data_upper = dr[1];
+  r->P.tf_lower = dr[0];
+  r->P.tf_upper = dr[1];
   update_tfn_range(r);
   r->sched_dirty = true;
   r->fb_reset = true;
@@ -859,6 +897,7 @@ OVR_SIMPLE_SETTER(ovr_hip_set_sparse_sampling, sparse, int32_t, true, "")
 OVR_SIMPLE_SETTER(ovr_hip_set_shading, shading, int32_t, v >= 0 && v <= 2, "[hip] unknown shading mode")
 OVR_SIMPLE_SETTER(ovr_hip_set_shading_pipeline, pipeline, int32_t, v >= 0 && v <= 2, "[hip] unknown shading pipeline")
 OVR_SIMPLE_SETTER(ovr_hip_set_empty_space_skipping, skipping, int32_t, true, "")
+OVR_SIMPLE_SETTER(ovr_hip_set_pixel_jitter, jitter, int32_t, v == 0 || v == 1, "[hip] unknown pixel-jitter mode")
 
 int ovr_hip_set_focus(ovr_hip_renderer* r, float cx, float cy, float scale, float base_noise)
 {
@@ -937,6 +976,7 @@ int ovr_hip_commit(ovr_hip_renderer* r)
   if (r->accumulate.update()) r->fb_reset = true; // :185-188
   if (r->rate.update()) r->fb_reset = true;       // :190-196
   if (r->shading.update()) r->fb_reset = true;
+  if (r->jitter.update()) r->fb_reset = true;
   (void)r->pipeline.update(); // both pipelines produce the same frame: no accumulation reset
   (void)r->skipping.update(); // skipping does not change the frame either
   if (r->shard.update()) {
@@ -1030,6 +1070,43 @@ int ovr_hip_mapframe_rgba8(ovr_hip_renderer* r, int mem_kind, int flip_vertical,
   return 0;
 }
 
+int ovr_hip_mapframe_rgba16f(ovr_hip_renderer* r, int mem_kind, int flip_vertical, const uint16_t** rgba16f, size_t* bytes)
+{
+  if (!r || !rgba16f || !bytes) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_mapframe_rgba16f: null argument");
+  if (mem_kind != OVR_HIP_MEM_DEVICE && mem_kind != OVR_HIP_MEM_HOST) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_mapframe_rgba16f: bad mem_kind");
+  if (int e = set_device(r)) return e;
+  if (int e = finish_frame(r)) return e;
+  const size_t n = r->fb_pixels;
+  *rgba16f = nullptr;
+  *bytes = 0;
+  if (n == 0) return 0;
+  hipStream_t st = r->stream();
+  if (!r->d_rgba16f) HIP_TRY(hipMalloc((void**)&r->d_rgba16f, n * 4 * sizeof(uint16_t)));
+  HIP_TRY(launch_rgba16f(r->d_rgba[r->cur], r->d_rgba16f, r->fbsize.current.w, r->fbsize.current.h, flip_vertical ? 1 : 0, st));
+  if (mem_kind == OVR_HIP_MEM_HOST) {
+    if (!r->h_rgba16f) HIP_TRY(hipHostMalloc((void**)&r->h_rgba16f, n * 4 * sizeof(uint16_t), hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(r->h_rgba16f, r->d_rgba16f, n * 4 * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  *rgba16f = mem_kind == OVR_HIP_MEM_HOST ? r->h_rgba16f : r->d_rgba16f;
+  *bytes = n * 4 * sizeof(uint16_t);
+  return 0;
+}
+
+int ovr_hip_get_volume_info(const ovr_hip_renderer* r, ovr_hip_volume_info* out)
+{
+  if (!r || !out) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_get_volume_info: null argument");
+  if (!r->have_volume) return fail(OVR_HIP_ESTATE, "[hip] ovr_hip_get_volume_info: no volume was set");
+  out->dims[0] = r->vd.nx; out->dims[1] = r->vd.ny; out->dims[2] = r->vd.nz;
+  out->value_type = r->value_type;
+  out->resident_bytes = (uint64_t)r->volume_bytes;
+  out->data_lower = r->data_lower;
+  out->data_upper = r->data_upper;
+  out->tf_lower = r->P.tf_lower;
+  out->tf_upper = r->P.tf_upper;
+  return 0;
+}
+
 int ovr_hip_swap(ovr_hip_renderer* r)
 {
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
@@ -1081,6 +1158,11 @@ int ovr_hip_pack_tiles(ovr_hip_renderer* r, float* dst, size_t dst_bytes)
 {
   if (!r || !dst) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_pack_tiles: null argument");
   if (int e = set_device(r)) return e;
+  // A frame of the pooled pipeline may still have to be rendered again (request-pool overflow: nothing was written to the
+  // framebuffer and only the host can grow the pool): resolve it before its tiles are packed.  The wait that costs moves
+  // here from the caller's ovr_hip_sync; the gather enqueued after the pack still overlaps the next frame.
+  if (r->async_pending && r->P.pool.reqs)
+    if (int e = finish_frame(r)) return e;
   const ShardP& s = r->shard.current;
   const int W = r->fbsize.current.w, H = r->fbsize.current.h;
   const size_t need = (size_t)count_owned_tiles(W, H, s.tw, s.th, s.rank, s.world) * s.tw * s.th * 4 * sizeof(float);

@@ -83,6 +83,10 @@ struct RayMarchParams {
   // sparse sampling: compacted (x,y) list + device-side count (2 * pixels), null in dense mode
   const int32_t* sparse_xy;
   const unsigned long long* sparse_count;
+  // pixel jitter: 0 = RandomTEA iff spp > 1 (the reference), 1 = blue-noise tile for every sample (jitter_noise: the noise
+  // tile stored [t][y][x], jitter_xy its edge; see jitter_slice in ovr_hip_kernels.hip)
+  int jitter_mode, jitter_xy;
+  const float* jitter_noise;
   // counters: [0] rays [1] samples [2] shaded samples [3] shadow samples [4] active pixels [5] skipped samples [6] skipped shadow samples
   unsigned long long* counters;
   const float* majorant;        // per-macrocell max TF opacity: empty-space skipping (null = off)
@@ -131,6 +135,10 @@ hipError_t launch_macrocell_ranges(const VolumeDesc& vd, float* out_minmax, hipS
 hipError_t launch_macrocell_majorants(const float* minmax, unsigned int count, const float* alphas, int n_alpha, float vr_lo, float vr_hi, float* out,
                                       hipStream_t stream);
 
+// global (min, max) of the macrocell value ranges = the volume's data range as the device's voxel read returns it
+// (compute_scalar_range + cuda_scalar_range, array.cpp:27-66,92-108); out = 2 floats on the device
+hipError_t launch_minmax_reduce(const float* minmax, unsigned long long cells, float* out, hipStream_t stream);
+
 // coarse occupancy (one byte per 4^3 macrocells, dilated by one macrocell) for the march's per-ray skip intervals
 hipError_t launch_macrocell_coarse(const float* majorant, int nx, int ny, int nz, unsigned char* out, hipStream_t stream);
 
@@ -142,6 +150,9 @@ hipError_t launch_unpack_tiles(const float* src, float* frame, int width, int he
                                size_t rank_stride_floats, hipStream_t stream);
 // image_to_rgba8 (imageio.cpp:146-181): RGBA32F frame -> packed RGBA8, optionally flipped vertically
 hipError_t launch_rgba8(const float* rgba, uint32_t* out, int width, int height, int flip, hipStream_t stream);
+// RGBA32F frame -> RGBA half (4 x uint16 per pixel) with the float -> half rule of the reference's EXR writer
+// (imageio.cpp:15-83 via tinyexr), optionally flipped vertically (save_image passes flip = true, imageio.cpp:271)
+hipError_t launch_rgba16f(const float* rgba, uint16_t* out, int width, int height, int flip, hipStream_t stream);
 int count_owned_tiles(int width, int height, int tile_w, int tile_h, int rank, int world);
 
 } // namespace ovrhip

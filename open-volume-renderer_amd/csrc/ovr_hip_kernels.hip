@@ -9,11 +9,14 @@
 //   TEA RNG ...................... ovr/common/random/random.h:146-188
 //   sparse-sampling mask ......... ovr/common/generate_mask.cu:55-120, ovr/common/random/blue_noise.h:81-102
 //
-// Kernel shape: one lane per pixel, one wave64 per 8x8 pixel tile, four waves (16x16 pixels) per workgroup.  The
-// transfer function (colour float4 table + alpha table, 20 KiB at the shipped resolution of 1024) is staged in LDS
-// once per workgroup; the volume is read from the bricked layout described in ovr_hip_kernels.h (one 128-byte
-// line = one 3-D brick).  Built with -ffp-contract=off: every fused multiply-add below is
-// explicit so the operation order is the one the CPU oracle (oracle/ovr_oracle.c) restates.
+// Kernel shape: FOUR LANES PER RAY - the 4 lanes of a quad are 4 consecutive steps of one ray - so a wave64 marches 16 rays
+// (a 4x4-pixel tile) and a workgroup of four waves an 8x8-pixel block; workgroups run longest rays first (schedule_kernel).
+// Shaded samples become 32-byte requests that a second, persistent kernel shades from a global pool and a third kernel
+// composites in ray order (pooled pipeline), or that the tile's own wave shades (in-place pipeline).  The transfer
+// function (colour float4 table + alpha table, 20 KiB at the shipped resolution of 1024), the per-axis brick-offset tables,
+// the request queues and the blue-noise jitter of the block's pixels live in LDS; the volume is read from the bricked layout
+// described in ovr_hip_kernels.h (one 128-byte line = one 3-D brick).  Built with -ffp-contract=off: every fused
+// multiply-add below is explicit so the operation order is the one the CPU oracle (oracle/ovr_oracle.c) restates.
 #include "ovr_hip_kernels.h"
 
 #include <float.h>
@@ -81,9 +84,16 @@ typedef unsigned char u8x2_u __attribute__((ext_vector_type(2), aligned(1)));
 typedef signed char i8x2_u __attribute__((ext_vector_type(2), aligned(1)));
 
 template <int VT> struct Vox;
+// f32 brick shape (experiment switches; the default is what the A/B runs of profiles/r02_notes.md keep)
+#ifndef OVR_F32_CX
+#define OVR_F32_CX 3
+#define OVR_F32_MBX 10
+#define OVR_F32_BY 2
+#define OVR_F32_BZ 1
+#endif
 template <> struct Vox<VOX_F32> {
   typedef float T; typedef f32x2_u P;
-  static constexpr int cx = 3, mbx = 10, by = 2, bz = 1; // cells per brick in x, bricks per macro block in x, log2 brick y/z
+  static constexpr int cx = OVR_F32_CX, mbx = OVR_F32_MBX, by = OVR_F32_BY, bz = OVR_F32_BZ; // cells per brick in x, bricks per macro block in x, log2 brick y/z
   static constexpr bool kScale = false, kClamp = false;
 };
 template <> struct Vox<VOX_U16> {
@@ -114,6 +124,7 @@ template <int VT> struct BrickMap {
   static constexpr unsigned sby = V::mbx * BV, sbz = (32u >> V::by) * V::mbx * BV;
   static constexpr unsigned MV = (32u >> V::bz) * sbz;                // stored voxels per macro block
   static constexpr unsigned MCX = V::cx * V::mbx;                     // cells per macro block along x (30 or 28)
+  static_assert(BV * sizeof(typename V::T) == 128, "a brick is exactly one 128-byte L1/L2 line");
   // exact for x < 65536: q = floor(x / d) = mulhi(x, ceil(2^32 / d))
   static __host__ __device__ __forceinline__ unsigned div_cx(unsigned x) { return (unsigned)(((unsigned long long)x * ((0xffffffffull / V::cx) + 1ull)) >> 32); }
   static __host__ __device__ __forceinline__ unsigned div_mbx(unsigned b) { return (unsigned)(((unsigned long long)b * ((0xffffffffull / V::mbx) + 1ull)) >> 32); }
@@ -719,6 +730,21 @@ __device__ __forceinline__ float quad_bcast(float x) // value of lane B of this 
 }
 __device__ __forceinline__ float sel4(float a0, float a1, float a2, float a3, int sub) { return sub == 0 ? a0 : sub == 1 ? a1 : sub == 2 ? a2 : a3; }
 
+// Blue-noise pixel jitter (P.jitter_mode == 1; BASELINE C5, north_star): sample k of frame f takes slice
+// t = ((f - 1) * spp + k) % 64 of the noise tile (lookup as blue_noise.h:95-99; the tile is stored transposed, [t][y][x]):
+// xi0 = tile[t][iy % xy][ix % xy], xi1 = the same slice shifted by half a tile in x and y.  In dense mode the workgroup
+// stages the 2 x 64 variates of its 8x8 pixels for the first kJitStaged samples in LDS; later samples and sparse-mode
+// pixels read the tile directly.
+constexpr int kJitStaged = 4;
+__device__ __forceinline__ int jitter_slice(const RayMarchParams& P, int k) { return (int)((((long long)P.frame_index - 1) * P.spp + k) % 64); }
+__device__ __forceinline__ void jitter_global(const RayMarchParams& P, int ix, int iy, int k, float& x0, float& x1)
+{
+  const int xy = P.jitter_xy, h = xy >> 1;
+  const float* slice = P.jitter_noise + (size_t)jitter_slice(P, k) * xy * xy;
+  x0 = slice[(size_t)(iy % xy) * xy + (ix % xy)];
+  x1 = slice[(size_t)((iy + h) % xy) * xy + ((ix + h) % xy)];
+}
+
 // which pixel does this QUAD own?  (4x4 pixels per wave, 8x8 per workgroup; sparse mode: 64 list entries per workgroup)
 // Dense mode: workgroup s of the 1-D grid renders the 8x8 block P.schedule[s] = bx | by << 16 - the blocks this rank owns,
 // longest rays first (schedule_kernel) - compute_screen_position of the reference (shaders_common.h:394-451) is the
@@ -795,10 +821,48 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
   ShadeReq* const queue = reinterpret_cast<ShadeReq*>(lds_raw) + (size_t)wave * (QCAP > 0 ? QCAP : 1);
   TfConsts tf;
   float pro_first = FLT_MAX, pro_last = -FLT_MAX; // skipping, spp == 1: the ray's skip interval, found here once
+  const float rsx = 1.f / (float)P.width, rsy = 1.f / (float)P.height;
+  const float scx = ((float)ix + .5f) * rsx, scy = ((float)iy + .5f) * rsy;
+  // pooled: one launch per sample-per-pixel generation (P.spp_index), in place: all here.  min(P.spp, 1) is 1, but as a
+  // run-time value: with a constant trip count of 1 the compiler restructures the kernel into a schedule that keeps fewer
+  // taps in flight (126 instead of 153 VGPRs) and the C3 march takes 1.98 instead of 1.53 ms
+  const int spp = POOLED ? min(P.spp, 1) : P.spp;
+  // blue-noise jitter: the variates of this block's pixels, staged in LDS (dense mode) for the samples this launch renders
+  __shared__ float jit_lds[kJitStaged][2][64];
+  const bool jit_staged = P.jitter_mode == 1 && !P.sparse_xy;
+  if (jit_staged) {
+    const unsigned int e = P.schedule[blockIdx.x];
+    const int xy = P.jitter_xy, h = xy >> 1;
+    const int nk = min(spp, kJitStaged);
+    for (int i = threadIdx.x; i < nk * 128; i += kBlock) {
+      const int k = i >> 7, d = (i >> 6) & 1, p = i & 63;
+      const int px = (int)(e & 0xffffu) * 8 + (p & 7) + d * h, py = (int)(e >> 16) * 8 + (p >> 3) + d * h;
+      jit_lds[k][d][p] = P.jitter_noise[(size_t)jitter_slice(P, (POOLED ? P.spp_index : 0) + k) * xy * xy + (size_t)(py % xy) * xy + (px % xy)];
+    }
+    __syncthreads();
+  }
+  // the two jitter variates of sample k (k counts the samples of this launch)
+  auto jitter = [&](int k, float& x0, float& x1) {
+    if (jit_staged && k < kJitStaged) {
+      const int ray = lane >> 2;
+      const int p = ((wave >> 1) * 4 + (ray >> 2)) * 8 + (wave & 1) * 4 + (ray & 3);
+      x0 = jit_lds[k][0][p];
+      x1 = jit_lds[k][1][p];
+    }
+    else jitter_global(P, ix, iy, (POOLED ? P.spp_index : 0) + k, x0, x1);
+  };
+  bool staged; // workgroup-uniform: the offset tables and the transfer function are in LDS
   {
     bool need = active;
-    if (P.spp == 1 && active) { // spp == 1: the (unjittered) ray is known - test it
-      const float ux0 = ((float)ix + .5f) / (float)P.width - 0.5f, uy0 = ((float)iy + .5f) / (float)P.height - 0.5f;
+    if (P.spp == 1 && active) { // spp == 1: the ray is known - test it (the same expressions as the march below uses)
+      float sx0 = scx, sy0 = scy;
+      if (P.jitter_mode == 1) {
+        float j0, j1;
+        jitter(0, j0, j1);
+        sx0 += (j0 - 0.5f) * rsx;
+        sy0 += (j1 - 0.5f) * rsy;
+      }
+      const float ux0 = sx0 - 0.5f, uy0 = sy0 - 0.5f;
       const f3 c0 = ld3(P.cam_dir), h0 = ld3(P.cam_hor), v0 = ld3(P.cam_ver);
       const f3 d0 = normalize3_exact(mk3(c0.x + ux0 * h0.x + uy0 * v0.x, c0.y + ux0 * h0.y + uy0 * v0.y, c0.z + ux0 * h0.z + uy0 * v0.z));
       float a0 = 0.f, b0 = FLT_MAX;
@@ -809,7 +873,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
         need = pro_first <= pro_last;
       }
     }
-    if (__syncthreads_or(need ? 1 : 0)) {
+    staged = __syncthreads_or(need ? 1 : 0) != 0;
+    if (staged) {
       unsigned char* base = lds_raw + (size_t)kWaves * QCAP * sizeof(ShadeReq);
       const size_t tb = (stage_tables<VT, AM>(P, base, vc) + 15) & ~(size_t)15;
       stage_tf(P, base + tb, !POOLED, tf);
@@ -823,8 +888,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
   const PoolDesc& Q = P.pool;
   const unsigned int tile = blockIdx.x * kWaves + wave;
 
-  const float rsx = 1.f / (float)P.width, rsy = 1.f / (float)P.height;
-  const float scx = ((float)ix + .5f) * rsx, scy = ((float)iy + .5f) * rsy;
   const unsigned int pixel_index = (unsigned int)ix + (unsigned int)iy * (unsigned int)P.width;
   unsigned int v0 = (unsigned int)P.frame_index, v1 = pixel_index; // RandomTEA(frame_index, pixel_index)
   const f3 org = ld3(P.cam_pos), cdir = ld3(P.cam_dir), chor = ld3(P.cam_hor), cver = ld3(P.cam_ver);
@@ -832,10 +895,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
 
   float o_a = 0.f;
   f3 o_c = mk3(0, 0, 0), o_g = mk3(0, 0, 0);
-  // pooled: one launch per sample-per-pixel generation (P.spp_index), in place: all here.  min(P.spp, 1) is 1, but as a
-  // run-time value: with a constant trip count of 1 the compiler restructures the kernel into a schedule that keeps fewer
-  // taps in flight (126 instead of 153 VGPRs) and the C3 march takes 1.98 instead of 1.53 ms
-  const int spp = POOLED ? min(P.spp, 1) : P.spp;
   if (POOLED && P.spp > 1)
     for (int i = 0; i < P.spp_index; ++i) tea16(v0, v1); // RandomTEA state of this generation (random.h:146-188)
   // wave-uniform queue cursors (stream positions; slot = position & (QCAP - 1))
@@ -877,7 +936,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
 
   for (int k_spp = 0; k_spp < spp; ++k_spp) { // uniform trip count: every lane of the wave runs every round
     float sx = scx, sy = scy;
-    if (P.spp > 1) {
+    if (P.jitter_mode == 1) {
+      float j0, j1;
+      jitter(k_spp, j0, j1);
+      sx += (j0 - 0.5f) * rsx;
+      sy += (j1 - 0.5f) * rsy;
+    }
+    else if (P.spp > 1) {
       tea16(v0, v1);
       sx += ((float)v0 * OVR_TEA_TOFLOAT - 0.5f) * rsx;
       sy += ((float)v1 * OVR_TEA_TOFLOAT - 0.5f) * rsy;
@@ -891,7 +956,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
     alpha = 0.f;
     color = mk3(0, 0, 0);
     gradient = mk3(0, 0, 0);
-    bool live = active && intersect_unit_box(t0, t1, oo, od);
+    // `staged` guards the prologue's decision: a ray is only marched when its workgroup has the tables and the TF in LDS
+    bool live = active && staged && intersect_unit_box(t0, t1, oo, od);
     if (active && owner) ++n_rays;
     float skip_first = -FLT_MAX, skip_last = FLT_MAX; // samples outside [skip_first, skip_last] are in empty macrocells
     if (SKIP) {
@@ -1732,6 +1798,36 @@ hipError_t launch_macrocell_majorants(const float* minmax, unsigned int count, c
   return hipGetLastError();
 }
 
+// the volume's data range: min / max over all macrocell ranges (every voxel lies in at least one cell); fminf / fmaxf drop
+// NaN operands like the reference's std::min / std::max chain does (array.cpp:44-62)
+__global__ __launch_bounds__(1024) void minmax_reduce_kernel(const float2* __restrict__ ranges, unsigned long long cells, float* __restrict__ out)
+{
+  __shared__ float slo[16], shi[16];
+  float lo = FLT_MAX, hi = -FLT_MAX; // numeric_limits<float>::max() / lowest()
+  for (unsigned long long i = threadIdx.x; i < cells; i += 1024ull) {
+    const float2 r = ranges[i];
+    lo = fminf(lo, r.x);
+    hi = fmaxf(hi, r.y);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, off));
+    hi = fmaxf(hi, __shfl_xor(hi, off));
+  }
+  if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) { lo = fminf(lo, slo[w]); hi = fmaxf(hi, shi[w]); }
+    out[0] = lo;
+    out[1] = hi;
+  }
+}
+hipError_t launch_minmax_reduce(const float* minmax, unsigned long long cells, float* out, hipStream_t stream)
+{
+  hipLaunchKernelGGL(minmax_reduce_kernel, dim3(1), dim3(1024), 0, stream, (const float2*)minmax, cells, out);
+  return hipGetLastError();
+}
+
 // occupancy for the per-ray skip interval (skip_interval): a coarse grid of 4^3 macrocells (64^3 voxels) per entry - small
 // enough (4 KiB at 1024^3) to stay in L1 while every ray walks it.  An entry is set if any of its macrocells, or any macrocell
 // next to one of them (dilation by one macrocell), can hold a sample with opacity > 0.  The dilation is the safety margin of the
@@ -1988,6 +2084,46 @@ hipError_t launch_rgba8(const float* rgba, uint32_t* out, int width, int height,
   if (width <= 0 || height <= 0) return hipSuccess;
   dim3 grid((unsigned)((width + 63) / 64), (unsigned)((height + 3) / 4));
   hipLaunchKernelGGL(rgba8_kernel, grid, dim3(256), 0, stream, (const float4*)rgba, out, width, height, flip);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// frame output, EXR: the reference's save_image(".exr") hands the flipped RGBA32F frame to tinyexr and asks for HALF pixels
+// (ovr/common/imageio.cpp:15-83,268-272).  The conversion on the device follows tinyexr's rule, which is NOT the hardware's
+// v_cvt_f16_f32 (round to nearest even): the float mantissa is cut to 10 bits and its bit 12 rounds up (ties away from
+// zero), the carry may run into the exponent; results below the half normal range shift the significand incl. the hidden
+// bit and round by the last bit shifted out; float denormals -> signed 0, NaN -> quiet NaN 0x200, overflow -> infinity.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int exr_half_bits(float f)
+{
+  const unsigned int u = __float_as_uint(f);
+  const unsigned int sign = (u >> 16) & 0x8000u, e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
+  unsigned int h = 0u;
+  if (e == 255u) h = 0x7c00u | (m ? 0x200u : 0u);
+  else if (e != 0u) {
+    const int ne = (int)e - 112; // re-biased exponent
+    if (ne >= 31) h = 0x7c00u;
+    else if (ne > 0) h = (((unsigned int)ne << 10) | (m >> 13)) + ((m >> 12) & 1u);
+    else if (ne >= -10) {
+      const unsigned int sig = m | 0x800000u;
+      h = (sig >> (14 - ne)) + ((sig >> (13 - ne)) & 1u);
+    }
+  }
+  return sign | h;
+}
+__global__ __launch_bounds__(256) void rgba16f_kernel(const float4* __restrict__ rgba, uint2* __restrict__ out, int width, int height, int flip)
+{
+  const int ix = blockIdx.x * 64 + (threadIdx.x & 63), iy = blockIdx.y * 4 + (threadIdx.x >> 6); // output position
+  if (ix >= width || iy >= height) return;
+  const int sy = flip ? height - 1 - iy : iy;
+  const float4 v = rgba[(size_t)sy * width + ix];
+  out[(size_t)iy * width + ix] = make_uint2(exr_half_bits(v.x) | (exr_half_bits(v.y) << 16), exr_half_bits(v.z) | (exr_half_bits(v.w) << 16));
+}
+hipError_t launch_rgba16f(const float* rgba, uint16_t* out, int width, int height, int flip, hipStream_t stream)
+{
+  if (width <= 0 || height <= 0) return hipSuccess;
+  dim3 grid((unsigned)((width + 63) / 64), (unsigned)((height + 3) / 4));
+  hipLaunchKernelGGL(rgba16f_kernel, grid, dim3(256), 0, stream, (const float4*)rgba, (uint2*)out, width, height, flip);
   return hipGetLastError();
 }
 

@@ -196,6 +196,17 @@ class DeviceHIP:
         L.check(self._lib.ovr_hip_get_macrocells(self._h, dims, mm.ctypes.data_as(C.POINTER(C.c_float)), mj.ctypes.data_as(C.POINTER(C.c_float)), n))
         return mm, mj
 
+    def set_pixel_jitter(self, mode):
+        """0 = RandomTEA, applied iff spp > 1 (the reference); 1 = blue-noise tile (set_noise_tile), applied to every sample
+        of every frame - progressive accumulation with frame-indexed slices (BASELINE C5)"""
+        L.check(self._lib.ovr_hip_set_pixel_jitter(self._h, int(mode)))
+
+    def volume_info(self):
+        """dims, bytes resident in HBM, the data range found at load (array.cpp:27-66,297) and the TF range in effect"""
+        v = L.VolumeInfo()
+        L.check(self._lib.ovr_hip_get_volume_info(self._h, C.byref(v)))
+        return v
+
     def set_grid_convention(self, convention):
         L.check(self._lib.ovr_hip_set_grid_convention(self._h, int(convention)))
 
@@ -319,11 +330,29 @@ class DeviceHIP:
             return torch.as_tensor(_DevicePtr(ptr.value, (h, w, 4), typestr="|u1"), device=torch.device("cuda", self.device_id))
         return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(h, w, 4))
 
+    def mapframe_rgba16f(self, flip_vertical=True, device=False):
+        """the current frame as RGBA half (IEEE binary16 bit patterns, (H, W, 4) uint16), converted on the GPU with the float ->
+        half rule of the reference's EXR writer (imageio.cpp:15-83, tinyexr); valid until the next call."""
+        ptr, nb = C.c_void_p(), C.c_size_t()
+        L.check(self._lib.ovr_hip_mapframe_rgba16f(self._h, L.MEM_DEVICE if device else L.MEM_HOST, 1 if flip_vertical else 0, C.byref(ptr), C.byref(nb)))
+        w, h = self._fbsize
+        if device:
+            import torch
+            return torch.as_tensor(_DevicePtr(ptr.value, (h, w, 4), typestr="<i2"), device=torch.device("cuda", self.device_id))
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint16)), shape=(h, w, 4))
+
     def save_image(self, path, flip_vertical=True):
-        """ovr::save_image of the reference (imageio.cpp:264-284: image_to_rgba8, rows flipped on write, PNG) for the
-        current frame; the 8-bit conversion runs on the GPU (mapframe_rgba8), Pillow writes the file."""
-        from PIL import Image
-        Image.fromarray(np.array(self.mapframe_rgba8(flip_vertical=flip_vertical), copy=True), "RGBA").save(path)
+        """ovr::save_image of the reference (imageio.cpp:264-284) for the current frame: the extension picks the format -
+        "exr" (RGBA half, rows flipped before the write), "png" / "jpg" (image_to_rgba8, rows flipped on write).  The pixel
+        conversion runs on the GPU (mapframe_rgba16f / mapframe_rgba8), imageio.py writes the file."""
+        from . import imageio
+        ext = path.rsplit(".", 1)[-1].lower()
+        if ext == "exr":
+            imageio.save_exr(path, np.array(self.mapframe_rgba16f(flip_vertical=flip_vertical), copy=True))
+        elif ext in ("jpg", "jpeg"):
+            imageio.save_jpg(path, np.array(self.mapframe_rgba8(flip_vertical=flip_vertical), copy=True))
+        else:
+            imageio.save_png(path, np.array(self.mapframe_rgba8(flip_vertical=flip_vertical), copy=True))
 
     # ---- getters ------------------------------------------------------------------------------------------------
     @property

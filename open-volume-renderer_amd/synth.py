@@ -145,6 +145,40 @@ def make_camera(kind, n, convention="cell"):
         eye = C + 1.9 * n * d / np.linalg.norm(d)
     elif kind == "inside":
         eye = C + np.array([0.11 * n, -0.07 * n, 0.23 * n])
+    elif kind in _EXTRA_CAMERAS:   # the other axes and diagonals (layout / view-dependence measurements)
+        d, dist, up = _EXTRA_CAMERAS[kind]
+        d = np.array(d, dtype=np.float64)
+        eye = C + dist * n * d / np.linalg.norm(d)
+        return tuple(float(v) for v in eye), tuple(float(v) for v in C), up
     else:
         raise ValueError(kind)
     return tuple(float(v) for v in eye), tuple(float(v) for v in C), (0.0, 1.0, 0.0)
+
+
+_EXTRA_CAMERAS = {
+    "side": ((1.0, 0.0, 0.0), 2.65, (0.0, 1.0, 0.0)),        # rays along -x
+    "top": ((0.0, 1.0, 0.0), 2.65, (0.0, 0.0, -1.0)),        # rays along -y
+    "oblique_y": ((0.41, 0.82, 0.40), 1.9, (0.0, 0.0, 1.0)),  # y-dominant diagonal
+    "oblique_z": ((0.40, 0.41, 0.82), 1.9, (0.0, 1.0, 0.0)),  # z-dominant diagonal
+    "diagonal": ((1.0, 1.0, 1.0), 1.9, (0.0, 1.0, 0.0)),      # no dominant axis
+}
+CAMERAS = ("front", "oblique", "inside") + tuple(_EXTRA_CAMERAS)
+
+
+def make_noise_tile(xy=64, seed=7, slices=64):
+    """Synthetic blue-noise-like tile in the layout of the reference's noise files ([y][x][t], float32 in [0,1);
+    ovr/common/random/blue_noise.h:44-47,95-99; the reference embeds data/noise/*.bin, which does not travel).  Every slice
+    is white noise with its low spatial frequencies removed (toroidal FFT high-pass), rank-equalised to a uniform
+    distribution - neighbouring pixels get dissimilar values, the property the mask and the pixel jitter want."""
+    rng = np.random.default_rng(seed)
+    fy = np.fft.fftfreq(xy)[:, None]
+    fx = np.fft.fftfreq(xy)[None, :]
+    hp = 1.0 - np.exp(-(fx * fx + fy * fy) / (2.0 * 0.18 ** 2))
+    out = np.empty((xy, xy, slices), dtype=np.float32)
+    for t in range(slices):
+        w = rng.standard_normal((xy, xy))
+        v = np.fft.ifft2(np.fft.fft2(w) * hp).real
+        rank = np.empty(xy * xy, dtype=np.int64)
+        rank[np.argsort(v.ravel(), kind="stable")] = np.arange(xy * xy)
+        out[:, :, t] = ((rank + 0.5) / (xy * xy)).reshape(xy, xy).astype(np.float32)
+    return out

@@ -26,6 +26,7 @@ class Scene(C.Structure):
         ("sparse_sampling", C.c_int), ("focus_center", C.c_float * 2), ("focus_scale", C.c_float), ("base_noise", C.c_float),
         ("noise_tile", C.POINTER(C.c_float)), ("noise_xy", C.c_int),
         ("tile_w", C.c_int), ("tile_h", C.c_int), ("rank", C.c_int), ("world", C.c_int),
+        ("data_range", C.c_float * 2), ("have_data_range", C.c_int), ("pixel_jitter", C.c_int), ("skip_zero_opacity", C.c_int),
     ]
 
 
@@ -73,6 +74,12 @@ def load():
     lib.ovr_oracle_tile_owner.restype = C.c_int
     lib.ovr_oracle_macrocell_value_range.argtypes = [C.POINTER(Scene), fp]
     lib.ovr_oracle_macrocell_majorant.argtypes = [C.POINTER(Scene), fp, C.c_int, fp]
+    lib.ovr_oracle_data_range.argtypes = [C.POINTER(Scene), fp]
+    lib.ovr_oracle_jitter.argtypes = [C.POINTER(Scene), C.c_int, C.c_int, C.c_int, C.c_int, fp]
+    lib.ovr_oracle_float_to_half.argtypes = [C.c_float]
+    lib.ovr_oracle_float_to_half.restype = C.c_uint16
+    lib.ovr_oracle_half_to_float.argtypes = [C.c_uint16]
+    lib.ovr_oracle_half_to_float.restype = C.c_float
     _lib = lib
     return lib
 
@@ -86,7 +93,7 @@ class OracleScene:
 
     def __init__(self, volume, colors, alphas, value_range, camera, width, height, fovy=60.0, spp=1, rate=1.0,
                  shading=SHADE_FULL, grid_origin=(0, 0, 0), grid_spacing=(1, 1, 1), convention=GRID_CELL,
-                 sparse=False, focus=((0.5, 0.5), 0.2, 0.1), noise=None, shard=None):
+                 sparse=False, focus=((0.5, 0.5), 0.2, 0.1), noise=None, shard=None, jitter=0, skip_zero_opacity=False):
         self.lib = load()
         self.volume = np.ascontiguousarray(volume)
         self.colors = np.ascontiguousarray(colors, dtype=np.float32).ravel()
@@ -121,7 +128,19 @@ class OracleScene:
             s.rank, s.world, s.tile_w, s.tile_h = shard
         else:
             s.rank, s.world, s.tile_w, s.tile_h = 0, 1, 0, 0
+        s.pixel_jitter = int(jitter)
+        s.skip_zero_opacity = int(bool(skip_zero_opacity))
         self.s = s
+        if not (s.tfn_range[1] >= s.tfn_range[0]):   # invalid range: the data range takes its place (volume.cpp:135-142)
+            dr = (C.c_float * 2)()
+            self.lib.ovr_oracle_data_range(C.byref(s), dr)
+            s.data_range[:] = [dr[0], dr[1]]
+            s.have_data_range = 1
+
+    def data_range(self):
+        dr = (C.c_float * 2)()
+        self.lib.ovr_oracle_data_range(C.byref(self.s), dr)
+        return float(dr[0]), float(dr[1])
 
     def render(self, frames=1, accumulate=False, nthreads=0, want_grad=True):
         """renders `frames` consecutive frames (frame_index 1..frames); returns (rgba, grad, counters of the last frame)"""
@@ -218,3 +237,14 @@ def sparse_mask(frame_index, width, height, center, scale, base_noise, noise):
     n = lib.ovr_oracle_sparse_mask(out.ctypes.data_as(C.POINTER(C.c_int32)), int(frame_index), width, height, c,
                                    float(scale), float(base_noise), _fp(noise), xy)
     return out[:n].copy()
+
+
+def float_to_half(a):
+    """the reference's EXR float -> half conversion (tinyexr), elementwise; returns uint16"""
+    lib = load()
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    out = np.empty(a.shape, dtype=np.uint16)
+    fi, fo = a.ravel(), out.ravel()
+    for i in range(fi.size):
+        fo[i] = lib.ovr_oracle_float_to_half(float(fi[i]))
+    return out

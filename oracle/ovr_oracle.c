@@ -206,15 +206,39 @@ typedef struct {
   float lower, upper, scale; /* volume.cpp:131-145 */
 } tfn_range;
 
+/* compute_scalar_range (array.cpp:27-66: max from numeric_limits::lowest(), min from ::max(), std::max / std::min in array
+ * order) followed by cuda_scalar_range (array.cpp:92-108: integer types are integer_normalize<float, T>'d, floating types cast
+ * to float) on the array the device volume is created from: u16 / i16 / f64 have been converted to float by then
+ * (array.cpp:335-345), so their range is the range of the converted floats.  voxel_value() returns exactly those per-voxel
+ * values, and both conversions are monotone, so min / max of voxel_value equal the normalized min / max. */
+void ovr_oracle_data_range(const ovr_oracle_scene* s, float out[2])
+{
+  const size_t n = (size_t)s->dims[0] * (size_t)s->dims[1] * (size_t)s->dims[2];
+  float lo = FLT_MAX, hi = -FLT_MAX; /* numeric_limits<float>::max() / lowest() */
+  for (size_t i = 0; i < n; ++i) {
+    const float f = voxel_value(s, i);
+    hi = (hi < f) ? f : hi; /* std::max(v, value) */
+    lo = (f < lo) ? f : lo; /* std::min(v, value) */
+  }
+  out[0] = lo;
+  out[1] = hi;
+}
+
 static tfn_range make_tfn_range(const ovr_oracle_scene* s)
 {
   tfn_range r;
   const int dt = device_value_type(s->value_type);
-  /* volume.cpp:135-142: only when max >= min; otherwise the data range computed at load time stays (not modelled:
-     callers always pass a valid range, as every shipped scene does) */
-  r.upper = ovr_oracle_integer_normalize(s->tfn_range[1], dt);
-  r.lower = ovr_oracle_integer_normalize(s->tfn_range[0], dt);
-  r.scale = 1.f / (r.upper - r.lower);
+  if (s->tfn_range[1] >= s->tfn_range[0]) { /* volume.cpp:135-142 */
+    r.upper = ovr_oracle_integer_normalize(s->tfn_range[1], dt);
+    r.lower = ovr_oracle_integer_normalize(s->tfn_range[0], dt);
+  }
+  else { /* an invalid range (the default (1, -1)) keeps what the volume was loaded with: its data range (array.cpp:297) */
+    float dr[2] = { s->data_range[0], s->data_range[1] };
+    if (!s->have_data_range) ovr_oracle_data_range(s, dr);
+    r.lower = dr[0];
+    r.upper = dr[1];
+  }
+  r.scale = 1.f / (r.upper - r.lower); /* volume.cpp:145 */
   return r;
 }
 
@@ -423,7 +447,10 @@ static void trace_ray(const frame_consts* fc, v3 org, v3 dir, float out_rgba[4],
       if (rgba[3] > 0.f) cnt->shaded_samples++;
 
       v3 n_c = v3_make(0, 0, 0);
-      if (s->shading != OVR_ORACLE_SHADE_NONE) {
+      /* skip_zero_opacity: a sample with corrected opacity exactly 0 adds fma(tr * clamp01(x), 0, acc) == acc to colour,
+         gradient and alpha whatever its shading is (clamp01 maps NaN to 0, the colour table is finite), so its gradient
+         taps and shadow march can be left out without changing a bit of the frame */
+      if (s->shading != OVR_ORACLE_SHADE_NONE && !(s->skip_zero_opacity && !(rgba[3] > 0.f))) {
         float g[3];
         ovr_oracle_gradient(s, p, sample, g);
         const v3 gn = v3_normalize(v3_make(g[0], g[1], g[2]));
@@ -495,6 +522,17 @@ int ovr_oracle_tile_owner(int tx, int ty, int tiles_x, int world)
   return (tx + ty) % world;
 }
 
+/* blue-noise pixel jitter (BASELINE C5 / north_star): tile lookup as blue_noise.h:95-99 does it for the sparse mask,
+ * value = tile[(y % XY) * XY * T + (x % XY) * T + (slice % T)], T = 64 */
+void ovr_oracle_jitter(const ovr_oracle_scene* s, int ix, int iy, int frame_index, int k, float out[2])
+{
+  const int xy = s->noise_xy;
+  const size_t t = (size_t)((((long long)frame_index - 1) * s->spp + k) % 64);
+  const int h = xy / 2;
+  out[0] = s->noise_tile[(size_t)(iy % xy) * xy * 64 + (size_t)(ix % xy) * 64 + t];
+  out[1] = s->noise_tile[(size_t)((iy + h) % xy) * xy * 64 + (size_t)((ix + h) % xy) * 64 + t];
+}
+
 static void render_pixel(const frame_consts* fc, int ix, int iy, int frame_index, int frame_accumulation, float* accum,
                          float* out_rgba, float* out_grad, ovr_oracle_counters* cnt)
 {
@@ -509,7 +547,13 @@ static void render_pixel(const frame_consts* fc, int ix, int iy, int frame_index
   const int spp = s->spp;
   for (int k = 0; k < spp; ++k) {
     float sx = scx, sy = scy;
-    if (spp > 1) {
+    if (s->pixel_jitter == 1) { /* blue-noise tile, every sample of every frame (progressive accumulation) */
+      float r[2];
+      ovr_oracle_jitter(s, ix, iy, frame_index, k, r);
+      sx += (r[0] - 0.5f) * rsx;
+      sy += (r[1] - 0.5f) * rsy;
+    }
+    else if (spp > 1) {
       float r[2];
       ovr_oracle_tea_floats(&v0, &v1, r);
       sx += (r[0] - 0.5f) * rsx;
@@ -551,52 +595,122 @@ static void render_pixel(const frame_consts* fc, int ix, int iy, int frame_index
   }
 }
 
+/* One frame = a list of work items - 8x8-pixel blocks of the image (dense) or runs of 64 entries of the sparse pixel list -
+ * handed out through one atomic cursor to a persistent pool of threads (created on first use, kept between frames; the
+ * calling thread works too).  Pixels are independent, so any split gives the same frame. */
 typedef struct {
   const frame_consts* fc;
   int frame_index, frame_accumulation;
   float *accum, *out_rgba, *out_grad;
-  ovr_oracle_counters cnt;
-  int tid, nthreads;
   const int32_t* sparse_xy;
   int64_t n_sparse;
-} worker_arg;
+  long long n_items, next;
+  int blocks_x;
+} frame_job;
 
-static void* worker(void* p)
+static void add_counters(ovr_oracle_counters* a, const ovr_oracle_counters* b)
 {
-  worker_arg* w = (worker_arg*)p;
-  const ovr_oracle_scene* s = w->fc->s;
-  memset(&w->cnt, 0, sizeof(w->cnt));
+  a->rays += b->rays;
+  a->samples += b->samples;
+  a->shaded_samples += b->shaded_samples;
+  a->shadow_samples += b->shadow_samples;
+  a->shadow_samples_visible += b->shadow_samples_visible;
+}
+
+static void process_items(frame_job* j, ovr_oracle_counters* cnt)
+{
+  const ovr_oracle_scene* s = j->fc->s;
   const int tw = s->tile_w > 0 ? s->tile_w : s->width, th = s->tile_h > 0 ? s->tile_h : s->height;
   const int tiles_x = (s->width + tw - 1) / tw;
   const int world = s->world > 0 ? s->world : 1;
-  if (w->sparse_xy) { /* the sparse pixel list, restricted to this rank's tiles when the image is sharded */
-    for (int64_t i = w->tid; i < w->n_sparse; i += w->nthreads) {
-      const int ix = w->sparse_xy[2 * i], iy = w->sparse_xy[2 * i + 1];
-      if (world > 1 && ovr_oracle_tile_owner(ix / tw, iy / th, tiles_x, world) != s->rank) continue;
-      render_pixel(w->fc, ix, iy, w->frame_index, w->frame_accumulation, w->accum, w->out_rgba, w->out_grad, &w->cnt);
+  for (;;) {
+    const long long it = __atomic_fetch_add(&j->next, 1, __ATOMIC_RELAXED);
+    if (it >= j->n_items) break;
+    if (j->sparse_xy) { /* the sparse pixel list, restricted to this rank's tiles when the image is sharded */
+      const int64_t e = (it + 1) * 64 < j->n_sparse ? (it + 1) * 64 : j->n_sparse;
+      for (int64_t i = it * 64; i < e; ++i) {
+        const int ix = j->sparse_xy[2 * i], iy = j->sparse_xy[2 * i + 1];
+        if (world > 1 && ovr_oracle_tile_owner(ix / tw, iy / th, tiles_x, world) != s->rank) continue;
+        render_pixel(j->fc, ix, iy, j->frame_index, j->frame_accumulation, j->accum, j->out_rgba, j->out_grad, cnt);
+      }
+      continue;
     }
-    return NULL;
+    const int bx = (int)(it % j->blocks_x) * 8, by = (int)(it / j->blocks_x) * 8;
+    for (int iy = by; iy < by + 8 && iy < s->height; ++iy)
+      for (int ix = bx; ix < bx + 8 && ix < s->width; ++ix) {
+        if (world > 1 && ovr_oracle_tile_owner(ix / tw, iy / th, tiles_x, world) != s->rank) continue;
+        render_pixel(j->fc, ix, iy, j->frame_index, j->frame_accumulation, j->accum, j->out_rgba, j->out_grad, cnt);
+      }
   }
-  /* pixels are interleaved over the threads (any split gives the same frame: pixels are independent) */
-  const long long npix = (long long)s->width * s->height;
-  for (long long i = w->tid; i < npix; i += w->nthreads) {
-    const int ix = (int)(i % s->width), iy = (int)(i / s->width);
-    if (world > 1 && ovr_oracle_tile_owner(ix / tw, iy / th, tiles_x, world) != s->rank) continue;
-    render_pixel(w->fc, ix, iy, w->frame_index, w->frame_accumulation, w->accum, w->out_rgba, w->out_grad, &w->cnt);
+}
+
+#define OVR_ORACLE_MAX_THREADS 512
+static struct {
+  pthread_mutex_t frame_mtx; /* one frame at a time */
+  pthread_mutex_t mtx;
+  pthread_cond_t start, done;
+  pthread_t th[OVR_ORACLE_MAX_THREADS];
+  int n_workers;            /* pool threads (the caller is one more) */
+  unsigned long generation; /* bumped once per frame */
+  int pending;              /* workers that have not finished the current generation */
+  int quit;
+  frame_job* job;
+  ovr_oracle_counters total;
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, { 0 }, 0, 0, 0, 0, NULL, { 0, 0, 0, 0, 0 } };
+
+static void* pool_worker(void* arg)
+{
+  unsigned long seen = (unsigned long)(size_t)arg; /* the generation at the time the pool was (re)built */
+  pthread_mutex_lock(&g_pool.mtx);
+  for (;;) {
+    while (!g_pool.quit && g_pool.generation == seen) pthread_cond_wait(&g_pool.start, &g_pool.mtx);
+    if (g_pool.quit) break;
+    seen = g_pool.generation;
+    frame_job* j = g_pool.job;
+    pthread_mutex_unlock(&g_pool.mtx);
+    ovr_oracle_counters cnt;
+    memset(&cnt, 0, sizeof(cnt));
+    process_items(j, &cnt);
+    pthread_mutex_lock(&g_pool.mtx);
+    add_counters(&g_pool.total, &cnt);
+    if (--g_pool.pending == 0) pthread_cond_signal(&g_pool.done);
   }
+  pthread_mutex_unlock(&g_pool.mtx);
   return NULL;
+}
+
+static void pool_resize(int n_workers) /* called with frame_mtx held */
+{
+  if (n_workers == g_pool.n_workers) return;
+  pthread_mutex_lock(&g_pool.mtx);
+  g_pool.quit = 1;
+  pthread_cond_broadcast(&g_pool.start);
+  pthread_mutex_unlock(&g_pool.mtx);
+  for (int t = 0; t < g_pool.n_workers; ++t) pthread_join(g_pool.th[t], NULL);
+  g_pool.quit = 0;
+  g_pool.n_workers = 0;
+  for (int t = 0; t < n_workers; ++t) {
+    if (pthread_create(&g_pool.th[t], NULL, pool_worker, (void*)(size_t)g_pool.generation) != 0) break;
+    g_pool.n_workers = t + 1;
+  }
 }
 
 void ovr_oracle_render_frame(const ovr_oracle_scene* s, int frame_index, int frame_accumulation, float* accum_rgba,
                              float* out_rgba, float* out_grad, ovr_oracle_counters* counters, int nthreads)
 {
   frame_consts fc;
+  ovr_oracle_scene sc = *s;
+  if (!sc.have_data_range && !(sc.tfn_range[1] >= sc.tfn_range[0])) { /* once per frame, not once per use */
+    ovr_oracle_data_range(&sc, sc.data_range);
+    sc.have_data_range = 1;
+  }
+  s = &sc;
   make_frame_consts(s, &fc);
   if (nthreads <= 0) {
     nthreads = (int)sysconf(_SC_NPROCESSORS_ONLN);
     if (nthreads < 1) nthreads = 1;
   }
-  if (nthreads > 256) nthreads = 256;
+  if (nthreads > OVR_ORACLE_MAX_THREADS) nthreads = OVR_ORACLE_MAX_THREADS;
   int32_t* sparse = NULL;
   int64_t n_sparse = 0;
   if (s->sparse_sampling) {
@@ -604,32 +718,38 @@ void ovr_oracle_render_frame(const ovr_oracle_scene* s, int frame_index, int fra
     n_sparse = ovr_oracle_sparse_mask(sparse, frame_index, s->width, s->height, s->focus_center, s->focus_scale, s->base_noise,
                                       s->noise_tile, s->noise_xy) / 2;
   }
-  pthread_t th[256];
-  worker_arg args[256];
-  for (int t = 0; t < nthreads; ++t) {
-    args[t].fc = &fc;
-    args[t].frame_index = frame_index;
-    args[t].frame_accumulation = frame_accumulation;
-    args[t].accum = accum_rgba;
-    args[t].out_rgba = out_rgba;
-    args[t].out_grad = out_grad;
-    args[t].tid = t;
-    args[t].nthreads = nthreads;
-    args[t].sparse_xy = sparse;
-    args[t].n_sparse = n_sparse;
-    if (nthreads == 1) worker(&args[t]);
-    else pthread_create(&th[t], NULL, worker, &args[t]);
-  }
-  ovr_oracle_counters total;
-  memset(&total, 0, sizeof(total));
-  for (int t = 0; t < nthreads; ++t) {
-    if (nthreads > 1) pthread_join(th[t], NULL);
-    total.rays += args[t].cnt.rays;
-    total.samples += args[t].cnt.samples;
-    total.shaded_samples += args[t].cnt.shaded_samples;
-    total.shadow_samples += args[t].cnt.shadow_samples;
-    total.shadow_samples_visible += args[t].cnt.shadow_samples_visible;
-  }
+  frame_job job;
+  job.fc = &fc;
+  job.frame_index = frame_index;
+  job.frame_accumulation = frame_accumulation;
+  job.accum = accum_rgba;
+  job.out_rgba = out_rgba;
+  job.out_grad = out_grad;
+  job.sparse_xy = sparse;
+  job.n_sparse = n_sparse;
+  job.blocks_x = (s->width + 7) / 8;
+  job.n_items = sparse ? (n_sparse + 63) / 64 : (long long)job.blocks_x * ((s->height + 7) / 8);
+  job.next = 0;
+
+  pthread_mutex_lock(&g_pool.frame_mtx);
+  pool_resize(nthreads - 1);
+  pthread_mutex_lock(&g_pool.mtx);
+  memset(&g_pool.total, 0, sizeof(g_pool.total));
+  g_pool.job = &job;
+  g_pool.pending = g_pool.n_workers;
+  g_pool.generation++;
+  pthread_cond_broadcast(&g_pool.start);
+  pthread_mutex_unlock(&g_pool.mtx);
+  ovr_oracle_counters mine;
+  memset(&mine, 0, sizeof(mine));
+  process_items(&job, &mine);
+  pthread_mutex_lock(&g_pool.mtx);
+  while (g_pool.pending > 0) pthread_cond_wait(&g_pool.done, &g_pool.mtx);
+  add_counters(&g_pool.total, &mine);
+  const ovr_oracle_counters total = g_pool.total;
+  g_pool.job = NULL;
+  pthread_mutex_unlock(&g_pool.mtx);
+  pthread_mutex_unlock(&g_pool.frame_mtx);
   if (counters) *counters = total;
   free(sparse);
 }
@@ -650,6 +770,48 @@ void ovr_oracle_rgba8(const float* rgba, int width, int height, int flip_vertica
       for (int c = 0; c < 4; ++c) o[c] = (uint8_t)(std_clamp01(in[c]) * 255.f);
     }
   }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* float -> half of the reference's EXR output (see ovr_oracle.h)                                    */
+/* ------------------------------------------------------------------------------------------------ */
+uint16_t ovr_oracle_float_to_half(float f)
+{
+  union { float f; uint32_t u; } in;
+  in.f = f;
+  const uint32_t sign = (in.u >> 16) & 0x8000u, e = (in.u >> 23) & 0xffu, m = in.u & 0x7fffffu;
+  uint32_t h = 0;
+  if (e == 0) h = 0;                                  /* zero and float denormals */
+  else if (e == 255) h = 0x7c00u | (m ? 0x200u : 0u); /* infinity / NaN */
+  else {
+    const int ne = (int)e - 127 + 15;
+    if (ne >= 31) h = 0x7c00u;                        /* overflow */
+    else if (ne <= 0) {                               /* below the half normal range */
+      if (14 - ne <= 24) {
+        const uint32_t sig = m | 0x800000u;
+        h = sig >> (14 - ne);
+        if ((sig >> (13 - ne)) & 1u) h++;
+      }
+    }
+    else {
+      h = ((uint32_t)ne << 10) | (m >> 13);
+      if (m & 0x1000u) h++; /* the carry may reach the exponent, and infinity */
+    }
+  }
+  return (uint16_t)(sign | h);
+}
+
+float ovr_oracle_half_to_float(uint16_t h)
+{
+  const uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  union { float f; uint32_t u; } out;
+  if (e == 0) {
+    out.f = (float)m * 5.9604644775390625e-8f; /* m * 2^-24, exact */
+    out.u |= sign;
+  }
+  else if (e == 31) out.u = sign | 0x7f800000u | (m << 13);
+  else out.u = sign | ((e + 112u) << 23) | (m << 13);
+  return out.f;
 }
 
 /* ------------------------------------------------------------------------------------------------ */

@@ -82,6 +82,17 @@ typedef struct ovr_oracle_scene {
   int noise_xy;            /* 64 (blue) or 128 (STBN) */
   /* image-plane shard (multi-GPU): only pixels of tiles owned by `rank` are rendered */
   int tile_w, tile_h, rank, world;
+  /* data range of the volume as the device texture returns it (array.cpp:27-66,92-108,297): used as the transfer-function
+   * range when tfn_range is invalid (hi < lo), volume.cpp:135-142.  Filled by ovr_oracle_data_range(); have_data_range = 0
+   * makes the oracle compute it on demand. */
+  float data_range[2];
+  int have_data_range;
+  /* pixel jitter: 0 = RandomTEA, applied iff spp > 1 (the reference, shaders_raymarching.cu:351-357);
+   * 1 = blue-noise tile (this repo's progressive mode, BASELINE C5): applied to every sample, see ovr_oracle_jitter() */
+  int pixel_jitter;
+  /* 0 = shade every sample like the reference; 1 = skip gradient + shadow march of samples whose corrected opacity is
+   * exactly 0 (they contribute exactly 0; frames are bit-identical - tests/test_oracle_kat.py) - the work the GPU does */
+  int skip_zero_opacity;
 } ovr_oracle_scene;
 
 typedef struct ovr_oracle_counters {
@@ -104,6 +115,25 @@ int ovr_oracle_intersect_box(float* t0, float* t1, const float org[3], const flo
 
 /* ovr/devices/optix7/array.h:68-106 */
 float ovr_oracle_integer_normalize(float value, int value_type);
+
+/* compute_scalar_range + cuda_scalar_range (ovr/devices/optix7/array.cpp:27-66,92-108) applied to the array the device
+ * ends up with (u16 / i16 / f64 converted to float first, array.cpp:335-345): out = {lower, upper} as seeded at
+ * array.cpp:297, i.e. integer-normalized for 8- and 32-bit integers, raw otherwise */
+void ovr_oracle_data_range(const ovr_oracle_scene* s, float out[2]);
+
+/* the two jitter variates of sample k of pixel (ix, iy) in frame frame_index for pixel_jitter == 1:
+ * slice t = ((frame_index - 1) * spp + k) % 64 of the noise tile (layout blue_noise.h:95-99),
+ * xi0 = tile[iy % xy][ix % xy][t], xi1 = tile[(iy + xy/2) % xy][(ix + xy/2) % xy][t] (toroidal half-tile shift) */
+void ovr_oracle_jitter(const ovr_oracle_scene* s, int ix, int iy, int frame_index, int k, float out[2]);
+
+/* float -> half as the reference's EXR output does it (ovr/common/imageio.cpp:15-83 asks tinyexr for HALF pixels;
+ * extern/tinyexr/tinyexr.h:889-924 float_to_half_full): the mantissa is cut to 10 bits and bit 12 of the float mantissa
+ * rounds it up (nearest, ties AWAY from zero - not IEEE ties-to-even), the carry may run into the exponent (and on to
+ * infinity); results below the half normal range shift the significand incl. its hidden bit and round the same way; float
+ * denormals become signed zero; NaN becomes a quiet NaN (payload 0x200), overflow becomes infinity.
+ * Pinned against the reference's own save_exr -> load_exr round trip (tests/golden/ref_probe.json). */
+uint16_t ovr_oracle_float_to_half(float f);
+float ovr_oracle_half_to_float(uint16_t h);
 
 /* ovr/devices/optix7/shaders_common.h:186-193 + texture setup array.cpp:300-306: clamp p to [0,1]^3,
  * linear-filtered, clamp-addressed sample at normalized coordinate p (object space) */

@@ -9,6 +9,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
+#include <unistd.h>
 #include <memory>
 #include <vector>
 
@@ -16,12 +18,20 @@ using namespace ovr;
 
 // defined at global scope in ovr/common/imageio.cpp:146 (not declared in the header)
 std::shared_ptr<uint32_t> image_to_rgba8(const float* input, int width, int height, int ch, int ch_stride, bool flip_vertical);
+void load_exr(float** data, int* width, int* height, const char* filename); // ovr/common/imageio.cpp:85-103
 
 static void print_vec(const char* name, const std::vector<double>& v, bool last = false)
 {
   printf("  \"%s\": [", name);
   for (size_t i = 0; i < v.size(); ++i) printf("%s%.9g", i ? ", " : "", v[i]);
   printf("]%s\n", last ? "" : ",");
+}
+
+static void print_bits(const char* name, const std::vector<double>& v)
+{
+  printf("  \"%s\": [", name);
+  for (size_t i = 0; i < v.size(); ++i) printf("%s%.0f", i ? ", " : "", v[i]);
+  printf("],\n");
 }
 
 int main()
@@ -94,6 +104,53 @@ int main()
     print_vec("xfm_origin_scale", { origin.x, origin.y, origin.z, scale.x, scale.y, scale.z });
     print_vec("xfm_points", { 3, 4, 5, -10, 0.5, 22, 16, 24, 8.5 });
     print_vec("xfm_results", o);
+  }
+  // (5) EXR output: ovr::save_image("*.exr", vec4f*) (ovr/common/imageio.cpp:264-272: rows flipped, tinyexr asked for HALF pixels)
+  //     followed by the reference's own load_exr (imageio.cpp:85-103): what the float -> half step does to each value, as raw
+  //     IEEE bit patterns (input float bits -> bits of the float the file holds)
+  {
+    const int W = 16, H = 5;
+    std::vector<float> img(W * H * 4);
+    uint32_t state = 12345u;
+    for (int i = 0; i < W * H * 4; ++i) {
+      state = state * 1664525u + 1013904223u;
+      float v;
+      switch (i % 16) {
+      case 0: v = 1.0f + std::ldexp(1.0f, -11) * (float)(1 + 2 * ((i / 16) % 8)); break;   // exact ties between two halves
+      case 1: v = std::ldexp(1.0f, -24) * (float)(i / 16) * 0.5f; break;                   // subnormal halves and ties among them
+      case 2: v = 65504.0f + (float)(i / 16); break;                                      // up to and across the overflow tie 65520
+      case 3: v = -((float)(i / 16) * 0.37f + 0.001f); break;
+      case 4: v = std::ldexp(1.0f, -14) - std::ldexp(1.0f, -26) * (float)(i / 16); break; // around the smallest normal half
+      case 5: v = std::ldexp(1.0f, -126) * 0.5f; break;                                   // a float denormal
+      case 6: v = 2.0f - std::ldexp(1.0f, -12); break;                                    // mantissa carry into the exponent
+      case 7: v = 1.0e9f; break;
+      case 8: v = -1.0e9f; break;
+      case 9: v = 0.0f; break;
+      case 10: v = -0.0f; break;
+      default: { uint32_t b = (state >> 9) | 0x3f800000u; float f; memcpy(&f, &b, 4); v = (f - 1.0f) * ((i % 3) ? 1.0f : 300.0f); } break;
+      }
+      img[i] = v;
+    }
+    const char* path = "/tmp/ovr_ref_probe.exr";
+    fflush(stdout);
+    const int saved = dup(1);                     // save_image prints to stdout: keep the JSON clean
+    (void)freopen("/dev/null", "w", stdout);
+    ovr::save_image(std::string(path), (const vec4f*)img.data(), W, H);
+    float* back = nullptr;
+    int w = 0, h = 0;
+    load_exr(&back, &w, &h, path);
+    fflush(stdout);
+    dup2(saved, 1);
+    close(saved);
+    std::vector<double> in, outbits;
+    for (int i = 0; i < W * H * 4; ++i) { uint32_t b; memcpy(&b, &img[i], 4); in.push_back((double)b); }
+    // the file holds the FLIPPED image: un-flip so that entry i answers input i
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W * 4; ++x) { uint32_t b; memcpy(&b, &back[(size_t)(H - 1 - y) * W * 4 + x], 4); outbits.push_back((double)b); }
+    printf("  \"exr_dims\": [%d, %d, %d, %d],\n", W, H, w, h);
+    print_bits("exr_input_bits", in);
+    print_bits("exr_roundtrip_bits", outbits);
+    free(back);
   }
   // (4) ValueType numbering and sizes (ovr/scene.h:32-73) - part of the C ABI
   {

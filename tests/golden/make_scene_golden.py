@@ -1,8 +1,8 @@
 """Generates tests/golden/scenes_expected.npz from the REAL reference scene loader (oracle/_ref/ref_scene_probe, built by
-oracle/build_ref.sh from oracle/ref_scene_probe.cpp against the reference's sources) for six of the scene files the reference
-ships under data/configs (copied to tests/golden/scenes/ as input fixtures - they are data, not code).  The six cover every
-feature the shipped scenes use: uint8 / uint16 / float volumes, 3...28 colour controls, 0...4 gaussian objects, base64 alpha
-arrays, scalarMappingRange with and without the unnormalized variant, sampleDistance 0.25 and 0.05.
+oracle/build_ref.sh from oracle/ref_scene_probe.cpp against the reference's sources) for ALL scene files the reference
+ships under data/configs (21; copied to tests/golden/scenes/ as input fixtures - they are data, not code): uint8 / uint16 /
+float volumes, 3...28 colour controls, 0...4 gaussian objects, base64 alpha arrays, scalarMappingRange with and without the
+unnormalized variant, sampleDistance 0.25 and 0.05.
 Run from the repo root where the reference tree is present:  python tests/golden/make_scene_golden.py"""
 import json
 import os
@@ -13,8 +13,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = os.environ.get("OVR_ROOT", "/root/reference")
-SCENES = ["scene_bonsai.json", "scene_engine.json", "scene_skull_bone.json", "scene_heatrelease_1atm.json", "scene_vorts1.json",
-          "scene_fullbody_petct.json"]
+SCENES = sorted(f for f in os.listdir(os.path.join(REF, "data", "configs")) if f.endswith(".json")) if os.path.isdir(REF) else []
 
 
 def main():

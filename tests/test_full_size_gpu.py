@@ -233,3 +233,88 @@ def test_64bit_addressing_vs_oracle(ovr, oracle, hip_renderer_factory):
     d8 = np.abs(oracle.rgba8(frames[0], flip=False).astype(int) - oracle.rgba8(ref, flip=False).astype(int))[mask]
     assert d8.max() <= 1
     assert np.abs(frames[0] - ref)[mask].max() <= 2e-4
+
+
+def test_c4_as_named(ovr, oracle, hip_renderer_factory):
+    """BASELINE C4 as named: 2048^3 uint16 (native u16 in HBM: 11.4 G stored voxels -> the 64-bit z-table addressing mode),
+    1920x1080, reference shading.  pooled == in place == pooled + skipping bit for bit, counters conserved, and the CPU oracle
+    on the 1/64 of the frame's 64x64 tiles of one anti-diagonal (u16 is sampled as raw float: array.cpp:335-338)."""
+    import torch
+    n, size, tile = 2048, (1920, 1080), 64
+    dev = torch.device("cuda", 0)
+    vol = ovr.synth.make_volume_torch(n, dev, "uint16")
+    ref = st_ref = None
+    for pipeline, skip in ((2, False), (1, False), (2, True)):
+        ren = _setup(ovr, hip_renderer_factory(), vol, n, size, 2, pipeline=pipeline, skip=skip, dtype=np.uint16)
+        info = ren.volume_info()
+        assert info.resident_bytes > 2 ** 34 and tuple(info.dims) == (n, n, n)   # > 16 GiB: u16 with the x apron
+        ren.render()
+        f, st = _frame(ovr, ren), ren.stats()
+        if ref is None:
+            ref, st_ref = f, st
+            assert np.isfinite(f).all() and f[..., 3].min() >= 0.0 and f[..., 3].max() <= 1.0
+            assert st.rays == size[0] * size[1] and st.samples > 4e8 and st.shaded_samples > 1e6 and st.shadow_samples > 1e8
+        else:
+            assert np.array_equal(f, ref), (pipeline, skip)
+            assert st.samples + st.skipped_samples == st_ref.samples
+            assert st.shaded_samples == st_ref.shaded_samples
+            assert st.shadow_samples + st.skipped_shadow_samples == st_ref.shadow_samples
+        ren.close()
+    vol_host = vol.cpu().numpy()
+    if vol_host.dtype != np.uint16:
+        vol_host = vol_host.view(np.uint16)
+    del vol
+    torch.cuda.empty_cache()
+    colors, alphas, vr = ovr.synth.make_tfn("sparse", 1024, np.uint16)
+    cam = ovr.synth.make_camera("oblique", n)
+    # the zero-opacity shortcut (bit-identical, tests/test_oracle_kat.py) keeps the oracle at seconds for ~2000-step rays
+    sc = oracle.OracleScene(vol_host, colors, alphas, vr, cam, size[0], size[1], shading=oracle.SHADE_FULL, shard=(23, 64, tile, tile),
+                            skip_zero_opacity=True)
+    o_rgba, _, cnt = sc.render()
+    mask = np.zeros((size[1], size[0]), bool)
+    for tx, ty in ovr.tiles.owned_tiles(size[0], size[1], tile, tile, 23, 64):
+        mask[ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile] = True
+    assert mask.sum() > 30000 and cnt.samples > 1e7 and cnt.shaded_samples > 1e4
+    d8 = np.abs(oracle.rgba8(ref, flip=False).astype(int) - oracle.rgba8(o_rgba, flip=False).astype(int))[mask]
+    assert d8.max() <= 1
+    assert np.abs(ref - o_rgba)[mask].max() <= 2e-4
+
+
+def test_c5_as_named(ovr, oracle, hip_renderer_factory, c3_volume):
+    """BASELINE C5 as named: 1024^3 f32, 3840x2160, 64 progressive frames of one blue-noise-jittered sample per pixel, accumulated.
+    pooled == in place bit for bit after all 64 frames; the CPU oracle agrees on a tile subset after 2 accumulated frames."""
+    n, size, tile = 1024, (3840, 2160), 64
+    noise = ovr.synth.make_noise_tile(64)
+    frames, stats, two = [], [], None
+    for pipeline in (2, 1):
+        ren = hip_renderer_factory()
+        ren.set_noise_tile(noise)
+        ren.set_pixel_jitter(ovr.JITTER_BLUE_NOISE)
+        _setup(ovr, ren, c3_volume, n, size, 2, pipeline=pipeline, accumulate=True)
+        for i in range(64):
+            ren.render()
+            if i == 1 and two is None:
+                two = _frame(ovr, ren)
+        frames.append(_frame(ovr, ren))
+        stats.append(ren.stats())
+        ren.close()
+    a, b = stats
+    assert a.frame_index == 64 and b.frame_index == 64
+    assert np.array_equal(frames[0], frames[1])
+    assert np.isfinite(frames[0]).all() and frames[0][..., 3].max() <= 1.0 + 1e-6
+    assert (a.rays, a.samples, a.shaded_samples, a.shadow_samples) == (b.rays, b.samples, b.shaded_samples, b.shadow_samples)
+    assert a.rays == size[0] * size[1]
+    # the 64-frame image is smoother than a 2-frame one: jitter de-correlates over the slices
+    assert not np.array_equal(two, frames[0])
+    colors, alphas, vr = ovr.synth.make_tfn("sparse", 1024)
+    cam = ovr.synth.make_camera("oblique", n)
+    sc = oracle.OracleScene(c3_volume.cpu().numpy(), colors, alphas, vr, cam, size[0], size[1], shading=oracle.SHADE_FULL, jitter=1, noise=noise,
+                            shard=(47, 128, tile, tile), skip_zero_opacity=True)
+    o_rgba, _, cnt = sc.render(frames=2, accumulate=True)
+    mask = np.zeros((size[1], size[0]), bool)
+    for tx, ty in ovr.tiles.owned_tiles(size[0], size[1], tile, tile, 47, 128):
+        mask[ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile] = True
+    assert mask.sum() > 30000 and cnt.samples > 1e6
+    d8 = np.abs(oracle.rgba8(two, flip=False).astype(int) - oracle.rgba8(o_rgba, flip=False).astype(int))[mask]
+    assert d8.max() <= 1
+    assert np.abs(two - o_rgba)[mask].max() <= 2e-4

@@ -204,3 +204,95 @@ def test_shading_modes_are_nested(ovr, oracle):
     a2 = oracle_scene(oracle, case).render()[0]
     assert np.array_equal(a0[..., 3], a1[..., 3]) and np.array_equal(a1[..., 3], a2[..., 3])
     assert (a2[..., :3] <= a1[..., :3] + 1e-6).all()
+
+
+# ---- round 2: data-range fallback, blue-noise jitter, zero-opacity shortcut, thread pool, EXR half conversion ----------
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.float32, np.float64])
+def test_data_range_is_the_normalized_min_max(ovr, oracle, dtype):
+    """compute_scalar_range + cuda_scalar_range (array.cpp:27-66,92-108): integer types of 8 and 32 bits are normalized,
+    u16 / i16 / f64 are converted to float first (array.cpp:335-345) and keep raw values"""
+    case = make_case(ovr, oracle, n=12, dtype=dtype)
+    vol = case["vol"]
+    sc = oracle_scene(oracle, case)
+    lo, hi = sc.data_range()
+    vmin, vmax = vol.min(), vol.max()
+    f = np.float32
+    exp = {np.uint8: (f(vmin) / f(255), f(vmax) / f(255)),
+           np.int8: (max(f(vmin) / f(127), f(-1)), max(f(vmax) / f(127), f(-1))),
+           np.uint32: (f(vmin) / f(4294967295), f(vmax) / f(4294967295)),
+           np.int32: (max(f(vmin) / f(2147483647), f(-1)), max(f(vmax) / f(2147483647), f(-1)))}.get(dtype, (f(vmin), f(vmax)))
+    assert (f(lo), f(hi)) == (f(exp[0]), f(exp[1]))
+
+
+def test_invalid_tf_range_falls_back_to_the_data_range(ovr, oracle):
+    """volume.cpp:135-142: with hi < lo (the default (1, -1)) the range found at load time stays in effect"""
+    case = make_case(ovr, oracle, n=16, size=(24, 16))
+    sc = oracle_scene(oracle, case)
+    lo, hi = sc.data_range()
+    explicit = dict(case, vr=(lo, hi))
+    fallback = dict(case, vr=(1.0, -1.0))
+    a, _, ca = oracle_scene(oracle, explicit).render()
+    b, _, cb = oracle_scene(oracle, fallback).render()
+    assert np.array_equal(a, b) and ca.samples == cb.samples and ca.shaded_samples == cb.shaded_samples
+    other, _, _ = oracle_scene(oracle, dict(case, vr=(0.0, 1.0))).render()
+    assert not np.array_equal(a, other)   # the synthetic field does not span [0, 1] exactly
+
+
+def test_zero_opacity_shortcut_is_bit_identical(ovr, oracle):
+    """the work the GPU skips (gradient taps + shadow march of samples with opacity exactly 0) does not change a bit"""
+    for tf, shading in (("sparse", 2), ("bumps", 2), ("sparse", 1)):
+        case = make_case(ovr, oracle, n=24, tf=tf, cam="oblique", size=(40, 28), shading=shading)
+        plain, gp, cp = oracle_scene(oracle, case).render()
+        fast, gf, cf = oracle_scene(oracle, case, skip_zero_opacity=True).render()
+        assert np.array_equal(plain, fast) and np.array_equal(gp, gf)
+        assert (cp.samples, cp.shaded_samples) == (cf.samples, cf.shaded_samples)
+        if shading == 2:
+            assert cf.shadow_samples == cp.shadow_samples_visible < cp.shadow_samples
+
+
+def test_thread_pool_gives_the_same_frame_for_any_thread_count(ovr, oracle):
+    case = make_case(ovr, oracle, n=16, cam="oblique", size=(37, 23), spp=2)
+    ref, gr, cr = oracle_scene(oracle, case).render(frames=2, accumulate=True, nthreads=1)
+    for nt in (2, 5, 3, 16):   # the pool is resized between calls
+        a, g, c = oracle_scene(oracle, case).render(frames=2, accumulate=True, nthreads=nt)
+        assert np.array_equal(a, ref) and np.array_equal(g, gr)
+        assert (c.rays, c.samples, c.shaded_samples, c.shadow_samples) == (cr.rays, cr.samples, cr.shaded_samples, cr.shadow_samples)
+
+
+def test_blue_noise_jitter_lookup_and_effect(ovr, oracle):
+    import ctypes as C
+    noise = ovr.synth.make_noise_tile(16, seed=3)
+    case = make_case(ovr, oracle, n=16, cam="oblique", size=(40, 24), spp=2)
+    sc = oracle_scene(oracle, case, jitter=1, noise=noise)
+    out = (C.c_float * 2)()
+    for (ix, iy, frame, k) in [(0, 0, 1, 0), (17, 5, 1, 1), (39, 23, 3, 0), (8, 8, 40, 1)]:
+        sc.lib.ovr_oracle_jitter(C.byref(sc.s), ix, iy, frame, k, out)
+        t = ((frame - 1) * 2 + k) % 64
+        assert out[0] == noise[iy % 16, ix % 16, t] and out[1] == noise[(iy + 8) % 16, (ix + 8) % 16, t]
+    # jitter applies even with one sample per pixel, and changes from frame to frame
+    case1 = dict(case, spp=1)
+    plain, _, _ = oracle_scene(oracle, case1).render()
+    j1, _, _ = oracle_scene(oracle, case1, jitter=1, noise=noise).render()
+    assert not np.array_equal(plain, j1)
+    acc2, _, _ = oracle_scene(oracle, case1, jitter=1, noise=noise).render(frames=2, accumulate=True)
+    assert not np.array_equal(acc2, j1) and np.isfinite(acc2).all()
+
+
+def test_exr_half_conversion_rule(oracle):
+    """tinyexr's float_to_half_full (the reference's EXR pixels): nearest with ties AWAY from zero, float denormals -> 0,
+    carry into the exponent, overflow -> inf, NaN -> 0x7e00"""
+    lib = oracle.load()
+    h = lambda x: lib.ovr_oracle_float_to_half(float(np.float32(x)))
+    assert h(0.0) == 0 and h(-0.0) == 0x8000 and h(1.0) == 0x3c00 and h(-2.0) == 0xc000
+    assert h(65504.0) == 0x7bff and h(65520.0) == 0x7c00 and h(1e9) == 0x7c00   # 65520 is the tie to infinity: rounds up
+    assert h(float("inf")) == 0x7c00 and h(float("-inf")) == 0xfc00 and h(float("nan")) & 0x7fff == 0x7e00
+    assert h(1.0 + 2.0 ** -11) == 0x3c01          # exact tie between 0x3c00 and 0x3c01: away from zero (RNE would give 0x3c00)
+    assert h(1.0 + 3 * 2.0 ** -11) == 0x3c02      # tie between 0x3c01 and 0x3c02: up (RNE agrees here)
+    assert h(2.0 ** -24) == 1 and h(2.0 ** -25) == 1 and h(2.0 ** -26) == 0   # subnormal halves; half the smallest rounds up
+    assert h(1e-45) == 0                           # float denormal -> 0
+    assert h(2.0 - 2.0 ** -12) == 0x4000          # mantissa carry into the exponent
+    # round trip through half -> float is exact for every finite half
+    for bits in list(range(0, 0x7c00, 97)) + [0x7bff, 0x0001, 0x03ff, 0x0400]:
+        f = lib.ovr_oracle_half_to_float(bits)
+        assert lib.ovr_oracle_float_to_half(f) == bits

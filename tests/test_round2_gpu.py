@@ -1,0 +1,240 @@
+"""Round-2 features through the C ABI against the CPU oracle: the data-range fallback of an invalid transfer-function range
+(volume.cpp:131-145, array.cpp:27-66,297), blue-noise pixel jitter (BASELINE C5), the EXR half frame (imageio.cpp:15-83), the
+prologue/march agreement on frame widths that are not powers of two, and the pool-overflow path under the pipelined gather."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import json
+
+import numpy as np
+import pytest
+
+from helpers import compare, hip_frame, hip_setup, make_case, oracle_scene
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint8, np.int8, np.uint16, np.int16, np.float64, np.uint32])
+def test_data_range_fallback(ovr, oracle, hip_renderer_factory, dtype):
+    """the default TransferFunction range (1, -1) is invalid: the data range found at load stays in effect"""
+    case = make_case(ovr, oracle, n=24, dtype=dtype, cam="oblique", size=(56, 40))
+    case["vr"] = (1.0, -1.0)
+    sc = oracle_scene(oracle, case)
+    ren = hip_setup(ovr, hip_renderer_factory(), case)
+    info = ren.volume_info()
+    lo, hi = sc.data_range()
+    assert (np.float32(info.data_lower), np.float32(info.data_upper)) == (np.float32(lo), np.float32(hi))
+    assert (np.float32(info.tf_lower), np.float32(info.tf_upper)) == (np.float32(lo), np.float32(hi))
+    assert tuple(info.dims) == (24, 24, 24) and info.resident_bytes >= case["vol"].size * min(case["vol"].itemsize, 4)
+    ren.render()
+    got, _ = hip_frame(ovr, ren)
+    ref, _, cnt = sc.render()
+    st = ren.stats()
+    assert (st.samples, st.shaded_samples) == (cnt.samples, cnt.shaded_samples) and cnt.shaded_samples > 0
+    compare(oracle, got, ref, name=f"fallback {np.dtype(dtype).name}")
+    # a valid range replaces it, a later invalid one keeps the valid one (set_value_range only overwrites on hi >= lo)
+    vr2 = (float(case["vol"].min()) * 0.5 + float(case["vol"].max()) * 0.5, float(case["vol"].max()))
+    ren.set_transfer_function(case["colors"], case["alphas"], vr2)
+    ren.commit()
+    i2 = ren.volume_info()
+    assert i2.tf_lower > info.tf_lower and i2.data_lower == info.data_lower
+    ren.render()
+    got2, _ = hip_frame(ovr, ren)
+    ref2, _, _ = oracle_scene(oracle, dict(case, vr=vr2)).render()
+    compare(oracle, got2, ref2, name="valid range")
+    ren.set_transfer_function(case["colors"], case["alphas"], (1.0, -1.0))
+    ren.commit()
+    i3 = ren.volume_info()
+    assert (i3.tf_lower, i3.tf_upper) == (i2.tf_lower, i2.tf_upper)
+    ren.close()
+
+
+def test_data_range_fallback_with_skipping_and_macrocells(ovr, oracle, hip_renderer_factory):
+    case = make_case(ovr, oracle, n=40, cam="oblique", size=(64, 48))
+    case["vr"] = (1.0, -1.0)
+    ren = hip_setup(ovr, hip_renderer_factory(), case)
+    ren.render()
+    plain, _ = hip_frame(ovr, ren)
+    st0 = ren.stats()
+    ren.set_empty_space_skipping(True)
+    ren.commit()
+    ren.render()
+    skip, _ = hip_frame(ovr, ren)
+    st1 = ren.stats()
+    assert np.array_equal(plain, skip) and st1.samples + st1.skipped_samples == st0.samples
+    mm, mj = ren.macrocells()
+    omm, omj = oracle_scene(oracle, case).macrocells()
+    assert np.array_equal(mm, omm) and np.array_equal(mj, omj)
+    ren.close()
+
+
+@pytest.mark.parametrize("spp,pipeline,skip,shading", [(1, 0, False, 2), (1, 1, False, 2), (4, 2, False, 2), (4, 1, False, 2), (3, 0, True, 2),
+                                                     (1, 0, True, 1), (6, 0, False, 0), (2, 0, False, 1)])
+def test_blue_noise_jitter_vs_oracle(ovr, oracle, hip_renderer_factory, spp, pipeline, skip, shading):
+    """pixel jitter from the noise tile, slice ((frame - 1) * spp + k) % 64: three accumulated frames against the oracle; more
+    samples per pixel than the kernel stages in LDS (6 > 4) take the direct lookup"""
+    noise = ovr.synth.make_noise_tile(16 if spp != 4 else 64, seed=11)
+    case = make_case(ovr, oracle, n=28, tf="bumps", cam="oblique", size=(72, 40), spp=spp, shading=shading)
+    ren = hip_renderer_factory()
+    ren.set_noise_tile(noise)
+    ren.set_pixel_jitter(ovr.JITTER_BLUE_NOISE)
+    ren.set_empty_space_skipping(skip)
+    hip_setup(ovr, ren, case, accumulate=True, pipeline=pipeline)
+    sc = oracle_scene(oracle, case, jitter=1, noise=noise)
+    rendered = 0
+    for frames in (1, 3):
+        while rendered < frames:
+            ren.render()
+            rendered += 1
+        got, _ = hip_frame(ovr, ren)
+        ref, _, cnt = sc.render(frames=frames, accumulate=True)
+        st = ren.stats()
+        assert st.frame_index == frames
+        assert st.samples + st.skipped_samples == cnt.samples and st.shaded_samples == cnt.shaded_samples
+        compare(oracle, got, ref, name=f"jitter spp {spp} frames {frames}")
+    # the jittered frame differs from the unjittered one, and TEA mode is back after the switch
+    ren.set_pixel_jitter(ovr.JITTER_TEA)
+    ren.commit()
+    ren.render()
+    tea, _ = hip_frame(ovr, ren)
+    ref_tea, _, _ = oracle_scene(oracle, case).render(frames=1, accumulate=True)
+    compare(oracle, tea, ref_tea, name="back to TEA")
+    assert not np.array_equal(tea, got)
+    ren.close()
+
+
+def test_blue_noise_jitter_sparse_and_sharded(ovr, oracle, hip_renderer_factory):
+    noise = ovr.synth.make_noise_tile(16, seed=5)
+    case = make_case(ovr, oracle, n=24, cam="oblique", size=(80, 48), spp=2)
+    focus = ((0.5, 0.45), 0.3, 0.15)
+    ren = hip_renderer_factory()
+    ren.set_noise_tile(noise)
+    ren.set_pixel_jitter(1)
+    ren.set_focus(*focus)
+    ren.set_image_shard(1, 3, 16, 16)
+    hip_setup(ovr, ren, case)
+    ren.set_sparse_sampling(True)
+    ren.commit()
+    ren.render()
+    got, _ = hip_frame(ovr, ren)
+    sc = oracle_scene(oracle, case, jitter=1, noise=noise, sparse=True, focus=focus, shard=(1, 3, 16, 16))
+    ref, _, cnt = sc.render()
+    assert ren.stats().samples == cnt.samples
+    compare(oracle, got, ref, name="jitter sparse shard")
+    ren.close()
+
+
+def test_jitter_needs_a_noise_tile(ovr, hip_renderer_factory, oracle):
+    case = make_case(ovr, oracle, n=8, size=(16, 16))
+    ren = hip_setup(ovr, hip_renderer_factory(), case)
+    ren.set_pixel_jitter(1)
+    ren.commit()
+    with pytest.raises(RuntimeError, match="noise tile"):
+        ren.render()
+    with pytest.raises(RuntimeError, match="jitter"):
+        ren.set_pixel_jitter(7)
+    ren.close()
+
+
+@pytest.mark.parametrize("size", [(1920, 8), (1366, 24), (1000, 16), (333, 77)])
+def test_prologue_and_march_agree_on_any_width(ovr, oracle, hip_renderer_factory, size):
+    """frame widths that are not powers of two, camera placed so that the volume's silhouette crosses many 8x8 blocks: the
+    workgroup's staging decision and the march use the same ray ((ix + .5) / W vs (ix + .5) * (1 / W))"""
+    case = make_case(ovr, oracle, n=16, tf="dense", cam="oblique", size=size, shading=1, fovy=25.0)
+    for skip in (False, True):
+        ren = hip_renderer_factory()
+        ren.set_empty_space_skipping(skip)
+        hip_setup(ovr, ren, case)
+        ren.render()
+        got, _ = hip_frame(ovr, ren)
+        ref, _, cnt = oracle_scene(oracle, case).render()
+        st = ren.stats()
+        assert st.samples + st.skipped_samples == cnt.samples
+        compare(oracle, got, ref, name=f"width {size} skip {skip}")
+        ren.close()
+
+
+def test_exr_half_frame_and_files(ovr, oracle, hip_renderer_factory, tmp_path):
+    """the half frame of the EXR writer: bit-exact against the oracle's restatement of tinyexr's conversion, flipped like
+    save_image flips (imageio.cpp:271); the files save_image writes decode to the same pixels"""
+    case = make_case(ovr, oracle, n=24, tf="dense", cam="oblique", size=(96, 56), shading=2)
+    ren = hip_setup(ovr, hip_renderer_factory(), case)
+    ren.render()
+    rgba, _ = hip_frame(ovr, ren)
+    # inject values that exercise the rounding rule into a copy of the frame on the device
+    import torch
+    fb = ovr.FrameBufferData()
+    ren.mapframe(fb, device=True)
+    t = fb.rgba.data()
+    special = torch.tensor([1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11, 65520.0, 1e9, -1e9, 2.0 ** -24, 2.0 ** -25, 2.0 ** -26, 1e-45, -0.0,
+                            float("inf"), float("nan"), 2.0 - 2.0 ** -12, 6.1e-5, 6.0e-5, 0.1], dtype=torch.float32, device=t.device)
+    t.view(-1)[: special.numel()] = special
+    rgba = t.cpu().numpy().copy()
+    exp = oracle.float_to_half(rgba)
+    for flip in (False, True):
+        got = np.array(ren.mapframe_rgba16f(flip_vertical=flip), copy=True)
+        assert got.dtype == np.uint16 and got.shape == (56, 96, 4)
+        e = exp[::-1] if flip else exp
+        assert np.array_equal(got, e), np.argwhere(got != e)[:5]
+    dev = ren.mapframe_rgba16f(flip_vertical=True, device=True)
+    assert np.array_equal(dev.cpu().numpy().view(np.uint16), exp[::-1])
+    # files
+    t.view(-1)[: special.numel()] = 0.25   # finite pixels for the file round trips
+    ren.save_image(str(tmp_path / "f.exr"))
+    ren.save_image(str(tmp_path / "f.png"))
+    ren.save_image(str(tmp_path / "f.jpg"))
+    from PIL import Image
+    rgba8 = np.array(ren.mapframe_rgba8(flip_vertical=True), copy=True)
+    assert np.array_equal(np.array(Image.open(tmp_path / "f.png")), rgba8)
+    jpg = np.array(Image.open(tmp_path / "f.jpg")).astype(int)
+    assert jpg.shape == (56, 96, 3) and np.abs(jpg - rgba8[..., :3].astype(int)).mean() < 3.0
+    raw = open(tmp_path / "f.exr", "rb").read()
+    assert raw[:4] == bytes([0x76, 0x2f, 0x31, 0x01]) and b"channels\0chlist\0" in raw and b"compression\0compression\0" in raw
+    ren.close()
+
+
+def test_pool_overflow_under_the_pipelined_gather(ovr, oracle, hip_renderer_factory):
+    """with a request pool that overflows, the frame is rendered again inside the host wait - the tiles packed for
+    the gather must be those of the re-rendered frame.  One rank, forced overflow (OVR_HIP_POOL_CHUNKS=8)."""
+    import torch
+    case = make_case(ovr, oracle, n=32, tf="dense", cam="oblique", size=(96, 64), shading=2)
+    ref_ren = hip_setup(ovr, hip_renderer_factory(), case)
+    ref_ren.render()
+    ref, _ = hip_frame(ovr, ref_ren)
+    ref_ren.close()
+    os.environ["OVR_HIP_POOL_CHUNKS"] = "8"
+    try:
+        ren = hip_renderer_factory()
+        ren.set_image_shard(0, 1, 16, 16)
+        hip_setup(ovr, ren, case)
+        slots = ovr.tiles.max_owned_tiles(96, 64, 16, 16, 1)
+        payload = torch.zeros((slots, 16, 16, 4), dtype=torch.float32, device="cuda")
+        ren.render_async()
+        ovr._lib.check(ren._lib.ovr_hip_pack_tiles(ren._h, C.c_void_p(payload.data_ptr()), payload.numel() * 4))
+        ren.sync()
+        assert ren.stats().pool_chunks > 8
+    finally:
+        del os.environ["OVR_HIP_POOL_CHUNKS"]
+    frame = np.zeros((64, 96, 4), np.float32)
+    ovr.tiles.unpack_tiles_host(payload.cpu().numpy(), frame, 16, 16, 0, 1)
+    assert np.array_equal(frame.reshape(ref.shape), ref)
+    ren.close()
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` (no launcher) starts two ranks itself; rehearsed on one card over gloo"""
+    env = dict(os.environ, OVR_BENCH_BACKEND="gloo", OVR_BENCH_ONE_GPU="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "4", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"].startswith("gloo") and d["value"] > 0
+    assert d["per_frame"]["rays"] == 256 * 256
+    # a launcher / --gpus mismatch is an error, not a silent single-rank run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "tiny"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
