@@ -956,14 +956,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
     alpha = 0.f;
     color = mk3(0, 0, 0);
     gradient = mk3(0, 0, 0);
-    // `staged` guards the prologue's decision: a ray is only marched when its workgroup has the tables and the TF in LDS
-    bool live = active && staged && intersect_unit_box(t0, t1, oo, od);
+    bool live = active && intersect_unit_box(t0, t1, oo, od);
     if (active && owner) ++n_rays;
     float skip_first = -FLT_MAX, skip_last = FLT_MAX; // samples outside [skip_first, skip_last] are in empty macrocells
     if (SKIP) {
       if (P.spp == 1) { skip_first = pro_first; skip_last = pro_last; } // same ray, same [t0, t1] as in the prologue
       else skip_interval(vc, oo, od, t0, t1, sub, live, skip_first, skip_last);
     }
+    // `staged` guards the prologue's decision (it tests the same ray with the same expressions): without the tables and the TF
+    // in LDS no sample may be fetched - a skipping ray then only counts its (all empty) steps, any other ray is dead
+    if (SKIP) { if (!staged) { skip_first = FLT_MAX; skip_last = -FLT_MAX; } }
+    else live = live && staged;
     float tx = t0, ty = fminf(t1, t0 + mc.step);
     pend = 0;
 

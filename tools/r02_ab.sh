@@ -10,9 +10,10 @@ for name in "$@"; do
     OVR_HIP_LIBRARY=$lib timeout -k 10 600 python -m pytest tests/test_parity_gpu.py -x -q > gpurun_out/ab_parity_$name.log 2>&1
     echo "$name parity: $(tail -1 gpurun_out/ab_parity_$name.log)" >> $out
   fi
-  for cfg in "c3 front" "c3 oblique" "c2 oblique" ${OVR_AB_EXTRA:-}; do
+  IFS=',' read -ra cfgs <<< "${OVR_AB_CONFIGS:-c3 front,c3 oblique,c2 oblique}"
+  for cfg in "${cfgs[@]}"; do
     set -- $cfg
-    OVR_HIP_LIBRARY=$lib timeout -k 10 300 python bench.py --config $1 --camera $2 --steps 10 --warmup 3 --no-cpu-baseline --no-skip-leg 2>/dev/null | tail -1 | python3 -c "
+    OVR_HIP_LIBRARY=$lib timeout -k 10 300 python bench.py --config $1 --camera $2 --steps 10 --warmup 3 --no-cpu-baseline --no-skip-leg --no-views 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); p=d['roofline'].get('phase_ms_rank0',{})
 print('$name $1 $2', 'ms %.3f' % d['ms_per_step'], 'march %.3f shade %.3f comp %.3f' % (p.get('march',0),p.get('shade',0),p.get('composite',0)), 'frac', round(d['roofline']['frac'],3), 'pipe', round(d['roofline']['pipeline']['frac'],3))" >> $out
