@@ -48,7 +48,7 @@ CONFIGS = {
 VOXEL_BYTES = {"float32": 4, "uint16": 2, "uint8": 1}
 DTYPE_NAME = {"float32": "f32", "uint16": "u16", "uint8": "u8"}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-CAMERAS = ["front", "oblique", "inside", "side", "top", "oblique_y", "oblique_z", "diagonal"]
+CAMERAS = ["front", "oblique", "inside", "side", "top", "oblique_y", "oblique_z", "diagonal"] + ["tilt%d" % a for a in (5, 10, 15, 20, 25, 30, 35, 45)]
 
 
 def algorithmic_bytes(cfg, st, pixels, accumulate=True, grad=True):

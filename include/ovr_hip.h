@@ -74,6 +74,8 @@ typedef struct ovr_hip_stats {
   uint64_t pool_chunks;     /* pooled pipeline: 2 KiB request chunks used by the frame                         */
   uint64_t skipped_samples; /* empty-space skipping: primary iterations whose voxel fetch was skipped (not in `samples`) */
   uint64_t skipped_shadow_samples; /* same for shadow-march iterations (not in `shadow_samples`)                 */
+  int32_t layout;           /* which resident layout of the volume the frame read: 0 general, 1 thin, 2 thin transposed */
+  int32_t reserved;
 } ovr_hip_stats;
 
 const char* ovr_hip_last_error(void);
@@ -94,6 +96,16 @@ int ovr_hip_set_stream(ovr_hip_renderer* r, void* hip_stream);
 int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int value_type, const int32_t dims[3],
                        const float grid_origin[3], const float grid_spacing[3]);
 int ovr_hip_set_grid_convention(ovr_hip_renderer* r, int convention);
+/* extension (MI355X: 288 GB of HBM traded for bandwidth): which layouts of the volume ovr_hip_set_volume keeps resident.
+ * Besides the general layout (128-byte 3-D bricks) two "thin" replicas serve views whose rays run along a volume axis - 12 of
+ * the reference's 21 shipped scene cameras - where rays are sparser than voxels and a general brick is mostly wasted (C3 front
+ * view: 2.18 -> 1.69 ms per frame).  Frames are bit-identical whatever layout is read.  mode 0 = general only, 1 (default) =
+ * thin replicas for float / uint16 volumes when all replicas fit in 40 % of the free HBM (x 3 - 4 of the volume's size),
+ * 2 = always.  Takes effect at the next ovr_hip_set_volume. */
+int ovr_hip_set_volume_layouts(ovr_hip_renderer* r, int32_t mode);
+/* which resident layout a frame reads: -1 (default) = chosen per frame from the camera direction (thin within ~18 degrees of
+ * an axis), 0 / 1 / 2 = forced (general if that replica is not resident).  Applied at commit; does not reset the accumulation. */
+int ovr_hip_set_layout_choice(ovr_hip_renderer* r, int32_t choice);
 
 /* replaces MainRenderer::set_transfer_function -> StructuredRegularVolume::set_transfer_function
  * (ovr/renderer.h:154-161, volume.cpp:110-129): colors = n_colors flat RGB triples, alphas = n_alphas flat

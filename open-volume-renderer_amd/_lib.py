@@ -19,6 +19,7 @@ SHADE_NONE, SHADE_GRADIENT, SHADE_FULL = 0, 1, 2
 GRID_CELL_CENTRED, GRID_VERTEX_CENTRED = 0, 1
 PIPELINE_AUTO, PIPELINE_IN_PLACE, PIPELINE_POOLED = 0, 1, 2
 JITTER_TEA, JITTER_BLUE_NOISE = 0, 1
+LAYOUT_AUTO, LAYOUT_GENERAL, LAYOUT_THIN, LAYOUT_THIN_T = -1, 0, 1, 2
 
 
 class Stats(C.Structure):
@@ -38,6 +39,8 @@ class Stats(C.Structure):
         ("pool_chunks", C.c_uint64),
         ("skipped_samples", C.c_uint64),
         ("skipped_shadow_samples", C.c_uint64),
+        ("layout", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -94,6 +97,8 @@ SYMBOLS = {
     "ovr_hip_sparse_mask": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]),
     "ovr_hip_tea_floats": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int64]),
     "ovr_hip_set_pixel_jitter": (C.c_int, [_H, C.c_int32]),
+    "ovr_hip_set_volume_layouts": (C.c_int, [_H, C.c_int32]),
+    "ovr_hip_set_layout_choice": (C.c_int, [_H, C.c_int32]),
     "ovr_hip_get_volume_info": (C.c_int, [_H, C.POINTER(VolumeInfo)]),
     "ovr_hip_mapframe_rgba16f": (C.c_int, [_H, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
 }

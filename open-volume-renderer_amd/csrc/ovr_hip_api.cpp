@@ -109,10 +109,14 @@ struct ovr_hip_renderer {
   Queued<float> rate;
   Queued<ShardP> shard;
 
-  // volume
+  // volume: d_volume / vd = the general layout (always resident); replica[1..2] = the thin layouts (ovr_hip_kernels.h), if built
   void* d_volume = nullptr;
-  size_t volume_bytes = 0;
+  size_t volume_bytes = 0; // all resident replicas
   VolumeDesc vd{};
+  void* d_replica[3] = { nullptr, nullptr, nullptr };
+  VolumeDesc vd_replica[3] = {};
+  Queued<int> layouts;      // ovr_hip_set_volume_layouts: which replicas the next ovr_hip_set_volume builds
+  Queued<int> layout_choice; // -1 = by the camera direction, 0..2 = forced (falls back to general if not resident)
   int value_type = 0;
   float origin[3] = { 0, 0, 0 }, spacing[3] = { 1, 1, 1 };
   bool have_volume = false;
@@ -540,6 +544,26 @@ int enqueue_frame(ovr_hip_renderer* r)
     const float ex = r->spacing[0] * r->vd.nx, ey = r->spacing[1] * r->vd.ny, ez = r->spacing[2] * r->vd.nz;
     P.long_ray_steps = std::sqrt(ex * ex + ey * ey + ez * ez) / P.step;
   }
+  {
+    // which replica of the volume this frame reads (ovr_hip_kernels.h "View-dependent replicas"): the central ray's direction in
+    // object space; within ~18 degrees of an axis (dominant component >= 0.95: measured crossover, profiles/r02_notes.md) the
+    // thin replica whose pair axis is NOT that axis
+    int choice = r->layout_choice.current;
+    if (choice < 0) {
+      const float dx = P.cam_dir.x * P.inv_scale.x, dy = P.cam_dir.y * P.inv_scale.y, dz = P.cam_dir.z * P.inv_scale.z;
+      const float len = std::sqrt(dx * dx + dy * dy + dz * dz);
+      const float ax = std::fabs(dx) / len, ay = std::fabs(dy) / len, az = std::fabs(dz) / len;
+      choice = LAYOUT_GENERAL;
+      if (ax >= 0.95f) choice = LAYOUT_THIN_T;
+      else if (ay >= 0.95f || az >= 0.95f) choice = LAYOUT_THIN;
+    }
+    if (choice < 0 || choice > 2 || !r->d_replica[choice]) choice = LAYOUT_GENERAL;
+    const float vs = P.vol.value_scale, vm = P.vol.value_min_clamp;
+    P.vol = r->vd_replica[choice];
+    P.vol.value_scale = vs;
+    P.vol.value_min_clamp = vm;
+    r->stats.layout = choice;
+  }
   P.tf_color = r->d_tf_color;
   P.tf_alpha = r->d_tf_alpha;
   P.n_color = r->n_color;
@@ -711,6 +735,9 @@ int ovr_hip_create(ovr_hip_renderer** out, int device_id)
   r->shading.current = r->shading.queued = OVR_HIP_SHADE_FULL;
   r->grid_convention.current = r->grid_convention.queued = OVR_HIP_GRID_CELL_CENTRED;
   r->rate.current = r->rate.queued = 1.f;
+  r->layouts.current = r->layouts.queued = 1;
+  r->layout_choice.current = r->layout_choice.queued = -1;
+  if (const char* f = getenv("OVR_HIP_LAYOUTS")) r->layouts.current = r->layouts.queued = atoi(f); // diagnostic override
   *out = r;
   return 0;
 }
@@ -721,7 +748,8 @@ void ovr_hip_destroy(ovr_hip_renderer* r)
   (void)hipSetDevice(r->device);
   (void)hipDeviceSynchronize();
   (void)free_framebuffers(r);
-  if (r->d_volume) (void)hipFree(r->d_volume);
+  for (int k = 0; k < 3; ++k)
+    if (r->d_replica[k]) (void)hipFree(r->d_replica[k]);
   if (r->d_tf_color) (void)hipFree(r->d_tf_color);
   if (r->d_tf_alpha) (void)hipFree(r->d_tf_alpha);
   if (r->d_noise) (void)hipFree(r->d_noise);
@@ -767,21 +795,57 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
   if (int e = finish_frame(r)) return e;
   HIP_TRY(hipDeviceSynchronize());
 
+  hipStream_t st_ = r->own_stream[0];
   VolumeDesc vd{};
-  vd.type = vt;
-  vd.nx = dims[0]; vd.ny = dims[1]; vd.nz = dims[2];
-  volume_layout(vt, vd.nx, vd.ny, vd.nz, vd);
+  volume_layout(vt, dims[0], dims[1], dims[2], vd);
   vd.value_scale = 1.f;
   vd.value_min_clamp = -FLT_MAX;
   if (vt == VOX_U8) vd.value_scale = 1.f / 255.f;
   if (vt == VOX_I8) { vd.value_scale = 1.f / 127.f; vd.value_min_clamp = -127.f; }
   const size_t bytes = (size_t)vd.bytes;
 
-  if (r->d_volume) { HIP_TRY(hipFree(r->d_volume)); r->d_volume = nullptr; }
-  HIP_TRY(hipMalloc(&r->d_volume, bytes + 64)); // + slack: the pair load of the very last element
-  HIP_TRY(hipMemset(r->d_volume, 0, bytes + 64));  // padding voxels are never sampled, but must be finite
+  for (int k = 0; k < 3; ++k) {
+    if (r->d_replica[k]) HIP_TRY(hipFree(r->d_replica[k]));
+    r->d_replica[k] = nullptr;
+    r->vd_replica[k] = VolumeDesc{};
+  }
+  r->d_volume = nullptr;
+  HIP_TRY(hipMalloc(&r->d_replica[0], bytes + 64)); // + slack: the pair load of the very last element
+  HIP_TRY(hipMemset(r->d_replica[0], 0, bytes + 64));  // padding voxels are never sampled, but must be finite
+  r->d_volume = r->d_replica[0];
   r->volume_bytes = bytes;
   vd.data = r->d_volume;
+  r->vd_replica[0] = vd;
+  // thin replicas for views along a volume axis (ovr_hip_kernels.h).  mode 1 (default): built when the type has them and they
+  // fit comfortably (all replicas <= 40 % of the free HBM); mode 2: always (an allocation failure is an error); mode 0: never
+  {
+    std::lock_guard<std::mutex> lk(r->mtx);
+    (void)r->layouts.update();
+  }
+  int n_layouts = 1;
+  if (r->layouts.current != 0 && replica_voxel_type(vt, LAYOUT_THIN) >= 0) {
+    VolumeDesc t1 = vd, t2 = vd;
+    volume_layout(replica_voxel_type(vt, LAYOUT_THIN), vd.nx, vd.ny, vd.nz, t1);
+    volume_layout(replica_voxel_type(vt, LAYOUT_THIN_T), vd.nx, vd.ny, vd.nz, t2);
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (r->layouts.current == 2 || (double)(t1.bytes + t2.bytes) <= 0.4 * (double)free_b) {
+      const VolumeDesc* ts[2] = { &t1, &t2 };
+      for (int k = 1; k <= 2; ++k) {
+        HIP_TRY(hipMalloc(&r->d_replica[k], (size_t)ts[k - 1]->bytes + 64));
+        HIP_TRY(hipMemset(r->d_replica[k], 0, (size_t)ts[k - 1]->bytes + 64));
+        r->vd_replica[k] = *ts[k - 1];
+        r->vd_replica[k].data = r->d_replica[k];
+        r->volume_bytes += (size_t)ts[k - 1]->bytes;
+      }
+      n_layouts = 3;
+    }
+  }
+  auto relayout_all = [&](const void* src, int z0, int nzc) -> hipError_t {
+    for (int k = 0; k < n_layouts; ++k)
+      if (hipError_t e = launch_relayout(src, value_type, r->d_replica[k], r->vd_replica[k], z0, nzc, st_)) return e;
+    return hipSuccess;
+  };
 
   const size_t in_es = value_type_size(value_type);
   const size_t slice_bytes = (size_t)vd.nx * vd.ny * in_es;
@@ -790,7 +854,7 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
     // chunk over z only to keep grid.z within limits
     for (int z0 = 0; z0 < vd.nz; z0 += 32768) {
       const int nzc = std::min(32768, vd.nz - z0);
-      HIP_TRY(launch_relayout((const char*)data + (size_t)z0 * slice_bytes, value_type, r->d_volume, vd, z0, nzc, st));
+      HIP_TRY(relayout_all((const char*)data + (size_t)z0 * slice_bytes, z0, nzc));
     }
     HIP_TRY(hipStreamSynchronize(st));
   }
@@ -803,7 +867,7 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
     for (int z0 = 0; z0 < vd.nz; z0 += (int)slab) {
       const int nzc = (int)std::min<size_t>(slab, (size_t)(vd.nz - z0));
       hipError_t e = hipMemcpyAsync(d_stage, (const char*)data + (size_t)z0 * slice_bytes, (size_t)nzc * slice_bytes, hipMemcpyHostToDevice, st);
-      if (e == hipSuccess) e = launch_relayout(d_stage, value_type, r->d_volume, vd, z0, nzc, st);
+      if (e == hipSuccess) e = relayout_all(d_stage, z0, nzc);
       if (e == hipSuccess) e = hipStreamSynchronize(st);
       if (e != hipSuccess) { (void)hipFree(d_stage); return fail(OVR_HIP_EDEVICE, std::string("[hip] volume upload failed: ") + hipGetErrorString(e)); }
     }
@@ -897,6 +961,8 @@ OVR_SIMPLE_SETTER(ovr_hip_set_sparse_sampling, sparse, int32_t, true, "")
 OVR_SIMPLE_SETTER(ovr_hip_set_shading, shading, int32_t, v >= 0 && v <= 2, "[hip] unknown shading mode")
 OVR_SIMPLE_SETTER(ovr_hip_set_shading_pipeline, pipeline, int32_t, v >= 0 && v <= 2, "[hip] unknown shading pipeline")
 OVR_SIMPLE_SETTER(ovr_hip_set_empty_space_skipping, skipping, int32_t, true, "")
+OVR_SIMPLE_SETTER(ovr_hip_set_volume_layouts, layouts, int32_t, v >= 0 && v <= 2, "[hip] unknown volume-layout mode")
+OVR_SIMPLE_SETTER(ovr_hip_set_layout_choice, layout_choice, int32_t, v >= -1 && v <= 2, "[hip] unknown layout choice")
 OVR_SIMPLE_SETTER(ovr_hip_set_pixel_jitter, jitter, int32_t, v == 0 || v == 1, "[hip] unknown pixel-jitter mode")
 
 int ovr_hip_set_focus(ovr_hip_renderer* r, float cx, float cy, float scale, float base_noise)
@@ -977,6 +1043,7 @@ int ovr_hip_commit(ovr_hip_renderer* r)
   if (r->rate.update()) r->fb_reset = true;       // :190-196
   if (r->shading.update()) r->fb_reset = true;
   if (r->jitter.update()) r->fb_reset = true;
+  (void)r->layout_choice.update(); // every layout gives the same frame: no accumulation reset
   (void)r->pipeline.update(); // both pipelines produce the same frame: no accumulation reset
   (void)r->skipping.update(); // skipping does not change the frame either
   if (r->shard.update()) {

@@ -1,0 +1,1414 @@
+// ovr_hip_device.h - device code of the ray-march path that depends on the voxel type: helpers, the bricked voxel access,
+// raymarch_kernel / shade_pool_kernel and their launch dispatch.  Included by ovr_hip_kernels.hip (type-independent kernels
+// and the launch interface) and by ovr_hip_march_<type>.hip (one explicit instantiation of launch_v per voxel type).
+// See ovr_hip_kernels.hip for the overview.
+#pragma once
+#include "ovr_hip_kernels.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <algorithm>
+
+namespace ovrhip {
+
+// ------------------------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------------------------
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 ld3(const float3_& a) { return mk3(a.x, a.y, a.z); }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); } // NaN -> 0 like CUDA fminf/fmaxf
+__device__ __forceinline__ float lerpf(float a, float b, float f) { return fmaf(f, b - a, a); }
+// gdt normalize (extern/gdt/gdt/math/vec.h:443-448) with the hardware reciprocal square root (1 ulp)
+__device__ __forceinline__ f3 normalize3(f3 v)
+{
+  const float r = __builtin_amdgcn_rsqf(dot3(v, v));
+  return mk3(v.x * r, v.y * r, v.z * r);
+}
+// IEEE-exact normalize for the once-per-ray direction
+__device__ __forceinline__ f3 normalize3_exact(f3 v)
+{
+  const float l = sqrtf(dot3(v, v));
+  return mk3(v.x / l, v.y / l, v.z / l);
+}
+
+// opacity correction, shaders_raymarching.cu:118-122: 1 - __powf(1 - a, base*dt); __powf == exp2(y * log2(x)).
+// BF: branch-free form (bit select instead of the exec-mask branch the compiler builds around the two transcendentals);
+// same value - adj == 1 keeps a exactly as the reference's branch does.  Only the skipping shadow march gains from it
+// (0.85 -> 0.71 ms on C3); the other kernels are measurably slower with it, so they keep the branch.
+template <bool BF>
+__device__ __forceinline__ float opacity_correction(float a, float adj)
+{
+  if (BF) {
+    const float pw = __builtin_amdgcn_exp2f(adj * __builtin_amdgcn_logf(1.f - a));
+    const float c = clamp01(1.f - pw);
+    const unsigned int m = (fabsf(adj - 1.f) < 1e-7f) ? 0u : ~0u;
+    return __uint_as_float((__float_as_uint(c) & m) | (__float_as_uint(a) & ~m));
+  }
+  if (!(fabsf(adj - 1.f) < 1e-7f)) {
+    const float pw = __builtin_amdgcn_exp2f(adj * __builtin_amdgcn_logf(1.f - a));
+    a = clamp01(1.f - pw);
+  }
+  return a;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// voxel access.  Volume layout in HBM: 128-byte bricks with an x-apron, inside macro blocks (see ovr_hip_kernels.h).
+// One L1/L2 line is one brick.  A brick stores CX+1 voxels along x (the last one duplicates the first of its +x neighbour),
+// so the two x-neighbours of a trilinear tap always sit next to each other in ONE brick and a tap is 4 pair loads
+// (f32: 4 x 8 bytes) instead of 8 scalar loads.  The texture addresser spends ~41 clocks on a 64-lane gather instruction
+// whatever its width (tools/ubench_gather.hip), so halving the instruction count halves the cost of the path's bottleneck;
+// the price is 4/3 (8/7 for 8-bit) of the memory.   f32: (3+1)x4x2   u16/i16: (3+1)x4x4   u8/i8: (7+1)x4x4
+// The element offset is separable: off(x,y,z) = X(x) + Y(y) + Z(z).
+// ------------------------------------------------------------------------------------------------------------------
+typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+typedef unsigned short u16x2_u __attribute__((ext_vector_type(2), aligned(2)));
+typedef short i16x2_u __attribute__((ext_vector_type(2), aligned(2)));
+typedef unsigned char u8x2_u __attribute__((ext_vector_type(2), aligned(1)));
+typedef signed char i8x2_u __attribute__((ext_vector_type(2), aligned(1)));
+
+template <int VT> struct Vox;
+// f32 brick shape (experiment switches; the default is what the A/B runs of profiles/r02_notes.md keep)
+#ifndef OVR_F32_CX
+#define OVR_F32_CX 3
+#define OVR_F32_MBX 10
+#define OVR_F32_BY 2
+#define OVR_F32_BZ 1
+#endif
+template <> struct Vox<VOX_F32> {
+  typedef float T; typedef f32x2_u P;
+  static constexpr int cx = OVR_F32_CX, mbx = OVR_F32_MBX, by = OVR_F32_BY, bz = OVR_F32_BZ; // cells per brick in x, bricks per macro block in x, log2 brick y/z
+  static constexpr bool kScale = false, kClamp = false;
+  static constexpr bool kTransposed = false;
+};
+template <> struct Vox<VOX_U16> {
+  typedef unsigned short T; typedef u16x2_u P;
+  static constexpr int cx = 3, mbx = 10, by = 2, bz = 2;
+  static constexpr bool kScale = false, kClamp = false; // u16 is sampled as RAW float (array.cpp:335-338)
+  static constexpr bool kTransposed = false;
+};
+// Thin replicas (view-dependent layout choice, see VoxelType in ovr_hip_kernels.h): 1 cell + apron along the pair axis, 4 x 4
+// (f32) or 4 x 8 (u16) voxels across.  *_TT is stored with x and y exchanged, so its pair axis is the volume's y.
+#ifndef OVR_U16T_BY
+#define OVR_U16T_BY 2
+#define OVR_U16T_BZ 3
+#endif
+template <> struct Vox<VOX_F32_T> {
+  typedef float T; typedef f32x2_u P;
+  static constexpr int cx = 1, mbx = 32, by = 2, bz = 2;
+  static constexpr bool kScale = false, kClamp = false;
+  static constexpr bool kTransposed = false;
+};
+template <> struct Vox<VOX_F32_TT> : Vox<VOX_F32_T> { static constexpr bool kTransposed = true; };
+template <> struct Vox<VOX_U16_T> {
+  typedef unsigned short T; typedef u16x2_u P;
+  static constexpr int cx = 1, mbx = 32, by = OVR_U16T_BY, bz = OVR_U16T_BZ;
+  static constexpr bool kScale = false, kClamp = false;
+  static constexpr bool kTransposed = false;
+};
+template <> struct Vox<VOX_U16_TT> : Vox<VOX_U16_T> { static constexpr bool kTransposed = true; };
+template <> struct Vox<VOX_I16> {
+  typedef short T; typedef i16x2_u P;
+  static constexpr int cx = 3, mbx = 10, by = 2, bz = 2;
+  static constexpr bool kScale = false, kClamp = false;
+  static constexpr bool kTransposed = false;
+};
+template <> struct Vox<VOX_U8> {
+  typedef unsigned char T; typedef u8x2_u P;
+  static constexpr int cx = 7, mbx = 4, by = 2, bz = 2;
+  static constexpr bool kScale = true, kClamp = false; // normalized read: v / 255 (array.cpp:304-306)
+  static constexpr bool kTransposed = false;
+};
+template <> struct Vox<VOX_I8> {
+  typedef signed char T; typedef i8x2_u P;
+  static constexpr int cx = 7, mbx = 4, by = 2, bz = 2;
+  static constexpr bool kScale = true, kClamp = true; // max(v / 127, -1)
+  static constexpr bool kTransposed = false;
+};
+
+template <int VT> struct BrickMap {
+  typedef Vox<VT> V;
+  static constexpr unsigned SX = V::cx + 1;                           // stored voxels per brick row (4 or 8)
+  static constexpr unsigned BV = SX << (V::by + V::bz);               // stored voxels per brick (128 bytes)
+  static constexpr unsigned sby = V::mbx * BV, sbz = (32u >> V::by) * V::mbx * BV;
+  static constexpr unsigned MV = (32u >> V::bz) * sbz;                // stored voxels per macro block
+  static constexpr unsigned MCX = V::cx * V::mbx;                     // cells per macro block along x (30 or 28)
+  static_assert(BV * sizeof(typename V::T) == 128, "a brick is exactly one 128-byte L1/L2 line");
+  // exact for x < 65536: q = floor(x / d) = mulhi(x, ceil(2^32 / d))
+  static __host__ __device__ __forceinline__ unsigned div_cx(unsigned x) { return (unsigned)(((unsigned long long)x * ((0xffffffffull / V::cx) + 1ull)) >> 32); }
+  static __host__ __device__ __forceinline__ unsigned div_mbx(unsigned b) { return (unsigned)(((unsigned long long)b * ((0xffffffffull / V::mbx) + 1ull)) >> 32); }
+  static __host__ __device__ __forceinline__ unsigned X(unsigned x) // offset of voxel x as the LOWER member of a pair
+  {
+    const unsigned b = div_cx(x), xr = x - b * V::cx;
+    const unsigned m = div_mbx(b), bm = b - m * V::mbx;
+    return xr + bm * BV + m * MV;
+  }
+  static __host__ __device__ __forceinline__ unsigned Y(unsigned y, unsigned macro_y_stride)
+  {
+    return (y & ((1u << V::by) - 1u)) * SX + ((y >> V::by) & ((32u >> V::by) - 1u)) * sby + (y >> 5) * macro_y_stride;
+  }
+  static __host__ __device__ __forceinline__ unsigned Zlo(unsigned z)
+  {
+    return ((z & ((1u << V::bz) - 1u)) << V::by) * SX + ((z >> V::bz) & ((32u >> V::bz) - 1u)) * sbz;
+  }
+};
+
+struct VolConsts {
+  const void* data;
+  // per-axis offset tables in LDS (AM 0 / 1): tx[x] = X(x), ty[y] = Y(y), tz[z] = Z(z), bytes (AM 0) or elements (AM 1);
+  // ty / tz hold one extra entry equal to the last one, so (i, i + 1) is clamp-to-edge without a select
+  const unsigned int *tab_x, *tab_y, *tab_z;
+  const unsigned long long* tab_z64; // AM 2: z offsets need 64 bits (>= 2^32 stored voxels)
+  int nx1, ny1, nz1; // n - 1
+  const float* majorant; // per-macrocell max TF opacity (null: empty-space skipping off)
+  const unsigned char* occupancy; // per 4^3 macrocells: 1 if one of them, or a macrocell next to them, has majorant > 0
+  int mcx1, mcy1, mcz1;  // macrocell grid dims - 1
+  unsigned int macro_y;          // stored elements between macro rows: MV * macros_x
+  unsigned long long macro_z;    // stored elements between macro layers: MV * macros_x * macros_y
+  float fx1, fy1, fz1;
+  f3 cs, cb;
+  float vscale, vmin;
+};
+
+__device__ __forceinline__ void axis_tap(float po, float cs, float cb, float fn1, int n1, int& i0, int& i1, float& f)
+{
+  const float p = clamp01(po);                       // sample_volume_object_space clamps p to [0,1]
+  float x = fmaf(p, cs, cb);                         // cell-centred: p*N - 0.5
+  x = fminf(fmaxf(x, 0.f), fn1);                     // == clamp-to-edge addressing: taps (i0, min(i0+1, n-1))
+  const float fl = floorf(x);
+  f = x - fl;
+  i0 = (int)fl;
+  i1 = min(i0 + 1, n1);
+}
+
+// One trilinear tap, split in two so that several taps can be in flight before the first is consumed
+// (software pipelining: the march is latency-bound otherwise).  issue: 4 pair loads; finish: 7 lerps.
+struct Tap {
+  float c000, c100, c010, c110, c001, c101, c011, c111;
+  float fx, fy, fz;
+  int x0, y0, z0; // lower corner of the footprint (live only between tap_coords and tap_loads)
+};
+
+// macrocell (16^3 voxels, reference accel/spatial_partition.h:24) whose value range covers the footprint (i0, i0 + 1) on
+// every axis: cell c holds voxels [16c - 1, 16c + 15] (sp_singlemc.cu:36-42), i.e. c = (i0 + 1) >> 4
+
+__device__ __forceinline__ void tap_coords(const VolConsts& vc, f3 p, Tap& t)
+{
+  int x1, y1, z1;
+  axis_tap(p.x, vc.cs.x, vc.cb.x, vc.fx1, vc.nx1, t.x0, x1, t.fx);
+  axis_tap(p.y, vc.cs.y, vc.cb.y, vc.fy1, vc.ny1, t.y0, y1, t.fy);
+  axis_tap(p.z, vc.cs.z, vc.cb.z, vc.fz1, vc.nz1, t.z0, z1, t.fz);
+  (void)x1; (void)y1; (void)z1;
+}
+
+__device__ __forceinline__ unsigned int tap_cell(const VolConsts& vc, const Tap& t)
+{
+  const int cx = min((t.x0 + 1) >> 4, vc.mcx1), cy = min((t.y0 + 1) >> 4, vc.mcy1), cz = min((t.z0 + 1) >> 4, vc.mcz1);
+  return (unsigned int)cx + (unsigned int)(vc.mcx1 + 1) * ((unsigned int)cy + (unsigned int)(vc.mcy1 + 1) * (unsigned int)cz);
+}
+
+template <int VT, int AM>
+__device__ __forceinline__ void tap_loads(const VolConsts& vc, Tap& t)
+{
+  typedef BrickMap<VT> M;
+  typedef typename Vox<VT>::T T;
+  typedef typename Vox<VT>::P P;
+  // layout coordinates (a, b, c): a = the pair axis (the volume's x; its y in a transposed replica), b = the other of the two
+  constexpr bool TR = Vox<VT>::kTransposed;
+  const int a0 = TR ? t.y0 : t.x0, b0 = TR ? t.x0 : t.y0, z0 = t.z0;
+  const int nb1 = TR ? vc.nx1 : vc.ny1;
+  const int b1 = min(b0 + 1, nb1), z1 = min(z0 + 1, vc.nz1);
+  P p00, p10, p01, p11;
+  if (AM == 3) { // > 2^32 elements and axis tables too large for LDS: 64-bit element offsets, computed arithmetically
+    const unsigned ox = M::X((unsigned)a0);
+    const unsigned o0 = ox + M::Y((unsigned)b0, vc.macro_y), o1 = ox + M::Y((unsigned)b1, vc.macro_y);
+    const T* base = static_cast<const T*>(vc.data);
+    const unsigned long long oz0 = (unsigned long long)M::Zlo((unsigned)z0) + (unsigned long long)((unsigned)z0 >> 5) * vc.macro_z;
+    const unsigned long long oz1 = (unsigned long long)M::Zlo((unsigned)z1) + (unsigned long long)((unsigned)z1 >> 5) * vc.macro_z;
+    p00 = *reinterpret_cast<const P*>(base + (oz0 + o0)); p10 = *reinterpret_cast<const P*>(base + (oz0 + o1));
+    p01 = *reinterpret_cast<const P*>(base + (oz1 + o0)); p11 = *reinterpret_cast<const P*>(base + (oz1 + o1));
+  }
+  else if (AM == 2) { // > 2^32 elements: a and b offsets (inside one macro layer) stay 32-bit, the z table is 64-bit
+    (void)b1; (void)z1;
+    const unsigned ox = vc.tab_x[a0];
+    const unsigned o0 = ox + vc.tab_y[b0], o1 = ox + vc.tab_y[b0 + 1];
+    const unsigned long long oz0 = vc.tab_z64[z0], oz1 = vc.tab_z64[z0 + 1];
+    const T* base = static_cast<const T*>(vc.data);
+    p00 = *reinterpret_cast<const P*>(base + (oz0 + o0)); p10 = *reinterpret_cast<const P*>(base + (oz0 + o1));
+    p01 = *reinterpret_cast<const P*>(base + (oz1 + o0)); p11 = *reinterpret_cast<const P*>(base + (oz1 + o1));
+  }
+  else {
+    // three LDS lookups (one b32 + two adjacent pairs) replace ~40 bit-field / multiply instructions per tap: the march is
+    // VALU-bound once its gathers coalesce, and the LDS pipe is otherwise nearly idle
+    (void)b1; (void)z1;
+    const unsigned ox = vc.tab_x[a0];
+    const unsigned oy0 = vc.tab_y[b0], oy1 = vc.tab_y[b0 + 1];
+    const unsigned oz0 = vc.tab_z[z0], oz1 = vc.tab_z[z0 + 1];
+    const unsigned o0 = ox + oy0, o1 = ox + oy1;
+    if (AM == 1) { // < 2^32 elements: 32-bit element offsets, one 64-bit shift-add per load
+      const T* base = static_cast<const T*>(vc.data);
+      p00 = *reinterpret_cast<const P*>(base + (oz0 + o0)); p10 = *reinterpret_cast<const P*>(base + (oz0 + o1));
+      p01 = *reinterpret_cast<const P*>(base + (oz1 + o0)); p11 = *reinterpret_cast<const P*>(base + (oz1 + o1));
+    }
+    else { // the whole volume is <= 4 GiB: 32-bit BYTE offsets, the loads use the SGPR-base + 32-bit-VGPR-offset form
+      const char* cb = static_cast<const char*>(vc.data);
+      p00 = *reinterpret_cast<const P*>(cb + (oz0 + o0)); p10 = *reinterpret_cast<const P*>(cb + (oz0 + o1));
+      p01 = *reinterpret_cast<const P*>(cb + (oz1 + o0)); p11 = *reinterpret_cast<const P*>(cb + (oz1 + o1));
+    }
+  }
+  // p(b, c) = the pair along a at (b0 + b, z0 + c); the corners keep their volume-axis names, so the lerp order (x, then y,
+  // then z) and with it every bit of the result is the same for every layout
+  if (!TR) {
+    t.c000 = (float)p00.x; t.c100 = (float)p00.y; t.c010 = (float)p10.x; t.c110 = (float)p10.y;
+    t.c001 = (float)p01.x; t.c101 = (float)p01.y; t.c011 = (float)p11.x; t.c111 = (float)p11.y;
+  }
+  else {
+    t.c000 = (float)p00.x; t.c010 = (float)p00.y; t.c100 = (float)p10.x; t.c110 = (float)p10.y;
+    t.c001 = (float)p01.x; t.c011 = (float)p01.y; t.c101 = (float)p11.x; t.c111 = (float)p11.y;
+  }
+}
+
+template <int VT, int AM>
+__device__ __forceinline__ void tap_issue(const VolConsts& vc, f3 p, Tap& t)
+{
+  tap_coords(vc, p, t);
+  tap_loads<VT, AM>(vc, t);
+}
+
+template <int VT>
+__device__ __forceinline__ float tap_finish(const VolConsts& vc, Tap t)
+{
+  if (Vox<VT>::kClamp) {
+    t.c000 = fmaxf(t.c000, vc.vmin); t.c100 = fmaxf(t.c100, vc.vmin); t.c010 = fmaxf(t.c010, vc.vmin); t.c110 = fmaxf(t.c110, vc.vmin);
+    t.c001 = fmaxf(t.c001, vc.vmin); t.c101 = fmaxf(t.c101, vc.vmin); t.c011 = fmaxf(t.c011, vc.vmin); t.c111 = fmaxf(t.c111, vc.vmin);
+  }
+  const float c00 = lerpf(t.c000, t.c100, t.fx), c10 = lerpf(t.c010, t.c110, t.fx);
+  const float c01 = lerpf(t.c001, t.c101, t.fx), c11 = lerpf(t.c011, t.c111, t.fx);
+  const float c0 = lerpf(c00, c10, t.fy), c1 = lerpf(c01, c11, t.fy);
+  float s = lerpf(c0, c1, t.fz);
+  if (Vox<VT>::kScale) s *= vc.vscale;
+  return s;
+}
+
+// trilinear tap at object-space p (shaders_common.h:186-193); returns what tex3D<float> returns
+template <int VT, int AM>
+__device__ __forceinline__ float sample_volume(const VolConsts& vc, f3 p)
+{
+  Tap t;
+  tap_issue<VT, AM>(vc, p, t);
+  return tap_finish<VT>(vc, t);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// transfer function in LDS (or global when it does not fit)
+// ------------------------------------------------------------------------------------------------------------------
+struct TfConsts {
+  const float4* color; // LDS or global
+  const float* alpha;
+  int nc1, na1;
+  float fnc1, fna1;
+  float lower, upper, scale;
+};
+
+__device__ __forceinline__ float tf_coord(const TfConsts& tf, float sample)
+{
+  return clamp01((fminf(fmaxf(sample, tf.lower), tf.upper) - tf.lower) * tf.scale); // shaders_common.h:363, :316
+}
+__device__ __forceinline__ float tf_alpha(const TfConsts& tf, float v)
+{
+  const float x = v * tf.fna1;
+  const float fl = floorf(x);
+  const int i0 = (int)fl, i1 = min(i0 + 1, tf.na1);
+  return lerpf(tf.alpha[i0], tf.alpha[i1], x - fl);
+}
+__device__ __forceinline__ f3 tf_color(const TfConsts& tf, float v)
+{
+  const float x = v * tf.fnc1;
+  const float fl = floorf(x);
+  const int i0 = (int)fl, i1 = min(i0 + 1, tf.nc1);
+  const float f = x - fl;
+  const float4 a = tf.color[i0], b = tf.color[i1];
+  return mk3(lerpf(a.x, b.x, f), lerpf(a.y, b.y, f), lerpf(a.z, b.z, f));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// box test vs [0,1]^3, shaders_common.h:156-184 (__frcp_rn restated as an IEEE divide)
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool intersect_unit_box(float& t0, float& t1, f3 o, f3 d)
+{
+  const bool sx = fabsf(d.x) < FLT_MIN, sy = fabsf(d.y) < FLT_MIN, sz = fabsf(d.z) < FLT_MIN;
+  const float rx = 1.f / d.x, ry = 1.f / d.y, rz = 1.f / d.z;
+  const float lx = sx ? FLT_MAX : (0.f - o.x) * rx, ly = sy ? FLT_MAX : (0.f - o.y) * ry, lz = sz ? FLT_MAX : (0.f - o.z) * rz;
+  const float hx = sx ? -FLT_MAX : (1.f - o.x) * rx, hy = sy ? -FLT_MAX : (1.f - o.y) * ry, hz = sz ? -FLT_MAX : (1.f - o.z) * rz;
+  t0 = fmaxf(t0, fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fminf(lz, hz)));
+  t1 = fminf(t1, fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fmaxf(lz, hz)));
+  return t1 > t0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// TEA, random.h:146-188
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tea16(unsigned int& v0, unsigned int& v1)
+{
+  unsigned int sum = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    sum += 0x9e3779b9u;
+    v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+    v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+  }
+}
+#define OVR_TEA_TOFLOAT 2.3283064365386962890625e-10f
+
+// ------------------------------------------------------------------------------------------------------------------
+// per-frame constants shared by the primary and the shadow march
+// ------------------------------------------------------------------------------------------------------------------
+struct MarchConsts {
+  f3 inv_scale, wto_p, otw_it, light;
+  f3 gstep;     // one voxel in normalized object coordinates
+  f3 ginv;      // 1 / gstep
+  float step, base, shadow_stride;
+};
+
+__device__ __forceinline__ f3 to_object(const MarchConsts& mc, f3 p)
+{
+  return mk3(fmaf(p.x, mc.inv_scale.x, mc.wto_p.x), fmaf(p.y, mc.inv_scale.y, mc.wto_p.y), fmaf(p.z, mc.inv_scale.z, mc.wto_p.z));
+}
+
+// Empty-space skipping, per ray: the t interval outside of which every sample lies in a macrocell with majorant 0.
+// skip_walk: one lane walks the ray's [ta, tb] through the coarse occupancy grid (3-D DDA; accel/dda.h is the reference's
+// walker for its path tracer) and widens [first, last] by the entry / exit of every set entry it crosses.
+// Sample coordinates: x = p * cs + cb (tap_coords), macrocell = (floor(x) + 1) >> 4 (tap_cell), i.e. the regular 16-voxel
+// grid in w = x + 1; a coarse entry is 64 voxels of w.
+__device__ __forceinline__ void skip_walk(const VolConsts& vc, f3 oo, f3 od, float ta, float tb, float& first, float& last)
+{
+  const float w0[3] = { fmaf(oo.x, vc.cs.x, vc.cb.x + 1.f), fmaf(oo.y, vc.cs.y, vc.cb.y + 1.f), fmaf(oo.z, vc.cs.z, vc.cb.z + 1.f) };
+  const float dw[3] = { od.x * vc.cs.x, od.y * vc.cs.y, od.z * vc.cs.z };
+  const int m1[3] = { vc.mcx1 >> 2, vc.mcy1 >> 2, vc.mcz1 >> 2 }; // coarse grid dims - 1
+  constexpr float G = 64.f;
+  int ci[3], st[3];
+  float tmax[3], tdel[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float w = fmaf(ta, dw[k], w0[k]);
+    ci[k] = min(max((int)floorf(w * (1.f / G)), 0), m1[k]);
+    st[k] = dw[k] > 0.f ? 1 : -1;
+    const bool moves = fabsf(dw[k]) > 1e-20f;
+    tdel[k] = moves ? G / fabsf(dw[k]) : FLT_MAX;
+    tmax[k] = moves ? ((float)(ci[k] + (dw[k] > 0.f ? 1 : 0)) * G - w0[k]) / dw[k] : FLT_MAX;
+  }
+  float t = ta;
+  const int limit = m1[0] + m1[1] + m1[2] + 8; // a ray crosses at most this many entries: every lane leaves the loop
+  for (int it = 0; it < limit && t < tb; ++it) {
+    const bool occ = vc.occupancy[(size_t)ci[0] + (size_t)(m1[0] + 1) * ((size_t)ci[1] + (size_t)(m1[1] + 1) * (size_t)ci[2])] != 0;
+    const int ax = (tmax[0] <= tmax[1]) ? (tmax[0] <= tmax[2] ? 0 : 2) : (tmax[1] <= tmax[2] ? 1 : 2);
+    const float tn = ax == 0 ? tmax[0] : ax == 1 ? tmax[1] : tmax[2];
+    if (occ) { first = fminf(first, t); last = fmaxf(last, fminf(tn, tb)); }
+    t = fmaxf(t, tn);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (k == ax) {
+        const int nxt = ci[k] + st[k];
+        if (nxt < 0 || nxt > m1[k]) tmax[k] = FLT_MAX; // the clamped coordinate stays in the border entry
+        else { ci[k] = nxt; tmax[k] += tdel[k]; }
+      }
+  }
+  if (t < tb) { first = fminf(first, t); last = tb; } // safety limit hit (never expected): treat the rest as occupied
+}
+
+// raymarching_shadow, shaders_raymarching.cu:44-85 (+ :205-229): alpha-only march toward the light.
+// KS taps are issued before the first one is consumed; taps past the end of the march or past the early-termination
+// point are speculative (their coordinates are clamped, so the loads are always in bounds) and simply dropped.
+template <int VT, int AM, int KS, bool SKIP>
+__device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConsts& tf, const MarchConsts& mc, f3 org, unsigned int& n_shadow,
+                                              unsigned int& n_shadow_skipped)
+{
+  const f3 oo = to_object(mc, org);
+  const f3 od = mk3(mc.light.x * mc.inv_scale.x, mc.light.y * mc.inv_scale.y, mc.light.z * mc.inv_scale.z);
+  float t0 = 0.f, t1 = FLT_MAX;
+  float alpha = 0.f;
+  if (!intersect_unit_box(t0, t1, oo, od)) return alpha;
+  float tx = t0, ty = fminf(t1, t0 + mc.shadow_stride);
+  bool live = true;
+  // empty-space skipping: the shadow ray's own skip interval (a handful of coarse entries: the ray is a few hundred voxels)
+  float skip_first = FLT_MAX, skip_last = -FLT_MAX;
+  if (SKIP) skip_walk(vc, oo, od, t0, t1, skip_first, skip_last);
+  while (live) {
+    Tap taps[KS];
+    float dts[KS], mj[KS];
+    bool valid[KS];
+    bool any_inside = false;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      valid[k] = ty > tx;
+      dts[k] = ty - tx;
+      const float tm = 0.5f * (tx + ty);
+      const bool inside = !SKIP || (tm >= skip_first && tm <= skip_last);
+      if (SKIP) taps[k] = Tap{};
+      mj[k] = SKIP ? 0.f : 1.f;
+      if (inside) {
+        const f3 pos = mk3(fmaf(tm, mc.light.x, org.x), fmaf(tm, mc.light.y, org.y), fmaf(tm, mc.light.z, org.z));
+        tap_coords(vc, to_object(mc, pos), taps[k]);
+        if (SKIP) mj[k] = vc.majorant[tap_cell(vc, taps[k])]; // empty-space skipping: max TF opacity of the macrocell
+      }
+      any_inside = any_inside || (mj[k] > 0.f);
+      tx = ty;
+      ty = fminf(tx + mc.shadow_stride, t1);
+    }
+    if (SKIP && __ballot(any_inside) == 0ull) { // nothing to fetch for any lane of the wave: bookkeeping only
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        live = live && valid[k] && (alpha < 0.9999f);
+        n_shadow_skipped += live ? 1u : 0u;
+      }
+      continue;
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+      if (!SKIP || mj[k] > 0.f) tap_loads<VT, AM>(vc, taps[k]);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      // branch-free on purpose: a conditional use would let the compiler sink this tap's loads into the branch and
+      // serialise the taps again (seen in the ISA); dead lanes just compute a value that is not used
+      const float s = tap_finish<VT>(vc, taps[k]);
+      float a = tf_alpha(tf, tf_coord(tf, s));
+      a = opacity_correction<SKIP>(a, mc.base * dts[k]);
+      if (SKIP) a = mj[k] > 0.f ? a : 0.f; // a macrocell whose majorant is 0 holds no sample with opacity > 0
+      live = live && valid[k] && (alpha < 0.9999f);
+      alpha = live ? fmaf(1.f - alpha, a, alpha) : alpha;
+      n_shadow += (live && (!SKIP || mj[k] > 0.f)) ? 1u : 0u;
+      if (SKIP) n_shadow_skipped += (live && !(mj[k] > 0.f)) ? 1u : 0u;
+    }
+  }
+  return alpha;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the ray-march kernels
+//
+// Work decomposition: four lanes per ray (a quad = 4 consecutive steps), 16 rays = a 4x4 pixel tile per wave64, four waves
+// = 8x8 pixels per workgroup; workgroups are launched longest rays first (schedule_kernel).  Details at raymarch_kernel.
+//  * primary march: K instructions x 4 steps per round, all their voxel loads in flight before the first is consumed.
+//  * deferred, compacted shading (SHADE != 0): a sample whose opacity is > 0 is not shaded by its own lane; the lane
+//    pushes a 32-byte request into its wave's queue in LDS (slot = tail + prefix-of-ballot, v_mbcnt) and keeps
+//    marching - alpha does not depend on shading, so early termination is unaffected.  Requests are shaded 64 at a
+//    time, one request per lane (gradient taps, normals, shadow march toward the light - the expensive, otherwise
+//    badly divergent part); each owner applies its colour contributions in sample order (the requests of one lane
+//    form a linked list), so the result is bit-identical to shading in place.
+//  * two ways to shade a batch:
+//      in place   (raymarch_kernel)  the wave that owns the tile shades its own batches and gets the contributions
+//                                    back with ds_bpermute.  Used when shading is off and as the reference pipeline.
+//      pooled     (raymarch_kernel<POOLED> -> shade_pool_kernel -> composite_kernel)  the tile's wave spills each full
+//                                    batch as a 2 KiB chunk into a global pool; a second, persistent kernel shades
+//                                    chunks from ALL tiles with perfect load balance (the shadow work of a frame sits in
+//                                    a few hundred tiles: in place, their waves ran alone for 10 ms of a 13 ms kernel);
+//                                    a third kernel walks each tile's chunks in order and composites.
+//  * counters: per-workgroup partial sums, reduced by a tiny kernel (no same-address atomics).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+
+#ifndef OVR_SHADOW_K
+#define OVR_SHADOW_K 4
+#endif
+constexpr int kShadowTaps = OVR_SHADOW_K; // shadow-march taps in flight per lane
+// chunks a tile reserves at a time: consecutive chunks of one tile are shaded by ONE workgroup, one chunk per wave
+// (L1/L2 reuse: measured 2.4 -> 1.5 ms for the shading kernel at C3; 8 / 16 / 32 are slower - imbalance)
+constexpr int kRun = 4;
+
+struct ShadeReq { // 32 bytes; after shading the same slot holds the result (cx,cy,cz,gx,gy,gz,a,next)
+  float px, py, pz; // world-space sample position          | colour contribution  tr*clamp01(rgb*shade)
+  float s;          // sample value                           | gradient contribution tr*clamp01(n_c) .x
+  float v;          // transfer-function coordinate           | .y
+  float tr;         // transmittance before the sample        | .z
+  float a;          // corrected opacity
+  int next;         // stream position of the owner's next request (valid once that request exists)
+};
+
+__device__ __forceinline__ float bperm(int src_lane, float x)
+{
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(x)));
+}
+__device__ __forceinline__ int bperm_i(int src_lane, int x) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, x); }
+
+__device__ __forceinline__ void setup_consts(const RayMarchParams& P, VolConsts& vc, MarchConsts& mc)
+{
+  vc.data = P.vol.data;
+  vc.nx1 = P.vol.nx - 1; vc.ny1 = P.vol.ny - 1; vc.nz1 = P.vol.nz - 1;
+  vc.fx1 = (float)vc.nx1; vc.fy1 = (float)vc.ny1; vc.fz1 = (float)vc.nz1;
+  vc.macro_y = P.vol.macro_elems * (unsigned int)P.vol.macros_x;
+  vc.macro_z = (unsigned long long)P.vol.macro_elems * (unsigned long long)P.vol.macros_x * (unsigned long long)P.vol.macros_y;
+  vc.cs = ld3(P.coord_scale); vc.cb = ld3(P.coord_bias);
+  vc.vscale = P.vol.value_scale; vc.vmin = P.vol.value_min_clamp;
+  vc.majorant = P.majorant;
+  vc.occupancy = P.occupancy;
+  vc.mcx1 = (P.vol.nx + 15) / 16 - 1; vc.mcy1 = (P.vol.ny + 15) / 16 - 1; vc.mcz1 = (P.vol.nz + 15) / 16 - 1;
+  mc.inv_scale = ld3(P.inv_scale); mc.wto_p = ld3(P.wto_p); mc.otw_it = ld3(P.otw_it); mc.light = ld3(P.light);
+  mc.gstep = ld3(P.grad_step);
+  mc.ginv = mk3(1.f / mc.gstep.x, 1.f / mc.gstep.y, 1.f / mc.gstep.z);
+  mc.step = P.step; mc.base = P.base; mc.shadow_stride = P.shadow_stride;
+}
+
+// build the per-axis offset tables in LDS (all threads of the workgroup); returns the bytes used
+template <int VT, int AM>
+__device__ __forceinline__ size_t stage_tables(const RayMarchParams& P, unsigned char* base, VolConsts& vc)
+{
+  typedef BrickMap<VT> M;
+  vc.tab_x = vc.tab_y = vc.tab_z = nullptr;
+  vc.tab_z64 = nullptr;
+  if (AM == 3) return 0;
+  // layout axes: a = pair axis, b = the other one (x and y, exchanged in a transposed replica)
+  const int na = Vox<VT>::kTransposed ? P.vol.ny : P.vol.nx, nb = Vox<VT>::kTransposed ? P.vol.nx : P.vol.ny;
+  if (AM == 2) { // [z: nz + 1 x u64][a: na x u32][b: nb + 1 x u32], element offsets
+    unsigned long long* tz = reinterpret_cast<unsigned long long*>(base);
+    unsigned int* tx = reinterpret_cast<unsigned int*>(tz + P.vol.nz + 1);
+    unsigned int* ty = tx + na;
+    for (int i = threadIdx.x; i < na; i += kBlock) tx[i] = M::X((unsigned)i);
+    for (int i = threadIdx.x; i <= nb; i += kBlock) ty[i] = M::Y((unsigned)min(i, nb - 1), vc.macro_y);
+    for (int i = threadIdx.x; i <= P.vol.nz; i += kBlock) {
+      const unsigned z = (unsigned)min(i, P.vol.nz - 1);
+      tz[i] = (unsigned long long)M::Zlo(z) + (unsigned long long)(z >> 5) * vc.macro_z;
+    }
+    vc.tab_x = tx; vc.tab_y = ty; vc.tab_z64 = tz;
+    return (size_t)(P.vol.nz + 1) * sizeof(unsigned long long) + (size_t)(na + nb + 1) * sizeof(unsigned int);
+  }
+  unsigned int* tx = reinterpret_cast<unsigned int*>(base);
+  unsigned int* ty = tx + na;
+  unsigned int* tz = ty + nb + 1;
+  const unsigned int mul = AM == 0 ? (unsigned int)sizeof(typename Vox<VT>::T) : 1u;
+  for (int i = threadIdx.x; i < na; i += kBlock) tx[i] = M::X((unsigned)i) * mul;
+  for (int i = threadIdx.x; i <= nb; i += kBlock) ty[i] = M::Y((unsigned)min(i, nb - 1), vc.macro_y) * mul;
+  for (int i = threadIdx.x; i <= P.vol.nz; i += kBlock) {
+    const unsigned z = (unsigned)min(i, P.vol.nz - 1);
+    tz[i] = (M::Zlo(z) + (z >> 5) * (unsigned)vc.macro_z) * mul;
+  }
+  vc.tab_x = tx; vc.tab_y = ty; vc.tab_z = tz;
+  return (size_t)(na + nb + P.vol.nz + 2) * sizeof(unsigned int);
+}
+__host__ inline size_t table_lds_bytes(const RayMarchParams& p, int am)
+{
+  if (am == 3) return 0;
+  if (am == 2) return ((size_t)(p.vol.nz + 1) * sizeof(unsigned long long) + (size_t)(p.vol.nx + p.vol.ny + 1) * sizeof(unsigned int) + 15) & ~(size_t)15;
+  return ((size_t)(p.vol.nx + p.vol.ny + p.vol.nz + 2) * sizeof(unsigned int) + 15) & ~(size_t)15;
+}
+
+// stage the transfer function in LDS (all threads of the workgroup); color may be skipped by alpha-only kernels
+__device__ __forceinline__ void stage_tf(const RayMarchParams& P, unsigned char* tf_base, bool with_color, TfConsts& tf)
+{
+  float4* lc = reinterpret_cast<float4*>(tf_base);
+  float* la = reinterpret_cast<float*>(tf_base + (with_color ? (size_t)P.n_color * sizeof(float4) : 0));
+  if (with_color) {
+    const float4* gc = reinterpret_cast<const float4*>(P.tf_color);
+    for (int i = threadIdx.x; i < P.n_color; i += kBlock) lc[i] = gc[i];
+  }
+  for (int i = threadIdx.x; i < P.n_alpha; i += kBlock) la[i] = P.tf_alpha[i];
+  __syncthreads();
+  tf.color = lc;
+  tf.alpha = la;
+  tf.nc1 = P.n_color - 1; tf.na1 = P.n_alpha - 1;
+  tf.fnc1 = (float)tf.nc1; tf.fna1 = (float)tf.na1;
+  tf.lower = P.tf_lower; tf.upper = P.tf_upper; tf.scale = P.tf_scale;
+}
+
+// accumulation + framebuffer write, shaders_raymarching.cu:389-409
+__device__ __forceinline__ void write_pixel(const RayMarchParams& P, unsigned int pixel_index, f3 o_c, float o_a, f3 o_g)
+{
+  float4 out = make_float4(o_c.x, o_c.y, o_c.z, o_a);
+  float4* fb = reinterpret_cast<float4*>(P.rgba) + pixel_index;
+  if (P.accumulate) {
+    float4* ac = reinterpret_cast<float4*>(P.accum) + pixel_index;
+    if (P.frame_index == 1) {
+      *ac = out;
+    }
+    else {
+      float4 acc = *ac;
+      acc.x += out.x; acc.y += out.y; acc.z += out.z; acc.w += out.w;
+      *ac = acc;
+      const float fi = (float)P.frame_index;
+      out = make_float4(acc.x / fi, acc.y / fi, acc.z / fi, acc.w / fi);
+    }
+  }
+  *fb = out;
+  if (P.grad) {
+    float* pg = P.grad + 3ull * pixel_index;
+    pg[0] = o_g.x; pg[1] = o_g.y; pg[2] = o_g.z;
+  }
+}
+
+// shade one request: gradient (shaders_common.h:195-215), normals, shadow march, Lambert-ish term
+// (shaders_raymarching.cu:124-158).  Writes the result over the request.
+template <int VT, int SHADE, int AM, bool SKIP>
+__device__ __forceinline__ void shade_request(const RayMarchParams& P, const VolConsts& vc, const TfConsts& tf, const MarchConsts& mc, ShadeReq& r,
+                                              unsigned int& n_shadow, unsigned int& n_shadow_skipped)
+{
+  const f3 pos = mk3(r.px, r.py, r.pz);
+  const f3 po = to_object(mc, pos);
+  // one-sided differences, flipped at the upper bound; the three taps are issued together
+  const bool flx = (po.x + mc.gstep.x) > 1.f, fly = (po.y + mc.gstep.y) > 1.f, flz = (po.z + mc.gstep.z) > 1.f;
+  Tap tgx, tgy, tgz;
+  tap_issue<VT, AM>(vc, mk3(po.x + (flx ? -mc.gstep.x : mc.gstep.x), po.y, po.z), tgx);
+  tap_issue<VT, AM>(vc, mk3(po.x, po.y + (fly ? -mc.gstep.y : mc.gstep.y), po.z), tgy);
+  tap_issue<VT, AM>(vc, mk3(po.x, po.y, po.z + (flz ? -mc.gstep.z : mc.gstep.z)), tgz);
+  const f3 rgb = tf_color(tf, r.v);
+  f3 g;
+  g.x = (tap_finish<VT>(vc, tgx) - r.s) * (flx ? -mc.ginv.x : mc.ginv.x);
+  g.y = (tap_finish<VT>(vc, tgy) - r.s) * (fly ? -mc.ginv.y : mc.ginv.y);
+  g.z = (tap_finish<VT>(vc, tgz) - r.s) * (flz ? -mc.ginv.z : mc.ginv.z);
+  const f3 gn = normalize3(g);
+  const f3 n_o = mk3(-gn.x, -gn.y, -gn.z);
+  const f3 n_w = normalize3(mk3(n_o.x * mc.otw_it.x, n_o.y * mc.otw_it.y, n_o.z * mc.otw_it.z));
+  f3 n_c = mk3(0, 0, 0);
+  if (P.grad) {
+    const float* m = P.wtc_it;
+    n_c = normalize3(mk3(fmaf(n_w.x, m[0], fmaf(n_w.y, m[3], n_w.z * m[6])), fmaf(n_w.x, m[1], fmaf(n_w.y, m[4], n_w.z * m[7])),
+                         fmaf(n_w.x, m[2], fmaf(n_w.y, m[5], n_w.z * m[8]))));
+  }
+  float shadow = 0.f;
+  if (SHADE == 2) shadow = march_shadow<VT, AM, kShadowTaps, SKIP>(vc, tf, mc, pos, n_shadow, n_shadow_skipped);
+  const float cosNL = fabsf(dot3(mc.light, n_w));
+  const float shade = 0.5f + 0.5f * cosNL * 2.f * (1.f - shadow); // shaders_raymarching.cu:156-157
+  const float tr = r.tr;
+  r.px = tr * clamp01(rgb.x * shade);
+  r.py = tr * clamp01(rgb.y * shade);
+  r.pz = tr * clamp01(rgb.z * shade);
+  r.s = tr * clamp01(n_c.x);
+  r.v = tr * clamp01(n_c.y);
+  r.tr = tr * clamp01(n_c.z);
+}
+
+// hand the contributions of one shaded batch (stream positions [base, base + n), result of position base + j in lane j)
+// back to the owning lanes: every owner walks its own requests of this batch in sample order
+__device__ __forceinline__ void apply_batch(const ShadeReq& res, unsigned int base, unsigned int n, int lane, int& pend, unsigned int& first, f3& color,
+                                            f3& gradient)
+{
+  for (;;) {
+    const bool has = (pend > 0) && ((first - base) < n);
+    if (__ballot(has) == 0ull) break;
+    const int j = has ? (int)(first - base) : lane;
+    const float tcx = bperm(j, res.px), tcy = bperm(j, res.py), tcz = bperm(j, res.pz);
+    const float tgx = bperm(j, res.s), tgy = bperm(j, res.v), tgz = bperm(j, res.tr);
+    const float ta = bperm(j, res.a);
+    const int tn = bperm_i(j, res.next);
+    if (has) {
+      color.x = fmaf(tcx, ta, color.x);
+      color.y = fmaf(tcy, ta, color.y);
+      color.z = fmaf(tcz, ta, color.z);
+      gradient.x = fmaf(tgx, ta, gradient.x);
+      gradient.y = fmaf(tgy, ta, gradient.y);
+      gradient.z = fmaf(tgz, ta, gradient.z);
+      first = (unsigned int)tn;
+      --pend;
+    }
+  }
+}
+
+constexpr int kNC = 7; // counters: rays, samples, shaded, shadow, active pixels, skipped samples, skipped shadow samples
+// per-wave counters -> LDS -> one plain store of the workgroup's partial sums (lds must hold kWaves*kNC uints)
+__device__ __forceinline__ void store_block_counters(const RayMarchParams& P, unsigned int* red, int lane, int wave, unsigned int n_rays,
+                                                     unsigned int n_samples, unsigned int n_shaded, unsigned int n_shadow, unsigned int n_active,
+                                                     unsigned int n_skipped, unsigned int n_shadow_skipped)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n_rays += __shfl_down(n_rays, off);
+    n_samples += __shfl_down(n_samples, off);
+    n_shaded += __shfl_down(n_shaded, off);
+    n_shadow += __shfl_down(n_shadow, off);
+    n_active += __shfl_down(n_active, off);
+    n_skipped += __shfl_down(n_skipped, off);
+    n_shadow_skipped += __shfl_down(n_shadow_skipped, off);
+  }
+  if (!P.block_counters) return;
+  __syncthreads(); // LDS is dead at this point: reuse its front
+  if (lane == 0) {
+    red[wave * kNC + 0] = n_rays; red[wave * kNC + 1] = n_samples; red[wave * kNC + 2] = n_shaded;
+    red[wave * kNC + 3] = n_shadow; red[wave * kNC + 4] = n_active; red[wave * kNC + 5] = n_skipped; red[wave * kNC + 6] = n_shadow_skipped;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNC) {
+    const unsigned int bid = blockIdx.x;
+    unsigned int sum = 0;
+    for (int w = 0; w < kWaves; ++w) sum += red[w * kNC + threadIdx.x];
+    P.block_counters[(size_t)bid * kNC + threadIdx.x] = sum;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the march kernel (both pipelines)
+//
+// Lane mapping - "four lanes per ray": a wave handles 16 rays (a 4x4 pixel tile); the 4 lanes of a quad are 4 CONSECUTIVE
+// STEPS of one ray.  The texture addresser coalesces a gather only inside quads of 4 consecutive lanes (16 clocks per
+// instruction when a quad shares a 128-byte line, 66 when its lanes hit 4 lines - tools/ubench_lines.hip); with one lane
+// per pixel (2 voxels apart at the bench's resolution) a quad almost never shared a brick, with 4 lanes per ray its taps
+// are 1 voxel apart and nearly always do.  A round = K instructions x 4 steps; every lane recomputes the ray's t sequence
+// (tx, ty recurrence, shaders_raymarching.cu:168-169) and the alpha recurrence (:165) for all 4K steps, fetching the
+// other lanes' opacities with DPP quad broadcasts, so the arithmetic and its order are exactly the reference's.
+//   POOLED = false: shade queued requests in place (raymarch pipeline 1)      POOLED = true: spill them to the pool
+// ------------------------------------------------------------------------------------------------------------------
+template <int B>
+__device__ __forceinline__ float quad_bcast(float x) // value of lane B of this lane's quad
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), B * 0x55, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sel4(float a0, float a1, float a2, float a3, int sub) { return sub == 0 ? a0 : sub == 1 ? a1 : sub == 2 ? a2 : a3; }
+
+// Blue-noise pixel jitter (P.jitter_mode == 1; BASELINE C5, north_star): sample k of frame f takes slice
+// t = ((f - 1) * spp + k) % 64 of the noise tile (lookup as blue_noise.h:95-99; the tile is stored transposed, [t][y][x]):
+// xi0 = tile[t][iy % xy][ix % xy], xi1 = the same slice shifted by half a tile in x and y.  In dense mode the workgroup
+// stages the 2 x 64 variates of its 8x8 pixels for the first kJitStaged samples in LDS; later samples and sparse-mode
+// pixels read the tile directly.
+constexpr int kJitStaged = 4;
+__device__ __forceinline__ int jitter_slice(const RayMarchParams& P, int k) { return (int)((((long long)P.frame_index - 1) * P.spp + k) % 64); }
+__device__ __forceinline__ void jitter_global(const RayMarchParams& P, int ix, int iy, int k, float& x0, float& x1)
+{
+  const int xy = P.jitter_xy, h = xy >> 1;
+  const float* slice = P.jitter_noise + (size_t)jitter_slice(P, k) * xy * xy;
+  x0 = slice[(size_t)(iy % xy) * xy + (ix % xy)];
+  x1 = slice[(size_t)((iy + h) % xy) * xy + ((ix + h) % xy)];
+}
+
+// which pixel does this QUAD own?  (4x4 pixels per wave, 8x8 per workgroup; sparse mode: 64 list entries per workgroup)
+// Dense mode: workgroup s of the 1-D grid renders the 8x8 block P.schedule[s] = bx | by << 16 - the blocks this rank owns,
+// longest rays first (schedule_kernel) - compute_screen_position of the reference (shaders_common.h:394-451) is the
+// identity on the launch index, which fixes neither an order nor a grouping.
+__device__ __forceinline__ bool assign_pixel_quad(const RayMarchParams& P, int lane, int wave, int& ix, int& iy)
+{
+  const int ray = lane >> 2;
+  bool active;
+  if (P.sparse_xy) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * (kBlock / 4) + (unsigned int)(threadIdx.x >> 2);
+    active = (2ull * i) < *P.sparse_count;
+    ix = active ? P.sparse_xy[2 * i] : 0;
+    iy = active ? P.sparse_xy[2 * i + 1] : 0;
+  }
+  else {
+    const unsigned int e = P.schedule[blockIdx.x];
+    ix = (int)(e & 0xffffu) * 8 + (wave & 1) * 4 + (ray & 3);
+    iy = (int)(e >> 16) * 8 + (wave >> 1) * 4 + (ray >> 2);
+    active = ix < P.width && iy < P.height;
+  }
+  if (P.world > 1 && active) active = ((ix / P.tile_w + iy / P.tile_h) % P.world) == P.rank;
+  return active;
+}
+
+// the primary rays' form: the 4 lanes of the quad each walk a quarter of [t0, t1]; min / max over the quad
+__device__ __forceinline__ void skip_interval(const VolConsts& vc, f3 oo, f3 od, float t0, float t1, int sub, bool live, float& t_first, float& t_last)
+{
+  float first = FLT_MAX, last = -FLT_MAX;
+  if (live) {
+    const float len = t1 - t0;
+    const float ta = fmaf((float)sub * 0.25f, len, t0), tb = sub == 3 ? t1 : fmaf((float)(sub + 1) * 0.25f, len, t0);
+    skip_walk(vc, oo, od, ta, tb, first, last);
+  }
+  t_first = fminf(fminf(quad_bcast<0>(first), quad_bcast<1>(first)), fminf(quad_bcast<2>(first), quad_bcast<3>(first)));
+  t_last = fmaxf(fmaxf(quad_bcast<0>(last), quad_bcast<1>(last)), fmaxf(quad_bcast<2>(last), quad_bcast<3>(last)));
+}
+
+template <int SHADE, bool POOLED> struct QCfg {
+#ifndef OVR_POOLED_K
+#define OVR_POOLED_K 4
+#endif
+  static constexpr int K = POOLED ? OVR_POOLED_K : (SHADE == 0 ? 4 : 3);   // instructions (x4 steps) per round
+  static constexpr int QCAP = SHADE == 0 ? 0 : (POOLED ? 128 : 256);       // pooled: spills after every instruction
+};
+
+// Register budget: at most 3 waves per SIMD (up to 168 VGPRs).  Left alone the compiler squeezes the kernel into 128 VGPRs
+// for a 4th wave by serialising the K tap groups it is supposed to keep in flight - measured 1.98 instead of 1.53 ms on C3.
+#ifndef OVR_MARCH_WPE
+#define OVR_MARCH_WPE 3
+#endif
+template <int VT, int SHADE, int AM, bool POOLED, bool SKIP>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_MARCH_WPE))) void raymarch_kernel(const RayMarchParams P)
+{
+  using Cfg = QCfg<SHADE, POOLED>;
+  constexpr int K = Cfg::K;
+  constexpr int QCAP = Cfg::QCAP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & 3;               // this lane's step inside each group of 4 consecutive steps
+  const int qbase = lane & ~3;            // first lane of the quad
+  const bool owner = sub == 0;            // the quad's lane that keeps the pixel's colour / request list
+  const unsigned long long t_start = P.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+
+  int ix, iy;
+  const bool active = assign_pixel_quad(P, lane, wave, ix, iy);
+  unsigned int n_rays = 0, n_samples = 0, n_shaded = 0, n_shadow = 0, n_skipped = 0, n_shadow_skipped = 0;
+  VolConsts vc;
+  MarchConsts mc;
+  setup_consts(P, vc, mc);
+
+  // ---- LDS carve: [request queues][offset tables][TF colour (not needed by the pooled march)][TF alpha]
+  // A workgroup none of whose rays can hit the volume (most of the image outside the silhouette) stages nothing; with
+  // empty-space skipping, neither does one whose rays only cross empty macrocells.
+  ShadeReq* const queue = reinterpret_cast<ShadeReq*>(lds_raw) + (size_t)wave * (QCAP > 0 ? QCAP : 1);
+  TfConsts tf;
+  float pro_first = FLT_MAX, pro_last = -FLT_MAX; // skipping, spp == 1: the ray's skip interval, found here once
+  const float rsx = 1.f / (float)P.width, rsy = 1.f / (float)P.height;
+  const float scx = ((float)ix + .5f) * rsx, scy = ((float)iy + .5f) * rsy;
+  // pooled: one launch per sample-per-pixel generation (P.spp_index), in place: all here.  min(P.spp, 1) is 1, but as a
+  // run-time value: with a constant trip count of 1 the compiler restructures the kernel into a schedule that keeps fewer
+  // taps in flight (126 instead of 153 VGPRs) and the C3 march takes 1.98 instead of 1.53 ms
+  const int spp = POOLED ? min(P.spp, 1) : P.spp;
+  // blue-noise jitter: the variates of this block's pixels, staged in LDS (dense mode) for the samples this launch renders
+  __shared__ float jit_lds[kJitStaged][2][64];
+  const bool jit_staged = P.jitter_mode == 1 && !P.sparse_xy;
+  if (jit_staged) {
+    const unsigned int e = P.schedule[blockIdx.x];
+    const int xy = P.jitter_xy, h = xy >> 1;
+    const int nk = min(spp, kJitStaged);
+    for (int i = threadIdx.x; i < nk * 128; i += kBlock) {
+      const int k = i >> 7, d = (i >> 6) & 1, p = i & 63;
+      const int px = (int)(e & 0xffffu) * 8 + (p & 7) + d * h, py = (int)(e >> 16) * 8 + (p >> 3) + d * h;
+      jit_lds[k][d][p] = P.jitter_noise[(size_t)jitter_slice(P, (POOLED ? P.spp_index : 0) + k) * xy * xy + (size_t)(py % xy) * xy + (px % xy)];
+    }
+    __syncthreads();
+  }
+  // the two jitter variates of sample k (k counts the samples of this launch)
+  auto jitter = [&](int k, float& x0, float& x1) {
+    if (jit_staged && k < kJitStaged) {
+      const int ray = lane >> 2;
+      const int p = ((wave >> 1) * 4 + (ray >> 2)) * 8 + (wave & 1) * 4 + (ray & 3);
+      x0 = jit_lds[k][0][p];
+      x1 = jit_lds[k][1][p];
+    }
+    else jitter_global(P, ix, iy, (POOLED ? P.spp_index : 0) + k, x0, x1);
+  };
+  bool staged; // workgroup-uniform: the offset tables and the transfer function are in LDS
+  {
+    bool need = active;
+    if (P.spp == 1 && active) { // spp == 1: the ray is known - test it (the same expressions as the march below uses)
+      float sx0 = scx, sy0 = scy;
+      if (P.jitter_mode == 1) {
+        float j0, j1;
+        jitter(0, j0, j1);
+        sx0 += (j0 - 0.5f) * rsx;
+        sy0 += (j1 - 0.5f) * rsy;
+      }
+      const float ux0 = sx0 - 0.5f, uy0 = sy0 - 0.5f;
+      const f3 c0 = ld3(P.cam_dir), h0 = ld3(P.cam_hor), v0 = ld3(P.cam_ver);
+      const f3 d0 = normalize3_exact(mk3(c0.x + ux0 * h0.x + uy0 * v0.x, c0.y + ux0 * h0.y + uy0 * v0.y, c0.z + ux0 * h0.z + uy0 * v0.z));
+      float a0 = 0.f, b0 = FLT_MAX;
+      const f3 oo0 = to_object(mc, ld3(P.cam_pos)), od0 = mk3(d0.x * mc.inv_scale.x, d0.y * mc.inv_scale.y, d0.z * mc.inv_scale.z);
+      need = intersect_unit_box(a0, b0, oo0, od0);
+      if (SKIP && need) { // skipping: a ray that meets no occupied macrocell never fetches a voxel or a TF entry either
+        skip_interval(vc, oo0, od0, a0, b0, sub, true, pro_first, pro_last);
+        need = pro_first <= pro_last;
+      }
+    }
+    staged = __syncthreads_or(need ? 1 : 0) != 0;
+    if (staged) {
+      unsigned char* base = lds_raw + (size_t)kWaves * QCAP * sizeof(ShadeReq);
+      const size_t tb = (stage_tables<VT, AM>(P, base, vc) + 15) & ~(size_t)15;
+      stage_tf(P, base + tb, !POOLED, tf);
+    }
+    else {
+      tf = TfConsts{};
+      vc.tab_x = vc.tab_y = vc.tab_z = nullptr;
+      vc.tab_z64 = nullptr;
+    }
+  }
+  const PoolDesc& Q = P.pool;
+  const unsigned int tile = blockIdx.x * kWaves + wave;
+
+  const unsigned int pixel_index = (unsigned int)ix + (unsigned int)iy * (unsigned int)P.width;
+  unsigned int v0 = (unsigned int)P.frame_index, v1 = pixel_index; // RandomTEA(frame_index, pixel_index)
+  const f3 org = ld3(P.cam_pos), cdir = ld3(P.cam_dir), chor = ld3(P.cam_hor), cver = ld3(P.cam_ver);
+  const f3 oo = to_object(mc, org);
+
+  float o_a = 0.f;
+  f3 o_c = mk3(0, 0, 0), o_g = mk3(0, 0, 0);
+  if (POOLED && P.spp > 1)
+    for (int i = 0; i < P.spp_index; ++i) tea16(v0, v1); // RandomTEA state of this generation (random.h:146-188)
+  // wave-uniform queue cursors (stream positions; slot = position & (QCAP - 1))
+  unsigned int q_head = 0, q_tail = 0;
+  // pooled: the tile's current reservation of kRun consecutive chunks
+  unsigned int run_base = 0, run_left = 0;
+  int prev_chunk = -1;
+  if (POOLED && lane == 0) Q.tile_first[tile] = -1;
+  // per-ray request list (identical in the 4 lanes of the quad; the owner lane applies the contributions)
+  int pend = 0;
+  unsigned int first = 0, last = 0, last_gidx = 0;
+  float alpha = 0.f;
+  f3 color = mk3(0, 0, 0), gradient = mk3(0, 0, 0);
+
+  // pooled: spill the n oldest queued requests as one chunk of the global pool
+  auto spill = [&](unsigned int n) {
+    if (run_left == 0) {
+      unsigned int c0 = 0;
+      if (lane == 0) c0 = atomicAdd(&Q.ctrl[0], (unsigned int)kRun);
+      run_base = (unsigned int)__builtin_amdgcn_readfirstlane((int)c0);
+      run_left = kRun;
+    }
+    const unsigned int c = run_base + (kRun - run_left);
+    --run_left;
+    if (run_base + kRun <= Q.capacity) {
+      __builtin_amdgcn_wave_barrier();
+      if ((unsigned int)lane < n) Q.reqs[(size_t)c * 64 + lane] = queue[(q_head + lane) & (QCAP - 1)];
+      if (lane == 0) {
+        Q.chunk_n[c] = n;
+        if (prev_chunk >= 0) Q.chunk_next[prev_chunk] = (int)c; else Q.tile_first[tile] = (int)c;
+      }
+      if (pend > 0 && (last - q_head) < n) last_gidx = c * 64u + (last - q_head);
+      prev_chunk = (int)c;
+    }
+    // beyond capacity: the pool is exhausted; ctrl[0] keeps counting so the host knows how much was needed, re-sizes
+    // the pool and renders the frame again (ovr_hip_api.cpp) - nothing of this frame is used
+    q_head += n;
+  };
+
+  for (int k_spp = 0; k_spp < spp; ++k_spp) { // uniform trip count: every lane of the wave runs every round
+    float sx = scx, sy = scy;
+    if (P.jitter_mode == 1) {
+      float j0, j1;
+      jitter(k_spp, j0, j1);
+      sx += (j0 - 0.5f) * rsx;
+      sy += (j1 - 0.5f) * rsy;
+    }
+    else if (P.spp > 1) {
+      tea16(v0, v1);
+      sx += ((float)v0 * OVR_TEA_TOFLOAT - 0.5f) * rsx;
+      sy += ((float)v1 * OVR_TEA_TOFLOAT - 0.5f) * rsy;
+    }
+    const float ux = sx - 0.5f, uy = sy - 0.5f;
+    const f3 dir = normalize3_exact(mk3(cdir.x + ux * chor.x + uy * cver.x, cdir.y + ux * chor.y + uy * cver.y,
+                                        cdir.z + ux * chor.z + uy * cver.z));
+    // ---- __intersection__volume: object-space ray, direction not renormalised so t is shared
+    const f3 od = mk3(dir.x * mc.inv_scale.x, dir.y * mc.inv_scale.y, dir.z * mc.inv_scale.z);
+    float t0 = 0.f, t1 = FLT_MAX;
+    alpha = 0.f;
+    color = mk3(0, 0, 0);
+    gradient = mk3(0, 0, 0);
+    bool live = active && intersect_unit_box(t0, t1, oo, od);
+    if (active && owner) ++n_rays;
+    float skip_first = -FLT_MAX, skip_last = FLT_MAX; // samples outside [skip_first, skip_last] are in empty macrocells
+    if (SKIP) {
+      if (P.spp == 1) { skip_first = pro_first; skip_last = pro_last; } // same ray, same [t0, t1] as in the prologue
+      else skip_interval(vc, oo, od, t0, t1, sub, live, skip_first, skip_last);
+    }
+    // `staged` guards the prologue's decision (it tests the same ray with the same expressions): without the tables and the TF
+    // in LDS no sample may be fetched - a skipping ray then only counts its (all empty) steps, any other ray is dead
+    if (SKIP) { if (!staged) { skip_first = FLT_MAX; skip_last = -FLT_MAX; } }
+    else live = live && staged;
+    float tx = t0, ty = fminf(t1, t0 + mc.step);
+    pend = 0;
+
+    for (;;) {
+      const bool any_live = __ballot(live) != 0ull;
+      // ---- (1) in place: shade queued requests, a full batch whenever 64 are queued, the remainder once no ray is live
+      if (SHADE != 0 && !POOLED) {
+        while ((q_tail - q_head) >= 64u || (!any_live && q_tail != q_head)) {
+          const unsigned int n = min(q_tail - q_head, 64u);
+          __builtin_amdgcn_wave_barrier(); // requests were written by other lanes of this wave (LDS ops are in order)
+          ShadeReq r;
+          r.px = r.py = r.pz = r.s = r.v = r.tr = r.a = 0.f; r.next = 0;
+          if ((unsigned int)lane < n) {
+            r = queue[(q_head + lane) & (QCAP - 1)];
+            if (r.a > 0.f) shade_request<VT, SHADE, AM, SKIP>(P, vc, tf, mc, r, n_shadow, n_shadow_skipped); // a == 0: null request
+          }
+          int opend = owner ? pend : 0;
+          apply_batch(r, q_head, n, lane, opend, first, color, gradient);
+          // the quad's lanes keep identical list cursors: take the owner's
+          pend = __builtin_amdgcn_ds_bpermute(qbase << 2, opend);
+          first = (unsigned int)__builtin_amdgcn_ds_bpermute(qbase << 2, (int)first);
+          q_head += n;
+        }
+      }
+      if (!any_live) break;
+
+      // ---- (1b) empty-space skipping, bulk form: a round whose 4K steps all lie before (after) the ray's skip interval
+      //      needs neither the lanes' own sample positions nor per-step bookkeeping - only the (tx, ty) recurrence, which
+      //      has to be run step by step (its rounding is part of the result), and one validity test: the steps' midpoints
+      //      lie in [tx_0, tx_4K], and validity (ty > tx) is monotone, so the last step being valid makes all of them valid.
+      //      ~45 instructions per round instead of ~330 for the per-step form below.
+      if (SKIP) {
+        float ntx = tx, nty = ty, ptx = tx;
+#pragma unroll
+        for (int b = 0; b < 4 * K; ++b) {
+          ptx = ntx;
+          ntx = nty;
+          nty = fminf(ntx + mc.step, t1);
+        }
+        const bool all_valid = ntx > ptx;                       // the round's last step: ty_last (= ntx) > tx_last (= ptx)
+        const bool outside = (ntx < skip_first) || (tx > skip_last);
+        const bool go = live && (alpha < 0.9999f);
+        if (__ballot(live && !(outside && all_valid)) == 0ull) {
+          n_skipped += go ? (unsigned int)K : 0u;               // this lane's K steps of the round
+          live = go;
+          tx = ntx; ty = nty;
+          continue;
+        }
+      }
+      // ---- (2) the ray's next 4K steps: every lane runs the (tx, ty) recurrence, keeps its own K steps and one validity
+      //      bit per step (ty > tx, the first half of the reference's loop condition)
+      unsigned int vmask = 0;
+      Tap taps[K];
+      f3 poss[K];
+      float dts[K], mj[K], tms[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float txq[4], tyq[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          txq[b] = tx; tyq[b] = ty;
+          vmask |= (ty > tx) ? (1u << (4 * k + b)) : 0u;
+          tx = ty;
+          ty = fminf(tx + mc.step, t1);
+        }
+        const float mtx = sel4(txq[0], txq[1], txq[2], txq[3], sub);
+        const float mty = sel4(tyq[0], tyq[1], tyq[2], tyq[3], sub);
+        dts[k] = mty - mtx;
+        tms[k] = 0.5f * (mtx + mty);
+      }
+      // empty-space fast path (wave-uniform): every sample of this round lies in a macrocell whose majorant is 0, so all
+      // opacities are exactly 0, alpha does not move and nothing is pushed - only liveness and the counters advance
+      auto skip_round = [&]() {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            live = live && ((vmask >> (4 * k + b)) & 1u) != 0u && (alpha < 0.9999f);
+            n_skipped += (live && sub == b) ? 1u : 0u;
+          }
+        }
+      };
+      if (SKIP) {
+        // (a) by the ray's skip interval: no coordinates, no majorant lookups
+        bool inside = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) inside = inside || (tms[k] >= skip_first && tms[k] <= skip_last);
+        if (__ballot(inside && live) == 0ull) { skip_round(); continue; }
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        poss[k] = mk3(fmaf(tms[k], dir.x, org.x), fmaf(tms[k], dir.y, org.y), fmaf(tms[k], dir.z, org.z));
+        tap_coords(vc, to_object(mc, poss[k]), taps[k]);
+        mj[k] = SKIP ? vc.majorant[tap_cell(vc, taps[k])] : 1.f; // empty-space skipping: the macrocell's max TF opacity
+      }
+      if (SKIP) {
+        // (b) by the majorants of this round's own macrocells
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) any = any || (mj[k] > 0.f);
+        if (__ballot(any && live) == 0ull) { skip_round(); continue; }
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (!SKIP || mj[k] > 0.f) tap_loads<VT, AM>(vc, taps[k]);
+      // ---- (3) own samples: value, TF coordinate, corrected opacity (and colour when shading is off)
+      float sa[K], va[K], aa[K];
+      f3 ca[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        sa[k] = tap_finish<VT>(vc, taps[k]);
+        va[k] = tf_coord(tf, sa[k]);
+        aa[k] = opacity_correction<false>(tf_alpha(tf, va[k]), mc.base * dts[k]);
+        if (SKIP) aa[k] = mj[k] > 0.f ? aa[k] : 0.f; // a macrocell whose majorant is 0 holds no sample with opacity > 0
+        if (SHADE == 0) {
+          const f3 rgb = tf_color(tf, va[k]);
+          ca[k] = mk3(clamp01(rgb.x), clamp01(rgb.y), clamp01(rgb.z));
+        }
+      }
+      // ---- (3b) transparent round (wave-uniform; ~9 of 10 rounds with a sparse transfer function): no live sample of any
+      //      ray of the wave has opacity > 0, so every step adds exactly 0 to alpha and colour (fma(tr, 0, x) == x) and
+      //      pushes nothing - only liveness and the counters move.  The validity bits are monotone (once ty == tx == t1 it
+      //      stays), so step i is live iff the ray was live at the start of the round, alpha < 0.9999 and bit i is set.
+#ifndef OVR_FAST_SKIP
+#define OVR_FAST_SKIP 0 /* the skipping kernels have their own, earlier fast path; this one costs them 30 VGPRs */
+#endif
+      if (OVR_FAST_SKIP || !SKIP) {
+        bool opaque = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) opaque = opaque || (aa[k] > 0.f);
+        if (__ballot(opaque && live) == 0ull) {
+          const bool go = live && (alpha < 0.9999f);
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const bool ml = go && ((vmask >> (4 * k + sub)) & 1u) != 0u;
+            n_samples += (ml && (!SKIP || mj[k] > 0.f)) ? 1u : 0u;
+            if (SKIP) n_skipped += (ml && !(mj[k] > 0.f)) ? 1u : 0u;
+          }
+          live = go && ((vmask >> (4 * K - 1)) & 1u) != 0u;
+          continue;
+        }
+      }
+      // ---- (4) the ray's alpha recurrence over the 4K steps, in order; every lane of the quad computes all of it
+      //      (a dead or zero-opacity step feeds a = 0: fma(tr, 0, alpha) == alpha exactly, so no select is needed)
+      bool mlive[K], mpush[K];
+      float mtr[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float al[4];   // alpha BEFORE each of the 4 steps
+        bool lv[4];    // the reference's loop condition at each step, shaders_raymarching.cu:110
+#define OVR_STEP(B)                                                                                                            \
+        {                                                                                                                      \
+          const float aj = quad_bcast<B>(aa[k]);                                                                               \
+          live = live && ((vmask >> (4 * k + B)) & 1u) != 0u && (alpha < 0.9999f);                                             \
+          lv[B] = live;                                                                                                        \
+          al[B] = alpha;                                                                                                       \
+          const float ae = live ? aj : 0.f;                                                                                    \
+          const float trj = 1.f - alpha;                                                                                       \
+          if (SHADE == 0) {                                                                                                    \
+            const float cxj = quad_bcast<B>(ca[k].x), cyj = quad_bcast<B>(ca[k].y), czj = quad_bcast<B>(ca[k].z);              \
+            color.x = fmaf(trj * cxj, ae, color.x);                                                                            \
+            color.y = fmaf(trj * cyj, ae, color.y);                                                                            \
+            color.z = fmaf(trj * czj, ae, color.z);                                                                            \
+          }                                                                                                                    \
+          alpha = fmaf(trj, ae, alpha);                                                                                        \
+        }
+        OVR_STEP(0) OVR_STEP(1) OVR_STEP(2) OVR_STEP(3)
+#undef OVR_STEP
+        mlive[k] = sub == 0 ? lv[0] : sub == 1 ? lv[1] : sub == 2 ? lv[2] : lv[3];
+        mtr[k] = 1.f - sel4(al[0], al[1], al[2], al[3], sub);
+        // a sample whose corrected opacity is exactly 0 adds exactly 0 to colour, gradient and alpha: nothing is shaded
+        mpush[k] = mlive[k] && (aa[k] > 0.f);
+      }
+      // ---- (5) count; queue the samples that need shading (slot = tail + prefix of the ballot, lane order = step order)
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        n_samples += (mlive[k] && (!SKIP || mj[k] > 0.f)) ? 1u : 0u;
+        if (SKIP) n_skipped += (mlive[k] && !(mj[k] > 0.f)) ? 1u : 0u;
+        n_shaded += mpush[k] ? 1u : 0u;
+        if (SHADE != 0) {
+          // Quad-granular compaction: if any of a ray's 4 steps needs shading the ray takes 4 consecutive slots (the steps
+          // that do not are written as null requests, a == 0, and cost the shader nothing but an idle lane).  Stream
+          // positions stay multiples of 4, so in every 64-request chunk the 4 lanes of a quad shade 4 consecutive steps of
+          // ONE ray: their gradient and shadow taps are 1 voxel apart and share bricks (texture-addresser coalescing).
+          const bool push = mpush[k];
+          const unsigned long long mp = __ballot(push);
+          if (mp != 0ull) {
+            const unsigned int quad_bits = (unsigned int)(mp >> qbase) & 0xfu;
+            const bool qpush = quad_bits != 0u;
+            const unsigned long long m = __ballot(qpush); // whole quads
+            const unsigned int below = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+            if (qpush) {
+              const unsigned int pos_q = q_tail + below;            // = quad_first + sub
+              const unsigned int quad_first = pos_q - (unsigned int)sub;
+              const unsigned int higher = quad_bits >> (sub + 1);   // later steps of this ray pushed by this instruction
+              ShadeReq r;
+              r.px = poss[k].x; r.py = poss[k].y; r.pz = poss[k].z;
+              r.s = sa[k]; r.v = va[k]; r.tr = mtr[k];
+              r.a = push ? aa[k] : 0.f;
+              r.next = (push && higher != 0u) ? (int)(pos_q + 1u + (unsigned int)__builtin_ctz(higher)) : 0;
+              queue[pos_q & (QCAP - 1)] = r;
+              const unsigned int first_sub = (unsigned int)__builtin_ctz(quad_bits), last_sub = 31u - (unsigned int)__builtin_clz(quad_bits);
+              if (push && (unsigned int)sub == first_sub && pend > 0) { // link the ray's previous request to this one
+                if (!POOLED || (int)(last - q_head) >= 0) queue[last & (QCAP - 1)].next = (int)pos_q; // still in LDS
+                else Q.reqs[last_gidx].next = (int)pos_q;                                              // already spilled
+              }
+              if (pend == 0) first = quad_first + first_sub;
+              last = quad_first + last_sub;
+              pend += (int)__popc(quad_bits);
+            }
+            q_tail += (unsigned int)__popcll(m);
+            if (POOLED && (q_tail - q_head) >= 64u) spill(64u);
+          }
+        }
+      }
+    }
+
+    // render_raymarching / alpha_blend with an always-missing background (shaders_raymarching.cu:260-321)
+    if (!POOLED) {
+      o_a += alpha;
+      if (alpha > 0.f) {
+        o_c.x += color.x / alpha; o_c.y += color.y / alpha; o_c.z += color.z / alpha;
+        o_g.x += gradient.x / alpha; o_g.y += gradient.y / alpha; o_g.z += gradient.z / alpha;
+      }
+    }
+  }
+
+  if (POOLED) {
+    if (q_tail != q_head) spill(q_tail - q_head); // the tile's last, partial chunk
+    if (lane == 0 && run_base + kRun <= Q.capacity)
+      for (unsigned int i = kRun - run_left; i < (unsigned int)kRun && run_left != 0; ++i) Q.chunk_n[run_base + i] = 0; // unused tail of the reservation
+    if (lane == 0) Q.tile_count[tile] = q_tail;
+    if (active && owner) Q.pix_state[pixel_index] = make_float4(alpha, __uint_as_float(first), __int_as_float(pend), 0.f);
+  }
+  else if (active && owner) {
+    const float rspp = 1.f / (float)spp;
+    o_a *= rspp;
+    o_c.x *= rspp; o_c.y *= rspp; o_c.z *= rspp;
+    o_g.x *= rspp; o_g.y *= rspp; o_g.z *= rspp;
+    write_pixel(P, pixel_index, o_c, o_a, o_g);
+  }
+
+  if (P.trace && lane == 0) { // diagnostic only (OVR_HIP_TRACE): per-wave residency interval and work, never read by the kernel
+    unsigned long long* t = P.trace + (size_t)tile * 4;
+    t[0] = t_start; t[1] = __builtin_amdgcn_s_memrealtime();
+    t[2] = ((unsigned long long)n_samples << 32) | n_shaded; t[3] = n_shadow;
+  }
+  store_block_counters(P, reinterpret_cast<unsigned int*>(lds_raw), lane, wave, n_rays, n_samples, n_shaded, n_shadow,
+                       (active && owner && (!POOLED || P.spp_index == 0)) ? 1u : 0u, n_skipped,
+                       n_shadow_skipped);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// pooled pipeline, kernel B: persistent waves shade chunks from all tiles; one returning atomic per chunk
+// ------------------------------------------------------------------------------------------------------------------
+template <int VT, int SHADE, int AM, bool SKIP>
+__global__ __launch_bounds__(kBlock) void shade_pool_kernel(const RayMarchParams P)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  TfConsts tf;
+  VolConsts vc;
+  MarchConsts mc;
+  setup_consts(P, vc, mc);
+  const size_t tb = (stage_tables<VT, AM>(P, lds_raw, vc) + 15) & ~(size_t)15; // [offset tables][TF]
+  stage_tf(P, lds_raw + tb, true, tf);
+  const PoolDesc& Q = P.pool;
+  const unsigned int n_runs = Q.ctrl[0] > Q.capacity ? 0u : Q.ctrl[0] / (unsigned int)kRun; // overflow: the frame is re-rendered
+  unsigned int n_shadow = 0, n_shadow_skipped = 0;
+  __shared__ unsigned int s_run;
+  for (;;) {
+    // one returning atomic per workgroup and run; the 4 waves shade the run's chunks (consecutive depth steps of ONE
+    // tile: their gradient and shadow taps fall into the same bricks, which the CU's L1 and the XCD's L2 now keep)
+    __syncthreads();
+    if (threadIdx.x == 0) s_run = atomicAdd(&Q.ctrl[1], 1u);
+    __syncthreads();
+    const unsigned int run = s_run;
+    if (run >= n_runs) break; // every workgroup reaches this: the cursor only grows
+    for (unsigned int i = (unsigned int)wave; i < (unsigned int)kRun; i += kWaves) {
+      const unsigned int c = run * kRun + i;
+      const unsigned int n = Q.chunk_n[c];
+      if ((unsigned int)lane < n) {
+        ShadeReq r = Q.reqs[(size_t)c * 64 + lane];
+        if (r.a > 0.f) { // a == 0: null request (a step of the quad that needs no shading)
+          shade_request<VT, SHADE, AM, SKIP>(P, vc, tf, mc, r, n_shadow, n_shadow_skipped);
+          Q.reqs[(size_t)c * 64 + lane] = r;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n_shadow += __shfl_down(n_shadow, off);
+    n_shadow_skipped += __shfl_down(n_shadow_skipped, off);
+  }
+  __syncthreads();
+  unsigned int* red = reinterpret_cast<unsigned int*>(lds_raw);
+  if (lane == 0) { red[wave] = n_shadow; red[kWaves + wave] = n_shadow_skipped; }
+  __syncthreads();
+  if (threadIdx.x == 0 && Q.shade_counters) {
+    Q.shade_counters[2 * blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    Q.shade_counters[2 * blockIdx.x + 1] = red[4] + red[5] + red[6] + red[7];
+  }
+}
+
+
+constexpr int kReduceBlocks = 64;
+
+// the two kernels of the pooled pipeline that do not depend on the voxel type live in ovr_hip_kernels.hip
+hipError_t launch_composite(const RayMarchParams& q, dim3 grid, hipStream_t stream);
+hipError_t launch_reduce_counters(const unsigned int* partials, int n_blocks, const unsigned int* shade_partials, int n_shade_blocks,
+                                  unsigned long long* counters, unsigned int* pool_ctrl, hipStream_t stream);
+
+inline dim3 raymarch_grid(const RayMarchParams& p)
+{
+  return dim3((unsigned)raymarch_grid_blocks(p));
+}
+
+template <typename KernT>
+inline hipError_t set_lds(KernT kern, size_t lds)
+{
+  if (lds > 64 * 1024) return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  return hipSuccess;
+}
+
+constexpr int kShadeBlocks = 1024; // persistent shade grid: 4 workgroups per CU
+
+template <int VT, int SHADE, int AM, bool SKIP>
+inline hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const hipEvent_t* ev)
+{
+  const size_t tf_lds = raymarch_lds_bytes(p.n_color, p.n_alpha);
+  if (tf_lds == 0) return hipErrorInvalidValue;
+  if (!p.sparse_xy && p.n_schedule > 0 && !p.schedule) return hipErrorInvalidValue;
+  const dim3 grid = raymarch_grid(p), block(kBlock);
+  hipError_t e;
+  const bool pooled = (SHADE != 0) && p.pool.reqs != nullptr;
+  if (!pooled) {
+    const size_t lds = std::max<size_t>(tf_lds + table_lds_bytes(p, AM) + (size_t)kWaves * QCfg<SHADE, false>::QCAP * sizeof(ShadeReq), 64); // >= 64 B: the counter reduction reuses it
+    auto kern = raymarch_kernel<VT, SHADE, AM, false, SKIP>;
+    if ((e = set_lds(kern, lds)) != hipSuccess) return e;
+    if (grid.x > 0) hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (ev) { (void)hipEventRecord(ev[1], stream); (void)hipEventRecord(ev[2], stream); }
+    if (p.block_counters && p.counters) {
+      if ((e = hipMemsetAsync(p.counters, 0, 8 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+      if ((e = launch_reduce_counters(p.block_counters, (int)raymarch_grid_blocks(p), nullptr, 0, p.counters, nullptr, stream)) != hipSuccess) return e;
+    }
+    return hipGetLastError();
+  }
+  // ---- pooled pipeline: march -> shade -> composite, once per sample-per-pixel generation
+  if ((e = hipMemsetAsync(p.pool.ctrl, 0, 4 * sizeof(unsigned int), stream)) != hipSuccess) return e;
+  if (p.block_counters && p.counters)
+    if ((e = hipMemsetAsync(p.counters, 0, 8 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+  RayMarchParams q = p;
+  for (int g = 0; g < p.spp; ++g) {
+    q.spp_index = g;
+    if (g > 0 && (e = hipMemsetAsync(p.pool.ctrl, 0, 2 * sizeof(unsigned int), stream)) != hipSuccess) return e;
+    {
+      constexpr int SH = SHADE == 0 ? 1 : SHADE; // (never instantiated for SHADE == 0: pooled is false)
+      const size_t lds = (size_t)kWaves * QCfg<SH, true>::QCAP * sizeof(ShadeReq) + table_lds_bytes(p, AM) + (size_t)p.n_alpha * sizeof(float) + 64;
+      auto kern = raymarch_kernel<VT, SH, AM, true, SKIP>;
+      if ((e = set_lds(kern, lds)) != hipSuccess) return e;
+      if (grid.x > 0) hipLaunchKernelGGL(kern, grid, block, lds, stream, q);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (ev && g == p.spp - 1) (void)hipEventRecord(ev[1], stream);
+    {
+      const size_t lds = std::max<size_t>(tf_lds + table_lds_bytes(p, AM), 64);
+      auto kern = shade_pool_kernel<VT, SHADE, AM, SKIP>;
+      if ((e = set_lds(kern, lds)) != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(kShadeBlocks), block, lds, stream, q);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (ev && g == p.spp - 1) (void)hipEventRecord(ev[2], stream);
+    if (grid.x > 0 && (e = launch_composite(q, grid, stream)) != hipSuccess) return e;
+    if (p.block_counters && p.counters)
+      if ((e = launch_reduce_counters(p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)p.pool.shade_counters, kShadeBlocks, p.counters,
+                                      p.pool.ctrl, stream)) != hipSuccess) return e;
+  }
+  return hipGetLastError();
+}
+
+template <int VT, int SHADE, int AM>
+inline hipError_t launch_vsb(const RayMarchParams& p, hipStream_t stream, const hipEvent_t* ev)
+{
+  // empty-space skipping is a separate instantiation: the non-skipping kernels stay exactly as they are
+  if (p.majorant) return launch_vsbs<VT, SHADE, AM, true>(p, stream, ev);
+  return launch_vsbs<VT, SHADE, AM, false>(p, stream, ev);
+}
+
+template <int VT, int SHADE>
+inline hipError_t launch_vs(const RayMarchParams& p, hipStream_t stream, const hipEvent_t* ev)
+{
+  // addressing mode: 0 = 32-bit byte offsets (volume <= 4 GiB; largest byte offset = bytes - sizeof(voxel)),
+  //                  1 = 32-bit element offsets (< 2^32 stored voxels), 2 = 64-bit z table in LDS,
+  //                  3 = 64-bit, computed (axis tables would not fit in LDS next to the queues: a dimension beyond ~8000)
+  int am = p.vol.bytes <= 0x100000000ull ? 0 : (p.vol.bytes / voxel_size(p.vol.type) < 0xffffffffull) ? 1 : 2;
+  if (const char* f = getenv("OVR_HIP_ADDRESSING")) am = std::max(am, atoi(f)); // diagnostic: a more general mode than needed (tests)
+  if (am == 2 && table_lds_bytes(p, 2) > 64 * 1024) am = 3;
+  switch (am) {
+  case 0: return launch_vsb<VT, SHADE, 0>(p, stream, ev);
+  case 1: return launch_vsb<VT, SHADE, 1>(p, stream, ev);
+  case 2: return launch_vsb<VT, SHADE, 2>(p, stream, ev);
+  default: return launch_vsb<VT, SHADE, 3>(p, stream, ev);
+  }
+}
+
+// one explicit instantiation per voxel type, each in its own translation unit (ovr_hip_march_*.hip): the ~60 kernel variants of
+// a type compile in parallel with the other types
+template <int VT>
+hipError_t launch_v(const RayMarchParams& p, hipStream_t stream, const hipEvent_t* ev)
+{
+  switch (p.shading) {
+  case 0: return launch_vs<VT, 0>(p, stream, ev);
+  case 1: return launch_vs<VT, 1>(p, stream, ev);
+  default: return launch_vs<VT, 2>(p, stream, ev);
+  }
+}
+
+
+} // namespace ovrhip

@@ -8,7 +8,9 @@
 namespace ovrhip {
 
 // device-resident scalar types of the bricked volume (u32/i32/f64 inputs are converted at upload, see relayout)
-enum VoxelType : int { VOX_U8 = 0, VOX_I8 = 1, VOX_U16 = 2, VOX_I16 = 3, VOX_F32 = 4 };
+// VOX_*_T / VOX_*_TT are not further scalar types but further LAYOUTS of a resident f32 / u16 volume ("thin" replicas, below)
+enum VoxelType : int { VOX_U8 = 0, VOX_I8 = 1, VOX_U16 = 2, VOX_I16 = 3, VOX_F32 = 4, VOX_F32_T = 5, VOX_F32_TT = 6, VOX_U16_T = 7, VOX_U16_TT = 8 };
+enum VolumeLayout : int { LAYOUT_GENERAL = 0, LAYOUT_THIN = 1, LAYOUT_THIN_T = 2 };
 
 // Volume layout in HBM ("x-apron bricks in macro blocks"):
 //   voxels are grouped into 128-byte bricks = one L1/L2 line.  A brick covers CX x 4 x (2|4) cells and stores CX+1 voxels
@@ -20,9 +22,17 @@ enum VoxelType : int { VOX_U8 = 0, VOX_I8 = 1, VOX_U16 = 2, VOX_I16 = 3, VOX_F32
 //   One line holds one 3-D brick: the 2x2x2 footprint of a tap touches ~2.4 lines for ANY ray direction (a row-major
 //   layout touches 4 and loses all reuse as soon as rays do not run along x: measured 81 % L1 / 52 % L2 miss rate on the
 //   oblique bench camera), and a tap is 4 pair loads instead of 8 scalar loads.
+//
+// View-dependent replicas (288 GB of HBM buy bandwidth): when the rays of a frame run within ~18 degrees of a volume axis - 12 of
+//   the reference's 21 shipped scene cameras do - and are sparser than the voxels, a general brick is mostly wasted: a ray uses
+//   a 2 x 2 column of it.  A THIN replica stores 1 cell (+ apron) along the pair axis and 4 x 4 (f32) / 4 x 8 (u16) voxels
+//   across: thin across the rays, 4-8 steps deep along them.  VOX_*_T has the pair axis on x (for rays along y or z), VOX_*_TT
+//   is the same layout of the volume with x and y exchanged (pair axis = the volume's y; for rays along x).  The tap reads the
+//   same 8 voxels and lerps them in the same order from any layout, so frames are bit-identical; the host picks the replica
+//   per frame from the camera direction (ovr_hip_api.cpp: choose_layout).  Measured: profiles/r02_notes.md.
 struct VolumeDesc {
   const void* data;
-  int type;        // VoxelType
+  int type;        // VoxelType (of this replica: the base type, or its _T / _TT variant)
   int nx, ny, nz;
   int macros_x, macros_y, macros_z;
   unsigned int macro_elems;         // stored voxels per macro block
@@ -108,10 +118,11 @@ size_t raymarch_grid_blocks(const RayMarchParams& p);
 // sorts the n owned blocks of src (bx | by << 16, any order) by descending ray length into dst; uses p's camera and box
 hipError_t launch_schedule(const RayMarchParams& p, const unsigned int* src, unsigned int n, unsigned int* dst, hipStream_t stream);
 
-// linear (x fastest) -> bricked layout; src may be any reference ValueType, dst is the VoxelType chosen by
-// device_voxel_type().  z0/nz_chunk allow chunked uploads from host staging.
+// linear (x fastest) -> bricked layout; src may be any reference ValueType, dst is laid out as vd.type says (the VoxelType
+// chosen by device_voxel_type() or one of its replicas).  z0/nz_chunk allow chunked uploads from host staging.
 int device_voxel_type(int ovr_value_type);
-void volume_layout(int voxel_type, int nx, int ny, int nz, VolumeDesc& vd); // fills macros_*, macro_elems, bytes
+int replica_voxel_type(int base_voxel_type, int layout); // the VoxelType of a layout of a base type, -1 if that replica does not exist
+void volume_layout(int voxel_type, int nx, int ny, int nz, VolumeDesc& vd); // fills type, nx.., macros_*, macro_elems, bytes
 size_t voxel_size(int voxel_type);
 hipError_t launch_relayout(const void* src_linear, int ovr_value_type, void* dst, const VolumeDesc& vd, int z0, int nz_chunk,
                            hipStream_t stream);

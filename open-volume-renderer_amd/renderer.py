@@ -207,6 +207,15 @@ class DeviceHIP:
         L.check(self._lib.ovr_hip_get_volume_info(self._h, C.byref(v)))
         return v
 
+    def set_volume_layouts(self, mode):
+        """which layouts of the volume the next init / volume upload keeps in HBM: 0 general only, 1 (default) thin replicas
+        when they fit comfortably, 2 always (include/ovr_hip.h)"""
+        L.check(self._lib.ovr_hip_set_volume_layouts(self._h, int(mode)))
+
+    def set_layout_choice(self, choice):
+        """-1 (default): the layout a frame reads follows the camera direction; 0 / 1 / 2: forced.  Frames are bit-identical."""
+        L.check(self._lib.ovr_hip_set_layout_choice(self._h, int(choice)))
+
     def set_grid_convention(self, convention):
         L.check(self._lib.ovr_hip_set_grid_convention(self._h, int(convention)))
 

@@ -145,6 +145,10 @@ def make_camera(kind, n, convention="cell"):
         eye = C + 1.9 * n * d / np.linalg.norm(d)
     elif kind == "inside":
         eye = C + np.array([0.11 * n, -0.07 * n, 0.23 * n])
+    elif kind.startswith("tilt"):   # the front camera swung off the z axis by <n> degrees (towards +x, a little +y)
+        a = math.radians(float(kind[4:]))
+        d = np.array([math.sin(a) * math.cos(math.radians(35.0)), math.sin(a) * math.sin(math.radians(35.0)), math.cos(a)])
+        eye = C + 2.65 * n * d
     elif kind in _EXTRA_CAMERAS:   # the other axes and diagonals (layout / view-dependence measurements)
         d, dist, up = _EXTRA_CAMERAS[kind]
         d = np.array(d, dtype=np.float64)

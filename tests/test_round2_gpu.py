@@ -238,3 +238,102 @@ def test_bench_launches_its_own_ranks(tmp_path):
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "tiny"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
+
+
+# ---- view-dependent volume replicas (thin layouts) ----------------------------------------------------------------------------
+
+_AXIS_CAMS = {"x": ((200.0, 3.0, -2.0), (0.0, 1.0, 0.0)), "y": ((4.0, 190.0, 5.0), (0.0, 0.0, 1.0)), "z": ((-3.0, 2.0, 210.0), (0.0, 1.0, 0.0)),
+              "oblique": ((-120.0, 70.0, 66.0), (0.0, 1.0, 0.0))}
+
+
+def _layout_case(ovr, oracle, dtype, dims, cam, shading=2, size=(88, 56)):
+    case = make_case(ovr, oracle, dtype=dtype, dims=dims, tf="bumps", size=size, shading=shading)
+    c = np.array(dims, dtype=np.float64) / 2.0
+    off, up = _AXIS_CAMS[cam]
+    case["cam"] = (tuple(c + np.array(off)), tuple(c), up)
+    return case
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint16, np.float64])
+@pytest.mark.parametrize("cam", ["x", "y", "z", "oblique"])
+def test_layouts_are_bit_identical(ovr, oracle, hip_renderer_factory, dtype, cam):
+    """the general layout and the two thin replicas (pair axis x / pair axis y) of a non-cubic volume give the same frame bit
+    for bit - with and without empty-space skipping, both pipelines - and that frame agrees with the oracle"""
+    dims = (45, 70, 33)   # nx != ny != nz: an exchanged axis cannot go unnoticed
+    case = _layout_case(ovr, oracle, dtype, dims, cam)
+    ren = hip_renderer_factory()
+    ren.set_volume_layouts(2)
+    hip_setup(ovr, ren, case)
+    frames = {}
+    for choice in (0, 1, 2):
+        for skip, pipeline in ((False, 0), (True, 0), (False, 1)):
+            ren.set_layout_choice(choice)
+            ren.set_empty_space_skipping(skip)
+            ren.set_shading_pipeline(pipeline)
+            ren.commit()
+            ren.render()
+            st = ren.stats()
+            assert st.layout == choice
+            frames[(choice, skip, pipeline)] = (hip_frame(ovr, ren), (st.samples + st.skipped_samples, st.shaded_samples, st.shadow_samples + st.skipped_shadow_samples))
+    (ref_rgba, ref_grad), ref_cnt = frames[(0, False, 0)]
+    for k, ((rgba, grad), cnt) in frames.items():
+        assert np.array_equal(rgba, ref_rgba) and np.array_equal(grad, ref_grad), k
+        assert cnt == ref_cnt, k
+    o_rgba, _, cnt = oracle_scene(oracle, case).render()
+    assert ref_cnt[0] == cnt.samples and ref_cnt[1] == cnt.shaded_samples and cnt.shaded_samples > 100
+    compare(oracle, ref_rgba, o_rgba, name=f"layouts {np.dtype(dtype).name} {cam}")
+    info = ren.volume_info()
+    assert info.resident_bytes > 3 * case["vol"].size * min(case["vol"].itemsize, 4)   # general (x 4/3) + two thin (x 2 each)
+    ren.close()
+
+
+def test_layout_follows_the_camera(ovr, oracle, hip_renderer_factory):
+    """within ~18 degrees of a volume axis the frame reads a thin replica (pair axis off that axis); types without replicas and
+    renderers told not to build them stay on the general layout"""
+    dims = (40, 40, 40)
+    expect = {"x": 2, "y": 1, "z": 1, "oblique": 0}
+    for cam, layout in expect.items():
+        case = _layout_case(ovr, oracle, np.float32, dims, cam, shading=1, size=(48, 32))
+        ren = hip_setup(ovr, hip_renderer_factory(), case)
+        ren.render()
+        assert ren.stats().layout == layout, cam
+        ren.close()
+    case = _layout_case(ovr, oracle, np.uint8, dims, "z", shading=1, size=(48, 32))
+    ren = hip_setup(ovr, hip_renderer_factory(), case)
+    ren.render()
+    assert ren.stats().layout == 0
+    ren.close()
+    case = _layout_case(ovr, oracle, np.float32, dims, "z", shading=1, size=(48, 32))
+    ren = hip_renderer_factory()
+    ren.set_volume_layouts(0)
+    hip_setup(ovr, ren, case)
+    general_only = ren.volume_info().resident_bytes
+    ren.render()
+    assert ren.stats().layout == 0
+    ren.close()
+    ren = hip_setup(ovr, hip_renderer_factory(), case)
+    assert ren.volume_info().resident_bytes > 3 * general_only
+    # anisotropic spacing: the choice is made in object space (a view along world z is still along the volume's z)
+    ren.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_thin_layouts_in_every_addressing_mode(ovr, oracle, hip_renderer_factory, mode):
+    """the 32-bit element, 64-bit z-table and computed addressing modes forced onto the thin replicas of a small volume"""
+    case = _layout_case(ovr, oracle, np.uint16, (37, 29, 50), "y", shading=2, size=(64, 40))
+    ren = hip_renderer_factory()
+    ren.set_volume_layouts(2)
+    hip_setup(ovr, ren, case)
+    ren.render()
+    ref = hip_frame(ovr, ren)[0]
+    os.environ["OVR_HIP_ADDRESSING"] = str(mode)
+    try:
+        for choice in (1, 2):
+            ren.set_layout_choice(choice)
+            ren.commit()
+            ren.render()
+            assert ren.stats().layout == choice
+            assert np.array_equal(hip_frame(ovr, ren)[0], ref), (mode, choice)
+    finally:
+        del os.environ["OVR_HIP_ADDRESSING"]
+    ren.close()
