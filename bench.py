@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--tile", type=int, default=16, help="image-shard tile size in pixels (16: best balance over 8 ranks, tools/shard_balance.py)")
     ap.add_argument("--no-skip-leg", action="store_true", help="do not time the extra leg with empty-space skipping (N = 1 only)")
     ap.add_argument("--no-views", action="store_true", help="do not time the camera x transfer-function matrix (N = 1 only)")
+    ap.add_argument("--layout", type=int, default=-1, choices=[-1, 0, 1, 2], help="volume layout a frame reads: -1 by camera direction (default), 0 general, 1 thin, 2 thin transposed")
+    ap.add_argument("--lds-staging", action="store_true", help="unshaded march of float volumes: stage the bricks of each round through LDS (measurement switch)")
     ap.add_argument("--skip-empty", action="store_true", help="enable macrocell empty-space skipping (not the headline: fewer samples are fetched)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -242,6 +244,8 @@ def worker(args, world):
         ren.set_pixel_jitter(ovr.JITTER_BLUE_NOISE)
     if multi:
         ren.set_image_shard(rank, world, args.tile, args.tile)
+    ren.set_layout_choice(args.layout)
+    ren.set_lds_staging(args.lds_staging)
     scene = ovr.Scene(volume=vol, transfer_function=None, volume_sampling_rate=cfg["rate"])
     ren.init(scene, ovr.Camera(*cam))
     ren.set_camera(*cam)  # fovy 60, as renderbatch ends up with (renderer.h:149-152)
@@ -444,7 +448,7 @@ def worker(args, world):
                        "transfer_function": cfg["tf"], "camera": cfg["cam"], "fovy": 60, "sampling_rate": cfg["rate"],
                        "spp": cfg["spp"], "pixel_jitter": "blue-noise tile (synthetic 64x64x64), slice = frame % 64" if noise is not None else "RandomTEA iff spp > 1 (reference)",
                        "shading": ["none", "gradient", "gradient+shadow"][cfg["shading"]],
-                       "frame_accumulation": True, "empty_space_skipping": bool(args.skip_empty), "parallelism": f"image tiles {args.tile}x{args.tile} over {world} rank(s)"},
+                       "frame_accumulation": True, "empty_space_skipping": bool(args.skip_empty), "volume_layout_read": ["general", "thin", "thin transposed"][last_stats.layout], "parallelism": f"image tiles {args.tile}x{args.tile} over {world} rank(s)"},
             "per_frame": {k: per_step[k] for k in sorted(per_step)},
             # the dominant kernel of the frame (longest mean launch); the whole pipeline and the other kernels beside it
             "roofline": {"bound": "hbm", "achieved": kern[dom]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -459,7 +463,9 @@ def worker(args, world):
                          "compulsory_floor_bytes": floor_bytes,
                          "volume_resident_bytes": int(vinfo.resident_bytes),
                          "phase_ms_rank0": {"march": ph[0], "shade": ph[1], "composite": ph[2]},
-                         "pool_chunks": int(last_stats.pool_chunks)},
+                         "pool_chunks": int(last_stats.pool_chunks),
+                         "lds_staging": {"on": bool(args.lds_staging), "fallback_taps_per_frame": int(last_stats.lds_fallback_taps),
+                                         "unstaged_workgroup_rounds_per_frame": int(last_stats.lds_unstaged_rounds)}},
         }
         if multi:
             out["rccl_ranks"] = dist.get_world_size()

@@ -76,6 +76,8 @@ typedef struct ovr_hip_stats {
   uint64_t skipped_shadow_samples; /* same for shadow-march iterations (not in `shadow_samples`)                 */
   int32_t layout;           /* which resident layout of the volume the frame read: 0 general, 1 thin, 2 thin transposed */
   int32_t reserved;
+  uint64_t lds_fallback_taps;   /* LDS-staged bricks: taps of live samples that fell outside the staged box (read from L1/L2 instead) */
+  uint64_t lds_unstaged_rounds; /* LDS-staged bricks: workgroup rounds whose box exceeded the LDS budget (ordinary path)            */
 } ovr_hip_stats;
 
 const char* ovr_hip_last_error(void);
@@ -149,6 +151,10 @@ int ovr_hip_set_empty_space_skipping(ovr_hip_renderer* r, int32_t enabled);
 #define OVR_HIP_JITTER_TEA 0
 #define OVR_HIP_JITTER_BLUE_NOISE 1
 int ovr_hip_set_pixel_jitter(ovr_hip_renderer* r, int32_t mode);
+/* extension (north_star "volume brick-tiled into LDS"): the unshaded (OVR_HIP_SHADE_NONE), non-skipping march of a float volume
+ * stages, once per round of 16 steps, every brick its 8x8-pixel workgroup can touch into LDS with whole-line loads and taps read
+ * LDS.  Bit-identical frames.  0 = off (default: it is slower than the L1 path wherever measured, profiles/r02_notes.md), 1 = on. */
+int ovr_hip_set_lds_staging(ovr_hip_renderer* r, int32_t mode);
 /* downloads the macrocell grids (for known-answer tests): dims = cells per axis; minmax = 2 floats per cell, majorant = 1 */
 int ovr_hip_get_macrocells(ovr_hip_renderer* r, int32_t dims[3], float* minmax_host, float* majorant_host, size_t capacity_cells);
 /* extension (multi-GPU): this renderer draws only the image tiles owned by `rank` of `world`;

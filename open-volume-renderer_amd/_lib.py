@@ -41,6 +41,8 @@ class Stats(C.Structure):
         ("skipped_shadow_samples", C.c_uint64),
         ("layout", C.c_int32),
         ("reserved", C.c_int32),
+        ("lds_fallback_taps", C.c_uint64),
+        ("lds_unstaged_rounds", C.c_uint64),
     ]
 
 
@@ -97,6 +99,7 @@ SYMBOLS = {
     "ovr_hip_sparse_mask": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]),
     "ovr_hip_tea_floats": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int64]),
     "ovr_hip_set_pixel_jitter": (C.c_int, [_H, C.c_int32]),
+    "ovr_hip_set_lds_staging": (C.c_int, [_H, C.c_int32]),
     "ovr_hip_set_volume_layouts": (C.c_int, [_H, C.c_int32]),
     "ovr_hip_set_layout_choice": (C.c_int, [_H, C.c_int32]),
     "ovr_hip_get_volume_info": (C.c_int, [_H, C.POINTER(VolumeInfo)]),

@@ -105,7 +105,7 @@ struct ovr_hip_renderer {
   Queued<CameraP> camera;
   Queued<TfnP> tfn;
   Queued<FocusP> focus;
-  Queued<int> spp, sparse, accumulate, shading, grid_convention, pipeline, skipping, jitter;
+  Queued<int> spp, sparse, accumulate, shading, grid_convention, pipeline, skipping, jitter, lds_staging;
   Queued<float> rate;
   Queued<ShardP> shard;
 
@@ -546,16 +546,19 @@ int enqueue_frame(ovr_hip_renderer* r)
   }
   {
     // which replica of the volume this frame reads (ovr_hip_kernels.h "View-dependent replicas"): the central ray's direction in
-    // object space; within ~18 degrees of an axis (dominant component >= 0.95: measured crossover, profiles/r02_notes.md) the
-    // thin replica whose pair axis is NOT that axis
+    // object space; within ~21 degrees of an axis (measured crossover 18-23 degrees, profiles/r02_notes.md) a thin replica
     int choice = r->layout_choice.current;
     if (choice < 0) {
       const float dx = P.cam_dir.x * P.inv_scale.x, dy = P.cam_dir.y * P.inv_scale.y, dz = P.cam_dir.z * P.inv_scale.z;
       const float len = std::sqrt(dx * dx + dy * dy + dz * dz);
       const float ax = std::fabs(dx) / len, ay = std::fabs(dy) / len, az = std::fabs(dz) / len;
+      // rays along x need the replica that is thin in y (pair axis y), rays along y the one thin in x; rays along z can use
+      // either - the one that is 4 voxels wide in the direction the rays drift to is 4-7 % faster (profiles/r02_notes.md)
       choice = LAYOUT_GENERAL;
-      if (ax >= 0.95f) choice = LAYOUT_THIN_T;
-      else if (ay >= 0.95f || az >= 0.95f) choice = LAYOUT_THIN;
+      const float kAxis = 0.93f; // ~21 degrees
+      if (ax >= kAxis) choice = LAYOUT_THIN_T;
+      else if (ay >= kAxis) choice = LAYOUT_THIN;
+      else if (az >= kAxis) choice = ax >= ay ? LAYOUT_THIN_T : LAYOUT_THIN;
     }
     if (choice < 0 || choice > 2 || !r->d_replica[choice]) choice = LAYOUT_GENERAL;
     const float vs = P.vol.value_scale, vm = P.vol.value_min_clamp;
@@ -572,6 +575,8 @@ int enqueue_frame(ovr_hip_renderer* r)
   P.world = r->shard.current.world;
   P.tile_w = r->shard.current.tw;
   P.tile_h = r->shard.current.th;
+  P.lds_staging = r->lds_staging.current;
+  P.lds_brick_offset = 0;
   P.jitter_mode = r->jitter.current;
   P.jitter_noise = r->d_noise;
   P.jitter_xy = r->noise_xy;
@@ -682,6 +687,13 @@ int finish_frame(ovr_hip_renderer* r)
   r->stats.active_pixels = r->h_counters[4];
   r->stats.skipped_samples = r->h_counters[5];
   r->stats.skipped_shadow_samples = r->h_counters[6];
+  r->stats.lds_fallback_taps = r->stats.lds_unstaged_rounds = 0;
+  if (r->P.lds_staging && !r->P.majorant && r->P.shading == 0 && !r->P.sparse_xy && r->P.vol.type == VOX_F32) {
+    // the unshaded f32 march ran its LDS-staged variant: the two skip counters carried its diagnostics
+    r->stats.lds_fallback_taps = r->h_counters[5];
+    r->stats.lds_unstaged_rounds = r->h_counters[6];
+    r->stats.skipped_samples = r->stats.skipped_shadow_samples = 0;
+  }
   r->stats.frame_index = r->frame_index;
   if (r->d_trace) {
     if (const char* path = getenv("OVR_HIP_TRACE_FILE")) {
@@ -963,6 +975,7 @@ OVR_SIMPLE_SETTER(ovr_hip_set_shading_pipeline, pipeline, int32_t, v >= 0 && v <
 OVR_SIMPLE_SETTER(ovr_hip_set_empty_space_skipping, skipping, int32_t, true, "")
 OVR_SIMPLE_SETTER(ovr_hip_set_volume_layouts, layouts, int32_t, v >= 0 && v <= 2, "[hip] unknown volume-layout mode")
 OVR_SIMPLE_SETTER(ovr_hip_set_layout_choice, layout_choice, int32_t, v >= -1 && v <= 2, "[hip] unknown layout choice")
+OVR_SIMPLE_SETTER(ovr_hip_set_lds_staging, lds_staging, int32_t, v == 0 || v == 1, "[hip] unknown LDS-staging mode")
 OVR_SIMPLE_SETTER(ovr_hip_set_pixel_jitter, jitter, int32_t, v == 0 || v == 1, "[hip] unknown pixel-jitter mode")
 
 int ovr_hip_set_focus(ovr_hip_renderer* r, float cx, float cy, float scale, float base_noise)
@@ -1043,6 +1056,7 @@ int ovr_hip_commit(ovr_hip_renderer* r)
   if (r->rate.update()) r->fb_reset = true;       // :190-196
   if (r->shading.update()) r->fb_reset = true;
   if (r->jitter.update()) r->fb_reset = true;
+  (void)r->lds_staging.update(); // same frame either way
   (void)r->layout_choice.update(); // every layout gives the same frame: no accumulation reset
   (void)r->pipeline.update(); // both pipelines produce the same frame: no accumulation reset
   (void)r->skipping.update(); // skipping does not change the frame either

@@ -517,6 +517,14 @@ constexpr int kShadowTaps = OVR_SHADOW_K; // shadow-march taps in flight per lan
 // chunks a tile reserves at a time: consecutive chunks of one tile are shaded by ONE workgroup, one chunk per wave
 // (L1/L2 reuse: measured 2.4 -> 1.5 ms for the shading kernel at C3; 8 / 16 / 32 are slower - imbalance)
 constexpr int kRun = 4;
+#ifndef OVR_RUN_MAX
+#define OVR_RUN_MAX 16
+#endif
+#ifndef OVR_TICKET_RUNS
+#define OVR_TICKET_RUNS 8
+#endif
+constexpr int kTicketRuns = OVR_TICKET_RUNS; // shade kernel: most runs a workgroup takes per ticket
+constexpr int kRunMax = OVR_RUN_MAX; // largest reservation (a multiple of kRun: the shade kernel takes kRun chunks per workgroup)
 
 struct ShadeReq { // 32 bytes; after shading the same slot holds the result (cx,cy,cz,gx,gy,gz,a,next)
   float px, py, pz; // world-space sample position          | colour contribution  tr*clamp01(rgb*shade)
@@ -819,9 +827,18 @@ template <int SHADE, bool POOLED> struct QCfg {
 #ifndef OVR_MARCH_WPE
 #define OVR_MARCH_WPE 3
 #endif
-template <int VT, int SHADE, int AM, bool POOLED, bool SKIP>
+// LDSB = true: the "LDS-staged bricks" variant (north_star; measured in profiles/r02_notes.md).  Once per round the workgroup
+// copies every brick its 64 rays can touch in the round's 16 steps - the brick-aligned bounding box of the block's four corner
+// rays over the round's t range - from HBM / L2 into LDS with whole-line 16-byte loads (8 lanes per 128-byte brick), and the
+// round's taps read LDS (ds_read2_b32 pairs) instead of going through the texture addresser.  A round whose box exceeds the LDS
+// budget, and a tap that falls outside the staged box, take the ordinary path - the result is bit-identical either way.
+// Built for the in-place, unshaded march of the general f32 layout (BASELINE C2, where rays are denser than voxels).
+constexpr int kLdsBrickCap = 384;                       // 48 KiB of bricks per workgroup: two workgroups per CU
+struct LdsRegion { int bx0, by0, bz0, ebx, eby, ebz, nbr, ok; };
+template <int VT, int SHADE, int AM, bool POOLED, bool SKIP, bool LDSB = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_MARCH_WPE))) void raymarch_kernel(const RayMarchParams P)
 {
+  static_assert(!LDSB || (SHADE == 0 && !POOLED && !SKIP && AM <= 1 && !Vox<VT>::kTransposed), "LDS-staged bricks: unshaded in-place march only");
   using Cfg = QCfg<SHADE, POOLED>;
   constexpr int K = Cfg::K;
   constexpr int QCAP = Cfg::QCAP;
@@ -911,6 +928,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
   }
   const PoolDesc& Q = P.pool;
   const unsigned int tile = blockIdx.x * kWaves + wave;
+  // LDS-staged bricks: [.. tables, TF ..][bricks: kLdsBrickCap x 128 B][region descriptor][corner rays 4 x float3][t range]
+  float* const lds_bricks = LDSB ? reinterpret_cast<float*>(lds_raw + P.lds_brick_offset) : nullptr;
+  LdsRegion* const lds_region = reinterpret_cast<LdsRegion*>(lds_bricks + (size_t)kLdsBrickCap * 32);
+  float* const lds_corner = reinterpret_cast<float*>(lds_region + 1);
+  int* const lds_trange = reinterpret_cast<int*>(lds_corner + 12);
+  unsigned int n_lds_fb_taps = 0, n_lds_fb_rounds = 0; // diagnostics: taps outside the staged box, rounds whose box did not fit
+  if (LDSB && threadIdx.x < 4) { // directions of the block's corner rays, half a pixel outside the corner pixels (covers any jitter)
+    const unsigned int e = P.schedule[blockIdx.x];
+    const float cx_ = ((float)((int)(e & 0xffffu) * 8 + ((threadIdx.x & 1) ? 8 : 0))) / (float)P.width - 0.5f;
+    const float cy_ = ((float)((int)(e >> 16) * 8 + ((threadIdx.x & 2) ? 8 : 0))) / (float)P.height - 0.5f;
+    const f3 c0 = ld3(P.cam_dir), h0 = ld3(P.cam_hor), v0 = ld3(P.cam_ver);
+    const f3 d = normalize3_exact(mk3(c0.x + cx_ * h0.x + cy_ * v0.x, c0.y + cx_ * h0.y + cy_ * v0.y, c0.z + cx_ * h0.z + cy_ * v0.z));
+    lds_corner[3 * threadIdx.x] = d.x; lds_corner[3 * threadIdx.x + 1] = d.y; lds_corner[3 * threadIdx.x + 2] = d.z;
+  }
 
   const unsigned int pixel_index = (unsigned int)ix + (unsigned int)iy * (unsigned int)P.width;
   unsigned int v0 = (unsigned int)P.frame_index, v1 = pixel_index; // RandomTEA(frame_index, pixel_index)
@@ -923,8 +954,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
     for (int i = 0; i < P.spp_index; ++i) tea16(v0, v1); // RandomTEA state of this generation (random.h:146-188)
   // wave-uniform queue cursors (stream positions; slot = position & (QCAP - 1))
   unsigned int q_head = 0, q_tail = 0;
-  // pooled: the tile's current reservation of kRun consecutive chunks
-  unsigned int run_base = 0, run_left = 0;
+  // pooled: the tile's current reservation of consecutive chunks - kRun at first, doubling up to kRunMax with every further
+  // reservation: a tile that pushes a lot (dense transfer function: every sample is shaded) would otherwise hit the one
+  // pool counter every round - 48 k same-address returning atomics per C3 frame, which serialise in L2
+  unsigned int run_base = 0, run_left = 0, run_size = 0, run_next = kRun;
   int prev_chunk = -1;
   if (POOLED && lane == 0) Q.tile_first[tile] = -1;
   // per-ray request list (identical in the 4 lanes of the quad; the owner lane applies the contributions)
@@ -937,13 +970,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
   auto spill = [&](unsigned int n) {
     if (run_left == 0) {
       unsigned int c0 = 0;
-      if (lane == 0) c0 = atomicAdd(&Q.ctrl[0], (unsigned int)kRun);
+      if (lane == 0) c0 = atomicAdd(&Q.ctrl[0], run_next);
       run_base = (unsigned int)__builtin_amdgcn_readfirstlane((int)c0);
-      run_left = kRun;
+      run_left = run_size = run_next;
+      run_next = min(run_next * 2u, (unsigned int)kRunMax);
     }
-    const unsigned int c = run_base + (kRun - run_left);
+    const unsigned int c = run_base + (run_size - run_left);
     --run_left;
-    if (run_base + kRun <= Q.capacity) {
+    if (run_base + run_size <= Q.capacity) {
       __builtin_amdgcn_wave_barrier();
       if ((unsigned int)lane < n) Q.reqs[(size_t)c * 64 + lane] = queue[(q_head + lane) & (QCAP - 1)];
       if (lane == 0) {
@@ -993,9 +1027,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
     else live = live && staged;
     float tx = t0, ty = fminf(t1, t0 + mc.step);
     pend = 0;
+    unsigned int lds_round = 0;
+    if (LDSB) { // the workgroup's range of entry distances: round r of every ray lies in [tmin + 16 r step, tmax + 16 (r + 1) step]
+      __syncthreads();
+      if (threadIdx.x == 0) { lds_trange[0] = 0x7f7fffff; lds_trange[1] = 0; }
+      __syncthreads();
+      if (live) { atomicMin(&lds_trange[0], __float_as_int(t0)); atomicMax(&lds_trange[1], __float_as_int(t0)); } // t0 >= 0: ordered as ints
+      __syncthreads();
+    }
 
     for (;;) {
-      const bool any_live = __ballot(live) != 0ull;
+      // LDSB: the rounds are workgroup-synchronous (the staging below has barriers): all four waves run until no ray of the block is live
+      const bool any_live = LDSB ? (__syncthreads_or(live ? 1 : 0) != 0) : (__ballot(live) != 0ull);
       // ---- (1) in place: shade queued requests, a full batch whenever 64 are queued, the remainder once no ray is live
       if (SHADE != 0 && !POOLED) {
         while ((q_tail - q_head) >= 64u || (!any_live && q_tail != q_head)) {
@@ -1093,9 +1136,96 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
         for (int k = 0; k < K; ++k) any = any || (mj[k] > 0.f);
         if (__ballot(any && live) == 0ull) { skip_round(); continue; }
       }
+      if (LDSB) {
+        typedef BrickMap<VT> M;
+        // (a) wave 0: the brick-aligned box of this round - 4 corner rays x {t_lo, t_hi} (the rays of the block and the round's
+        //     t range span a convex set between them), one voxel of margin, one more for the taps' upper neighbours
+        if (wave == 0) {
+          const float t_lo = __int_as_float(lds_trange[0]) + ((float)(lds_round * (unsigned)(4 * K)) - 1.f) * mc.step;
+          const float t_hi = __int_as_float(lds_trange[1]) + ((float)((lds_round + 1u) * (unsigned)(4 * K)) + 1.f) * mc.step;
+          const int c = lane & 3;
+          const float tt = (lane & 4) ? t_hi : t_lo;
+          const f3 pw = mk3(fmaf(tt, lds_corner[3 * c], org.x), fmaf(tt, lds_corner[3 * c + 1], org.y), fmaf(tt, lds_corner[3 * c + 2], org.z));
+          const f3 po = to_object(mc, pw);
+          float lo[3] = { fmaf(po.x, vc.cs.x, vc.cb.x), fmaf(po.y, vc.cs.y, vc.cb.y), fmaf(po.z, vc.cs.z, vc.cb.z) };
+          float hi[3] = { lo[0], lo[1], lo[2] };
 #pragma unroll
-      for (int k = 0; k < K; ++k)
-        if (!SKIP || mj[k] > 0.f) tap_loads<VT, AM>(vc, taps[k]);
+          for (int off = 1; off < 8; off <<= 1)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+              hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+            }
+          if (lane == 0) {
+            const int n1[3] = { vc.nx1, vc.ny1, vc.nz1 };
+            int l[3], h[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              l[a] = min(max((int)floorf(fminf(fmaxf(lo[a], -4.f), 1e9f)) - 1, 0), n1[a]);
+              h[a] = min(max((int)floorf(fminf(fmaxf(hi[a], -4.f), 1e9f)) + 2, 0), n1[a]);
+            }
+            LdsRegion g;
+            g.bx0 = (int)M::div_cx((unsigned)l[0]); g.by0 = l[1] >> Vox<VT>::by; g.bz0 = l[2] >> Vox<VT>::bz;
+            g.ebx = (int)M::div_cx((unsigned)h[0]) - g.bx0 + 1; g.eby = (h[1] >> Vox<VT>::by) - g.by0 + 1; g.ebz = (h[2] >> Vox<VT>::bz) - g.bz0 + 1;
+            g.nbr = g.ebx * g.eby * g.ebz;
+            g.ok = g.nbr <= kLdsBrickCap ? 1 : 0;
+            *lds_region = g;
+          }
+        }
+        __syncthreads(); // also: every wave has finished reading the previous round's bricks
+        const LdsRegion g = *lds_region;
+        ++lds_round;
+        if (g.ok) {
+          // (b) copy the bricks: 8 lanes x 16 bytes per brick, whole 128-byte lines
+          const int row = threadIdx.x & 7;
+          const float rcp_x = 1.f / (float)g.ebx, rcp_xy = 1.f / (float)(g.ebx * g.eby);
+          for (int i = threadIdx.x >> 3; i < g.nbr; i += kBlock / 8) {
+            const int iz = (int)(((float)i + 0.5f) * rcp_xy), rem = i - iz * g.ebx * g.eby;
+            const int iy = (int)(((float)rem + 0.5f) * rcp_x), ixb = rem - iy * g.ebx;
+            const unsigned int off = vc.tab_x[(g.bx0 + ixb) * Vox<VT>::cx] + vc.tab_y[(g.by0 + iy) << Vox<VT>::by] + vc.tab_z[(g.bz0 + iz) << Vox<VT>::bz];
+            const float4 v = AM == 0 ? *reinterpret_cast<const float4*>(static_cast<const char*>(vc.data) + off + row * 16)
+                                     : *reinterpret_cast<const float4*>(static_cast<const float*>(vc.data) + off + row * 4);
+            reinterpret_cast<float4*>(lds_bricks)[i * 8 + row] = v;
+          }
+          __syncthreads();
+          // (c) the taps: region-relative brick index + position inside the brick; anything outside the box goes the ordinary way
+          const int sxy = g.ebx * g.eby;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            Tap& t = taps[k];
+            const int y1 = min(t.y0 + 1, vc.ny1), z1 = min(t.z0 + 1, vc.nz1);
+            const int bxr = (int)M::div_cx((unsigned)t.x0), xr = t.x0 - bxr * Vox<VT>::cx;
+            const int cy0 = (t.y0 >> Vox<VT>::by) - g.by0, cy1 = (y1 >> Vox<VT>::by) - g.by0, cz0 = (t.z0 >> Vox<VT>::bz) - g.bz0, cz1 = (z1 >> Vox<VT>::bz) - g.bz0;
+            const int cxr = bxr - g.bx0;
+            const bool inside = (unsigned)cxr < (unsigned)g.ebx && (unsigned)cy0 < (unsigned)g.eby && (unsigned)cy1 < (unsigned)g.eby &&
+                                (unsigned)cz0 < (unsigned)g.ebz && (unsigned)cz1 < (unsigned)g.ebz;
+            if (inside) {
+              constexpr int ym = (1 << Vox<VT>::by) - 1, zm = (1 << Vox<VT>::bz) - 1, SX = (int)M::SX;
+              const int ox = cxr * (int)M::BV + xr;
+              const int oy0 = cy0 * g.ebx * (int)M::BV + (t.y0 & ym) * SX, oy1 = cy1 * g.ebx * (int)M::BV + (y1 & ym) * SX;
+              const int oz0 = cz0 * sxy * (int)M::BV + ((t.z0 & zm) << Vox<VT>::by) * SX, oz1 = cz1 * sxy * (int)M::BV + ((z1 & zm) << Vox<VT>::by) * SX;
+              const float* b0 = lds_bricks + ox + oz0;
+              const float* b1 = lds_bricks + ox + oz1;
+              t.c000 = b0[oy0]; t.c100 = b0[oy0 + 1]; t.c010 = b0[oy1]; t.c110 = b0[oy1 + 1];
+              t.c001 = b1[oy0]; t.c101 = b1[oy0 + 1]; t.c011 = b1[oy1]; t.c111 = b1[oy1 + 1];
+            }
+            else {
+              tap_loads<VT, AM>(vc, t);
+              n_lds_fb_taps += live ? 1u : 0u;
+            }
+          }
+        }
+        else {
+          n_lds_fb_rounds += (lane == 0 && wave == 0) ? 1u : 0u;
+#pragma unroll
+          for (int k = 0; k < K; ++k) tap_loads<VT, AM>(vc, taps[k]);
+        }
+      }
+      else {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          if (!SKIP || mj[k] > 0.f) tap_loads<VT, AM>(vc, taps[k]);
+      }
       // ---- (3) own samples: value, TF coordinate, corrected opacity (and colour when shading is off)
       float sa[K], va[K], aa[K];
       f3 ca[K];
@@ -1220,8 +1350,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
 
   if (POOLED) {
     if (q_tail != q_head) spill(q_tail - q_head); // the tile's last, partial chunk
-    if (lane == 0 && run_base + kRun <= Q.capacity)
-      for (unsigned int i = kRun - run_left; i < (unsigned int)kRun && run_left != 0; ++i) Q.chunk_n[run_base + i] = 0; // unused tail of the reservation
+    if (lane == 0 && run_base + run_size <= Q.capacity)
+      for (unsigned int i = run_size - run_left; i < run_size && run_left != 0; ++i) Q.chunk_n[run_base + i] = 0; // unused tail of the reservation
     if (lane == 0) Q.tile_count[tile] = q_tail;
     if (active && owner) Q.pix_state[pixel_index] = make_float4(alpha, __uint_as_float(first), __int_as_float(pend), 0.f);
   }
@@ -1238,9 +1368,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
     t[0] = t_start; t[1] = __builtin_amdgcn_s_memrealtime();
     t[2] = ((unsigned long long)n_samples << 32) | n_shaded; t[3] = n_shadow;
   }
+  // LDSB (never combined with skipping): the two skip counters carry the staging diagnostics instead
   store_block_counters(P, reinterpret_cast<unsigned int*>(lds_raw), lane, wave, n_rays, n_samples, n_shaded, n_shadow,
-                       (active && owner && (!POOLED || P.spp_index == 0)) ? 1u : 0u, n_skipped,
-                       n_shadow_skipped);
+                       (active && owner && (!POOLED || P.spp_index == 0)) ? 1u : 0u, LDSB ? n_lds_fb_taps : n_skipped,
+                       LDSB ? n_lds_fb_rounds : n_shadow_skipped);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1261,22 +1392,39 @@ __global__ __launch_bounds__(kBlock) void shade_pool_kernel(const RayMarchParams
   const unsigned int n_runs = Q.ctrl[0] > Q.capacity ? 0u : Q.ctrl[0] / (unsigned int)kRun; // overflow: the frame is re-rendered
   unsigned int n_shadow = 0, n_shadow_skipped = 0;
   __shared__ unsigned int s_run;
+  // Guided self-scheduling: a workgroup takes a BATCH of consecutive runs per ticket - (runs left) / (2 x workgroups), at most
+  // kTicketRuns, at least 1 - because the ticket is a same-address returning atomic and those serialise in L2 (~30 clocks each:
+  // with one run per ticket the dense-transfer-function frame spent its whole shade time on 116 k tickets).  Large batches while
+  // there is plenty of work, single runs at the end for balance.  Inside a batch the 4 waves walk their chunks independently
+  // (run r, chunk `wave`): consecutive depth steps of ONE tile, whose gradient and shadow taps fall into the same bricks.
+  // The cap follows the frame: 1 run per ticket up to 32 runs per workgroup (sparse transfer functions: 36 k runs per C3 frame -
+  // there batches only cost balance, measured +3 ... 13 %), up to kTicketRuns beyond (dense: 174 k runs, shade 2.11 -> 1.13 ms)
+  const unsigned int ticket_cap = min((unsigned int)kTicketRuns, max(1u, n_runs / (32u * gridDim.x)));
+  unsigned int seen = 0; // a lower bound of the global cursor: the end of this workgroup's last batch
   for (;;) {
-    // one returning atomic per workgroup and run; the 4 waves shade the run's chunks (consecutive depth steps of ONE
-    // tile: their gradient and shadow taps fall into the same bricks, which the CU's L1 and the XCD's L2 now keep)
+    const unsigned int left = n_runs > seen ? n_runs - seen : 0u;
+    const unsigned int batch = min(ticket_cap, max(1u, left / (2u * gridDim.x)));
     __syncthreads();
-    if (threadIdx.x == 0) s_run = atomicAdd(&Q.ctrl[1], 1u);
+    if (threadIdx.x == 0) s_run = atomicAdd(&Q.ctrl[1], batch);
     __syncthreads();
-    const unsigned int run = s_run;
-    if (run >= n_runs) break; // every workgroup reaches this: the cursor only grows
-    for (unsigned int i = (unsigned int)wave; i < (unsigned int)kRun; i += kWaves) {
-      const unsigned int c = run * kRun + i;
-      const unsigned int n = Q.chunk_n[c];
-      if ((unsigned int)lane < n) {
-        ShadeReq r = Q.reqs[(size_t)c * 64 + lane];
-        if (r.a > 0.f) { // a == 0: null request (a step of the quad that needs no shading)
-          shade_request<VT, SHADE, AM, SKIP>(P, vc, tf, mc, r, n_shadow, n_shadow_skipped);
-          Q.reqs[(size_t)c * 64 + lane] = r;
+    const unsigned int run0 = s_run;
+    if (run0 >= n_runs) break; // every workgroup reaches this: the cursor only grows
+    seen = run0 + batch;
+    const unsigned int run1 = min(run0 + batch, n_runs);
+    for (unsigned int run = run0; run < run1; ++run) {
+#ifndef OVR_TICKET_LOCKSTEP
+#define OVR_TICKET_LOCKSTEP 1
+#endif
+      if (OVR_TICKET_LOCKSTEP && run != run0) __syncthreads(); // the 4 waves stay on ONE run: its chunks share their bricks in L1
+      for (unsigned int i = (unsigned int)wave; i < (unsigned int)kRun; i += kWaves) {
+        const unsigned int c = run * kRun + i;
+        const unsigned int n = Q.chunk_n[c];
+        if ((unsigned int)lane < n) {
+          ShadeReq r = Q.reqs[(size_t)c * 64 + lane];
+          if (r.a > 0.f) { // a == 0: null request (a step of the quad that needs no shading)
+            shade_request<VT, SHADE, AM, SKIP>(P, vc, tf, mc, r, n_shadow, n_shadow_skipped);
+            Q.reqs[(size_t)c * 64 + lane] = r;
+          }
         }
       }
     }
@@ -1329,9 +1477,23 @@ inline hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
   const bool pooled = (SHADE != 0) && p.pool.reqs != nullptr;
   if (!pooled) {
     const size_t lds = std::max<size_t>(tf_lds + table_lds_bytes(p, AM) + (size_t)kWaves * QCfg<SHADE, false>::QCAP * sizeof(ShadeReq), 64); // >= 64 B: the counter reduction reuses it
-    auto kern = raymarch_kernel<VT, SHADE, AM, false, SKIP>;
-    if ((e = set_lds(kern, lds)) != hipSuccess) return e;
-    if (grid.x > 0) hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
+    bool launched = false;
+    if constexpr (VT == VOX_F32 && SHADE == 0 && AM <= 1 && !SKIP) {
+      if (p.lds_staging && !p.sparse_xy) { // LDS-staged bricks (see raymarch_kernel): the bricks follow the tables and the TF
+        RayMarchParams q = p;
+        q.lds_brick_offset = (unsigned int)((lds + 15) & ~(size_t)15);
+        const size_t lds2 = q.lds_brick_offset + (size_t)kLdsBrickCap * 128 + sizeof(LdsRegion) + 12 * sizeof(float) + 2 * sizeof(int) + 16;
+        auto kern = raymarch_kernel<VT, SHADE, AM, false, SKIP, true>;
+        if ((e = set_lds(kern, lds2)) != hipSuccess) return e;
+        if (grid.x > 0) hipLaunchKernelGGL(kern, grid, block, lds2, stream, q);
+        launched = true;
+      }
+    }
+    if (!launched) {
+      auto kern = raymarch_kernel<VT, SHADE, AM, false, SKIP>;
+      if ((e = set_lds(kern, lds)) != hipSuccess) return e;
+      if (grid.x > 0) hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (ev) { (void)hipEventRecord(ev[1], stream); (void)hipEventRecord(ev[2], stream); }
     if (p.block_counters && p.counters) {

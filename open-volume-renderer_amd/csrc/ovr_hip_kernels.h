@@ -97,6 +97,9 @@ struct RayMarchParams {
   // tile stored [t][y][x], jitter_xy its edge; see jitter_slice in ovr_hip_kernels.hip)
   int jitter_mode, jitter_xy;
   const float* jitter_noise;
+  // LDS-staged bricks (raymarch_kernel<.., LDSB>): on / off, and where the brick area starts in the workgroup's dynamic LDS
+  int lds_staging;
+  unsigned int lds_brick_offset;
   // counters: [0] rays [1] samples [2] shaded samples [3] shadow samples [4] active pixels [5] skipped samples [6] skipped shadow samples
   unsigned long long* counters;
   const float* majorant;        // per-macrocell max TF opacity: empty-space skipping (null = off)

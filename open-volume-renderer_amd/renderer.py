@@ -207,6 +207,10 @@ class DeviceHIP:
         L.check(self._lib.ovr_hip_get_volume_info(self._h, C.byref(v)))
         return v
 
+    def set_lds_staging(self, on):
+        """LDS-staged bricks for the unshaded march of float volumes (include/ovr_hip.h); off by default"""
+        L.check(self._lib.ovr_hip_set_lds_staging(self._h, int(bool(on))))
+
     def set_volume_layouts(self, mode):
         """which layouts of the volume the next init / volume upload keeps in HBM: 0 general only, 1 (default) thin replicas
         when they fit comfortably, 2 always (include/ovr_hip.h)"""
