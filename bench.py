@@ -77,9 +77,10 @@ def kernels_hash():
     kernels it was taken from"""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "open-volume-renderer_amd", "csrc")
-    for name in ("ovr_hip_kernels.hip", "ovr_hip_kernels.h", "ovr_hip_api.cpp"):
-        with open(os.path.join(d, name), "rb") as f:
-            h.update(f.read())
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
     return h.hexdigest()[:16]
 
 
