@@ -466,7 +466,7 @@ def worker(args, world):
                          "phase_ms_rank0": {"march": ph[0], "shade": ph[1], "composite": ph[2]},
                          "pool_chunks": int(last_stats.pool_chunks),
                          "lds_staging": {"on": bool(args.lds_staging), "fallback_taps_per_frame": int(last_stats.lds_fallback_taps),
-                                         "unstaged_workgroup_rounds_per_frame": int(last_stats.lds_unstaged_rounds)}},
+                                         "unstaged_workgroup_rounds_per_frame": int(last_stats.lds_unstaged_rounds), "workgroup_rounds_per_frame": int(last_stats.lds_rounds)}},
         }
         if multi:
             out["rccl_ranks"] = dist.get_world_size()

@@ -78,6 +78,7 @@ typedef struct ovr_hip_stats {
   int32_t reserved;
   uint64_t lds_fallback_taps;   /* LDS-staged bricks: taps of live samples that fell outside the staged box (read from L1/L2 instead) */
   uint64_t lds_unstaged_rounds; /* LDS-staged bricks: workgroup rounds whose box exceeded the LDS budget (ordinary path)            */
+  uint64_t lds_rounds;          /* LDS-staged bricks: workgroup rounds in total                                                      */
 } ovr_hip_stats;
 
 const char* ovr_hip_last_error(void);
@@ -153,7 +154,7 @@ int ovr_hip_set_empty_space_skipping(ovr_hip_renderer* r, int32_t enabled);
 int ovr_hip_set_pixel_jitter(ovr_hip_renderer* r, int32_t mode);
 /* extension (north_star "volume brick-tiled into LDS"): the unshaded (OVR_HIP_SHADE_NONE), non-skipping march of a float volume
  * stages, once per round of 16 steps, every brick its 8x8-pixel workgroup can touch into LDS with whole-line loads and taps read
- * LDS.  Bit-identical frames.  0 = off (default: it is slower than the L1 path wherever measured, profiles/r02_notes.md), 1 = on. */
+ * LDS.  Bit-identical frames.  0 = off (default: 2.3 - 3 x slower than the L1 path on its best case, profiles/r02_notes.md), 1 = on. */
 int ovr_hip_set_lds_staging(ovr_hip_renderer* r, int32_t mode);
 /* downloads the macrocell grids (for known-answer tests): dims = cells per axis; minmax = 2 floats per cell, majorant = 1 */
 int ovr_hip_get_macrocells(ovr_hip_renderer* r, int32_t dims[3], float* minmax_host, float* majorant_host, size_t capacity_cells);

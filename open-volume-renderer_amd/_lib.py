@@ -43,6 +43,7 @@ class Stats(C.Structure):
         ("reserved", C.c_int32),
         ("lds_fallback_taps", C.c_uint64),
         ("lds_unstaged_rounds", C.c_uint64),
+        ("lds_rounds", C.c_uint64),
     ]
 
 

@@ -687,12 +687,13 @@ int finish_frame(ovr_hip_renderer* r)
   r->stats.active_pixels = r->h_counters[4];
   r->stats.skipped_samples = r->h_counters[5];
   r->stats.skipped_shadow_samples = r->h_counters[6];
-  r->stats.lds_fallback_taps = r->stats.lds_unstaged_rounds = 0;
+  r->stats.lds_fallback_taps = r->stats.lds_unstaged_rounds = r->stats.lds_rounds = 0;
   if (r->P.lds_staging && !r->P.majorant && r->P.shading == 0 && !r->P.sparse_xy && r->P.vol.type == VOX_F32) {
     // the unshaded f32 march ran its LDS-staged variant: the two skip counters carried its diagnostics
     r->stats.lds_fallback_taps = r->h_counters[5];
     r->stats.lds_unstaged_rounds = r->h_counters[6];
-    r->stats.skipped_samples = r->stats.skipped_shadow_samples = 0;
+    r->stats.lds_rounds = r->h_counters[3];
+    r->stats.skipped_samples = r->stats.skipped_shadow_samples = r->stats.shadow_samples = 0;
   }
   r->stats.frame_index = r->frame_index;
   if (r->d_trace) {

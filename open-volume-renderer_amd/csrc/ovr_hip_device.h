@@ -828,7 +828,7 @@ template <int SHADE, bool POOLED> struct QCfg {
 #define OVR_MARCH_WPE 3
 #endif
 // LDSB = true: the "LDS-staged bricks" variant (north_star; measured in profiles/r02_notes.md).  Once per round the workgroup
-// copies every brick its 64 rays can touch in the round's 16 steps - the brick-aligned bounding box of the block's four corner
+// copies the bricks its 64 rays touch in the round's 16 steps - the brick-aligned bounding box of the block's four corner
 // rays over the round's t range - from HBM / L2 into LDS with whole-line 16-byte loads (8 lanes per 128-byte brick), and the
 // round's taps read LDS (ds_read2_b32 pairs) instead of going through the texture addresser.  A round whose box exceeds the LDS
 // budget, and a tap that falls outside the staged box, take the ordinary path - the result is bit-identical either way.
@@ -1141,8 +1141,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
         // (a) wave 0: the brick-aligned box of this round - 4 corner rays x {t_lo, t_hi} (the rays of the block and the round's
         //     t range span a convex set between them), one voxel of margin, one more for the taps' upper neighbours
         if (wave == 0) {
-          const float t_lo = __int_as_float(lds_trange[0]) + ((float)(lds_round * (unsigned)(4 * K)) - 1.f) * mc.step;
-          const float t_hi = __int_as_float(lds_trange[1]) + ((float)((lds_round + 1u) * (unsigned)(4 * K)) + 1.f) * mc.step;
+          // (no safety margins: a tap that falls outside the box is caught below and read the ordinary way)
+          const float t_lo = __int_as_float(lds_trange[0]) + (float)(lds_round * (unsigned)(4 * K)) * mc.step;
+          const float t_hi = __int_as_float(lds_trange[1]) + (float)((lds_round + 1u) * (unsigned)(4 * K)) * mc.step;
           const int c = lane & 3;
           const float tt = (lane & 4) ? t_hi : t_lo;
           const f3 pw = mk3(fmaf(tt, lds_corner[3 * c], org.x), fmaf(tt, lds_corner[3 * c + 1], org.y), fmaf(tt, lds_corner[3 * c + 2], org.z));
@@ -1161,8 +1162,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
             int l[3], h[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-              l[a] = min(max((int)floorf(fminf(fmaxf(lo[a], -4.f), 1e9f)) - 1, 0), n1[a]);
-              h[a] = min(max((int)floorf(fminf(fmaxf(hi[a], -4.f), 1e9f)) + 2, 0), n1[a]);
+              l[a] = min(max((int)floorf(fminf(fmaxf(lo[a], -4.f), 1e9f)), 0), n1[a]);
+              h[a] = min(max((int)floorf(fminf(fmaxf(hi[a], -4.f), 1e9f)) + 1, 0), n1[a]); // + 1: the taps' upper neighbours
             }
             LdsRegion g;
             g.bx0 = (int)M::div_cx((unsigned)l[0]); g.by0 = l[1] >> Vox<VT>::by; g.bz0 = l[2] >> Vox<VT>::bz;
@@ -1175,8 +1176,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
         __syncthreads(); // also: every wave has finished reading the previous round's bricks
         const LdsRegion g = *lds_region;
         ++lds_round;
+        n_shadow += (lane == 0 && wave == 0) ? 1u : 0u; // diagnostics: workgroup rounds (the unshaded march has no shadow samples)
         if (g.ok) {
-          // (b) copy the bricks: 8 lanes x 16 bytes per brick, whole 128-byte lines
+          // (b) copy the bricks: 8 lanes x 16 bytes per brick, whole 128-byte lines.  (Issuing all of a thread's up to 12 loads
+          //     into a register array before the first store was measured slower: 1.48 instead of 1.02 ms on C2 front.)
           const int row = threadIdx.x & 7;
           const float rcp_x = 1.f / (float)g.ebx, rcp_xy = 1.f / (float)(g.ebx * g.eby);
           for (int i = threadIdx.x >> 3; i < g.nbr; i += kBlock / 8) {

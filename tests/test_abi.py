@@ -28,8 +28,8 @@ def test_library_exports_every_declared_symbol(ovr):
 
 
 def test_stats_struct_layout_matches_header(ovr):
-    # 5 x u64, 2 x f64, 2 x i32, 3 x f64, 3 x u64, 2 x i32, 2 x u64
-    assert C.sizeof(ovr._lib.Stats) == 5 * 8 + 2 * 8 + 2 * 4 + 3 * 8 + 3 * 8 + 2 * 4 + 2 * 8
+    # 5 x u64, 2 x f64, 2 x i32, 3 x f64, 3 x u64, 2 x i32, 3 x u64
+    assert C.sizeof(ovr._lib.Stats) == 5 * 8 + 2 * 8 + 2 * 4 + 3 * 8 + 3 * 8 + 2 * 4 + 3 * 8
 
 
 def test_no_cpu_fallback(ovr):
