@@ -844,14 +844,27 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     if (r->layouts.current == 2 || (double)(t1.bytes + t2.bytes) <= 0.4 * (double)free_b) {
       const VolumeDesc* ts[2] = { &t1, &t2 };
-      for (int k = 1; k <= 2; ++k) {
-        HIP_TRY(hipMalloc(&r->d_replica[k], (size_t)ts[k - 1]->bytes + 64));
-        HIP_TRY(hipMemset(r->d_replica[k], 0, (size_t)ts[k - 1]->bytes + 64));
-        r->vd_replica[k] = *ts[k - 1];
-        r->vd_replica[k].data = r->d_replica[k];
-        r->volume_bytes += (size_t)ts[k - 1]->bytes;
+      hipError_t e = hipSuccess;
+      for (int k = 1; k <= 2 && e == hipSuccess; ++k) {
+        e = hipMalloc(&r->d_replica[k], (size_t)ts[k - 1]->bytes + 64);
+        if (e == hipSuccess) e = hipMemset(r->d_replica[k], 0, (size_t)ts[k - 1]->bytes + 64);
       }
-      n_layouts = 3;
+      if (e == hipSuccess) {
+        for (int k = 1; k <= 2; ++k) {
+          r->vd_replica[k] = *ts[k - 1];
+          r->vd_replica[k].data = r->d_replica[k];
+          r->volume_bytes += (size_t)ts[k - 1]->bytes;
+        }
+        n_layouts = 3;
+      }
+      else { // no room after all: the replicas are an optimisation, the general layout alone renders the same frames
+        (void)hipGetLastError();
+        for (int k = 1; k <= 2; ++k) {
+          if (r->d_replica[k]) (void)hipFree(r->d_replica[k]);
+          r->d_replica[k] = nullptr;
+        }
+        if (r->layouts.current == 2) return fail(OVR_HIP_EDEVICE, std::string("[hip] volume replicas requested (layouts mode 2) but their allocation failed: ") + hipGetErrorString(e));
+      }
     }
   }
   auto relayout_all = [&](const void* src, int z0, int nzc) -> hipError_t {

@@ -1,4 +1,6 @@
 """host-side logic that needs no GPU: synthetic inputs, tile ownership, the scene flattening of the renderer mirror"""
+import os
+
 import numpy as np
 import pytest
 
@@ -84,3 +86,30 @@ def test_scene_flattening_matches_reference_format(ovr):
 def test_camera_default_fovy_is_60(ovr):
     # renderer.h:149-152: set_camera(from, at, up) builds a Camera whose fovy is the default 60 (scene.h:219)
     assert ovr.Camera((0, 0, 1), (0, 0, 0), (0, 1, 0)).fovy == 60.0
+
+
+def test_bench_refuses_a_launcher_mismatch_and_keys_traffic_by_the_kernel_hash(tmp_path, monkeypatch):
+    """bench.py on the CPU: a WORLD_SIZE / --gpus mismatch is an error before anything touches the GPU, and a committed
+    PMC traffic figure is only quoted for the kernel sources it was measured from"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "tiny"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE=4 but --gpus 2" in out.stderr
+    sys.path.insert(0, root)
+    import bench
+    h = bench.kernels_hash()
+    assert len(h) == 16 and h == bench.kernels_hash()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    entry = {"fetch_size_kib": {"raymarch_kernel": 1000}, "write_size_kib": {"raymarch_kernel": 10}, "traffic_bytes_per_launch": 2058240}
+    (prof / "r09_traffic.json").write_text(json.dumps({"kernels_hash": h, "entries": {"c3|oblique|sparse|2|1": entry}}))
+    (prof / "r08_traffic.json").write_text(json.dumps({"kernels_hash": "0" * 16, "entries": {"c2|oblique|sparse|0|1": entry}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernels_hash", lambda: h)
+    t, by_kernel, src = bench.load_traffic("c3|oblique|sparse|2|1")
+    assert t == 2058240 and by_kernel["raymarch_kernel"] == (2 * 1000 + 10) * 1024 and "r09_traffic.json" in src
+    t, by_kernel, src = bench.load_traffic("c2|oblique|sparse|0|1")       # only measured for other kernels
+    assert t is None and by_kernel == {} and src.startswith("null:")

@@ -8,7 +8,8 @@ bash tools/prof.sh r02_c3_front --config c3 --camera front $S
 bash tools/prof.sh r02_c3_dense --config c3 --tf dense $S
 bash tools/prof.sh r02_c3_front_general --config c3 --camera front --layout 0 $S
 bash tools/prof.sh r02_c2 --config c2 $S
-bash tools/prof.sh r02_c2_lds --config c2 --lds-staging --layout 0 $S
+bash tools/prof.sh r02_c2_front --config c2 --camera front --layout 0 $S
+bash tools/prof.sh r02_c2_front_lds --config c2 --camera front --lds-staging --layout 0 $S
 # the default command itself (views matrix, skipping leg, CPU baseline off): kernel stats only
 mkdir -p gpurun_out/prof_r02_default_cmd
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r02_default_cmd/stats -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_r02_default_cmd/bench.json 2> gpurun_out/prof_r02_default_cmd/stats.log
