@@ -72,6 +72,18 @@ def nominal_bytes(cfg, st, pixels, accumulate=True, grad=True):
     return st["samples"] * f * tap + st["shadow_samples"] * tap + pixels * (16 + (32 if accumulate else 0) + (12 if grad else 0))
 
 
+def layout_bytes(dtype, n, layout):
+    """bytes of ONE resident layout of an n^3 volume (ovr_hip_kernels.hip::volume_layout): macro blocks of (cells_x x 32 x 32) cells,
+    each storing bricks_x * (cells per brick + 1 apron) * 32 * 32 voxels; general = 3 (u8: 7) cells per brick along the pair
+    axis, thin = 1"""
+    if layout == 0:
+        cells, stored = (28, 4 * 8) if dtype == "uint8" else (30, 10 * 4)
+    else:
+        cells, stored = 32, 32 * 2
+    m = -(-n // 32)
+    return -(-n // cells) * m * m * stored * 32 * 32 * VOXEL_BYTES[dtype]
+
+
 def kernels_hash():
     """hash of the device + host sources of libovr_hip.so: a committed PMC traffic measurement is only quoted for the
     kernels it was taken from"""
@@ -428,9 +440,10 @@ def worker(args, world):
         ph = [p / steps for p in phase_ms]
         kern, dom, abytes = kernel_report(cfg, per_launch, ph, k_ms, pooled, traffic_by_kernel)
         achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        # compulsory floor: every resident brick of the volume once + the framebuffer traffic, at the HBM peak - an
+        # compulsory floor: every brick of the layout the frame reads once + the framebuffer traffic, at the HBM peak - an
         # upper bound of the unique bytes a frame can touch; what the march alone has to read when rays are sparser than voxels
-        floor_bytes = int(vinfo.resident_bytes) + pixels_per_launch * (16 + 32 + 12)
+        read_bytes = layout_bytes(cfg["dtype"], n, last_stats.layout)   # the layout this frame read, not every resident replica
+        floor_bytes = read_bytes + pixels_per_launch * (16 + 32 + 12)
         out = {
             "metric": "Msamples/s (primary ray-march samples after ERT); fps alongside",
             "value": tot["samples"] / dt / 1e6,
@@ -462,7 +475,7 @@ def worker(args, world):
                                       "nominal_frac_survey_F4": (nbytes / (k_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if k_ms > 0 else 0.0},
                          "compulsory_floor_ms": floor_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
                          "compulsory_floor_bytes": floor_bytes,
-                         "volume_resident_bytes": int(vinfo.resident_bytes),
+                         "volume_resident_bytes": int(vinfo.resident_bytes), "volume_layout_read_bytes": read_bytes,
                          "phase_ms_rank0": {"march": ph[0], "shade": ph[1], "composite": ph[2]},
                          "pool_chunks": int(last_stats.pool_chunks),
                          "lds_staging": {"on": bool(args.lds_staging), "fallback_taps_per_frame": int(last_stats.lds_fallback_taps),
