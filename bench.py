@@ -285,6 +285,7 @@ def worker(args, world):
             ren.render_async()
             gatherer.run()
             ren.sync()
+            gatherer.check()
 
     def timed_leg(steps, warmup):
         """warmup untimed steps, then exactly `steps` steps between barrier + device-synchronise pairs"""

@@ -75,7 +75,7 @@ typedef struct ovr_hip_stats {
   uint64_t skipped_samples; /* empty-space skipping: primary iterations whose voxel fetch was skipped (not in `samples`) */
   uint64_t skipped_shadow_samples; /* same for shadow-march iterations (not in `shadow_samples`)                 */
   int32_t layout;           /* which resident layout of the volume the frame read: 0 general, 1 thin, 2 thin transposed */
-  int32_t reserved;
+  int32_t stale_tiles;      /* 1: this frame was rendered again (request-pool overflow) AFTER ovr_hip_pack_tiles had packed it - discard that payload */
   uint64_t lds_fallback_taps;   /* LDS-staged bricks: taps of live samples that fell outside the staged box (read from L1/L2 instead) */
   uint64_t lds_unstaged_rounds; /* LDS-staged bricks: workgroup rounds whose box exceeded the LDS budget (ordinary path)            */
   uint64_t lds_rounds;          /* LDS-staged bricks: workgroup rounds in total                                                      */

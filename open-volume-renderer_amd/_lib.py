@@ -40,7 +40,7 @@ class Stats(C.Structure):
         ("skipped_samples", C.c_uint64),
         ("skipped_shadow_samples", C.c_uint64),
         ("layout", C.c_int32),
-        ("reserved", C.c_int32),
+        ("stale_tiles", C.c_int32),
         ("lds_fallback_taps", C.c_uint64),
         ("lds_unstaged_rounds", C.c_uint64),
         ("lds_rounds", C.c_uint64),

@@ -184,6 +184,10 @@ struct ovr_hip_renderer {
   ovr_hip_stats stats{};
   double render_time_ms = 0.0;
   bool async_pending = false;
+  // pipelined gather (ovr_hip_pack_tiles before the frame is known to be complete): allowed while the request pool has proven
+  // roomy for this configuration - the last frame since the last commit that changed anything used at most half of it
+  bool pool_roomy = false;
+  bool packed_early = false; // the pending frame's tiles were packed without waiting for it
 
   hipStream_t stream() const { return use_user_stream ? user_stream : own_stream[cur]; }
 };
@@ -658,6 +662,8 @@ int finish_frame(ovr_hip_renderer* r)
   if (r->P.pool.reqs) {
     // pool overflow: the march asked for more chunks than the pool holds; nothing was written to the framebuffer.
     // Grow the pool to what the frame needs (+25 %) and render the same frame again.
+    r->stats.stale_tiles = 0;
+    if (r->h_ctrl[3] > r->pool.capacity && r->packed_early) r->stats.stale_tiles = 1; // packed before this re-render: the caller must not use them
     for (int attempt = 0; attempt < 4 && r->h_ctrl[3] > r->pool.capacity; ++attempt) {
       const size_t need = (size_t)r->h_ctrl[3] + (size_t)r->h_ctrl[3] / 4 + 64;
       if (int e = ensure_pool(r, need)) return e;
@@ -667,9 +673,11 @@ int finish_frame(ovr_hip_renderer* r)
     }
     if (r->h_ctrl[3] > r->pool.capacity) return fail(OVR_HIP_EDEVICE, "[hip] request pool overflow persists after re-sizing");
     r->stats.pool_chunks = r->h_ctrl[3];
+    r->pool_roomy = (size_t)r->h_ctrl[3] * 2 <= (size_t)r->pool.capacity;
   }
   else {
     r->stats.pool_chunks = 0;
+    r->pool_roomy = true; // no pool: a frame is never rendered twice
   }
   float ms = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, r->ev[0], r->ev[3]));
@@ -704,6 +712,7 @@ int finish_frame(ovr_hip_renderer* r)
     }
   }
   r->async_pending = false;
+  r->packed_early = false;
   return 0;
 }
 
@@ -1078,6 +1087,7 @@ int ovr_hip_commit(ovr_hip_renderer* r)
     r->sched_list_dirty = true;
     r->fb_reset = true;
   }
+  if (r->fb_reset) r->pool_roomy = false; // something changed: the next frame's request count is unknown
   return 0;
 }
 
@@ -1254,10 +1264,13 @@ int ovr_hip_pack_tiles(ovr_hip_renderer* r, float* dst, size_t dst_bytes)
   if (!r || !dst) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_pack_tiles: null argument");
   if (int e = set_device(r)) return e;
   // A frame of the pooled pipeline may still have to be rendered again (request-pool overflow: nothing was written to the
-  // framebuffer and only the host can grow the pool): resolve it before its tiles are packed.  The wait that costs moves
-  // here from the caller's ovr_hip_sync; the gather enqueued after the pack still overlaps the next frame.
-  if (r->async_pending && r->P.pool.reqs)
-    if (int e = finish_frame(r)) return e;
+  // framebuffer and only the host can grow the pool).  Until the pool has proven roomy for this configuration (the last frame
+  // used at most half of it) the frame is resolved before its tiles are packed; after that the pack is enqueued right behind
+  // the frame, and should the improbable happen - an overflow after all - ovr_hip_stats.stale_tiles tells the caller.
+  if (r->async_pending && r->P.pool.reqs) {
+    if (!r->pool_roomy) { if (int e = finish_frame(r)) return e; }
+    else r->packed_early = true; // steady state: the pack runs right behind the frame, nothing waits on the host
+  }
   const ShardP& s = r->shard.current;
   const int W = r->fbsize.current.w, H = r->fbsize.current.h;
   const size_t need = (size_t)count_owned_tiles(W, H, s.tw, s.th, s.rank, s.world) * s.tw * s.th * 4 * sizeof(float);

@@ -83,9 +83,15 @@ template <> struct Vox<VOX_F32> {
   static constexpr bool kScale = false, kClamp = false;
   static constexpr bool kTransposed = false;
 };
+#ifndef OVR_U16_CX
+#define OVR_U16_CX 3
+#define OVR_U16_MBX 10
+#define OVR_U16_BY 2
+#define OVR_U16_BZ 2
+#endif
 template <> struct Vox<VOX_U16> {
   typedef unsigned short T; typedef u16x2_u P;
-  static constexpr int cx = 3, mbx = 10, by = 2, bz = 2;
+  static constexpr int cx = OVR_U16_CX, mbx = OVR_U16_MBX, by = OVR_U16_BY, bz = OVR_U16_BZ;
   static constexpr bool kScale = false, kClamp = false; // u16 is sampled as RAW float (array.cpp:335-338)
   static constexpr bool kTransposed = false;
 };

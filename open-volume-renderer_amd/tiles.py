@@ -136,6 +136,12 @@ class TileGather:
         self.outstanding = b
         self.index += 1
 
+    def check(self):
+        """after ren.sync(): a frame that overflowed its request pool although the pool had proven roomy was rendered again AFTER
+        its tiles went into the gather - loud failure instead of a stale frame (the caller renders the frame again)"""
+        if self.ren.stats().stale_tiles:
+            raise RuntimeError("[hip] a frame was re-rendered after its tiles had been packed for the gather: gathered tiles are stale")
+
     def flush(self):
         """scatter the last frame's tiles (enqueued on the renderer's stream; ren.sync() or a device sync completes it)"""
         self._scatter_outstanding()
