@@ -186,6 +186,7 @@ def main():
     ap.add_argument("--no-skip-leg", action="store_true", help="do not time the extra leg with empty-space skipping (N = 1 only)")
     ap.add_argument("--no-views", action="store_true", help="do not time the camera x transfer-function matrix (N = 1 only)")
     ap.add_argument("--layout", type=int, default=-1, choices=[-1, 0, 1, 2], help="volume layout a frame reads: -1 by camera direction (default), 0 general, 1 thin, 2 thin transposed")
+    ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2], help="shading pipeline: 0 automatic, 1 in place, 2 pooled")
     ap.add_argument("--lds-staging", action="store_true", help="unshaded march of float volumes: stage the bricks of each round through LDS (measurement switch)")
     ap.add_argument("--skip-empty", action="store_true", help="enable macrocell empty-space skipping (not the headline: fewer samples are fetched)")
     args = ap.parse_args()
@@ -258,6 +259,7 @@ def worker(args, world):
     if multi:
         ren.set_image_shard(rank, world, args.tile, args.tile)
     ren.set_layout_choice(args.layout)
+    ren.set_shading_pipeline(args.pipeline)
     ren.set_lds_staging(args.lds_staging)
     scene = ovr.Scene(volume=vol, transfer_function=None, volume_sampling_rate=cfg["rate"])
     ren.init(scene, ovr.Camera(*cam))

@@ -1,0 +1,186 @@
+"""A second, independent implementation of the ray marcher - written from SURVEY.md Appendix A (the specification of the reference's
+in-tree marcher) in float64 numpy, one ray at a time, sharing no code with oracle/ovr_oracle.c - checks the C oracle for
+transcription errors: frames agree to float32 accuracy, sample counts exactly.  Plus closed forms a homogeneous volume allows."""
+import math
+
+import numpy as np
+import pytest
+
+from helpers import make_case, oracle_scene
+
+LIGHT = np.array([-907.108, 2205.875, -400.0267])
+LIGHT = LIGHT / np.linalg.norm(LIGHT)
+
+
+def _normalize(v):
+    return v / np.sqrt(np.dot(v, v))
+
+
+class Spec:
+    """SURVEY.md Appendix A, cell-centred convention, spp = 1, no accumulation"""
+
+    def __init__(self, vol, colors, alphas, vr, cam, size, fovy, rate, shading, origin=(0, 0, 0), spacing=(1, 1, 1)):
+        self.vol = vol.astype(np.float64)
+        if vol.dtype == np.uint8:
+            self.vol /= 255.0
+        self.dims = np.array(vol.shape[::-1], dtype=np.float64)
+        self.C = np.asarray(colors, np.float64).reshape(-1, 3)
+        self.A = np.asarray(alphas, np.float64).reshape(-1, 2)[:, 1]
+        lo, hi = vr
+        if vol.dtype == np.uint8:
+            lo, hi = float(np.uint8(lo)) / 255.0, float(np.uint8(hi)) / 255.0
+        self.lower, self.upper = lo, hi
+        self.W, self.H = size
+        eye, at, up = (np.array(v, np.float64) for v in cam)
+        t = 2.0 * math.tan(fovy * 0.5 * math.pi / 180.0)
+        aspect = self.W / self.H
+        self.D = _normalize(at - eye)
+        self.Hh = t * aspect * _normalize(np.cross(self.D, up))
+        self.Vv = np.cross(self.Hh, self.D) / aspect
+        self.org = eye
+        self.scale = np.array(spacing, np.float64) * self.dims
+        self.origin = np.array(origin, np.float64)
+        self.step = 1.0 / rate
+        self.shading = shading
+
+    def to_object(self, p):
+        return (p - self.origin) / self.scale
+
+    def box(self, o, d, tmin=0.0):
+        lo_t, hi_t = -np.inf, np.inf
+        for k in range(3):
+            if abs(d[k]) < np.finfo(np.float32).tiny:
+                continue   # the reference ignores the slab of a zero component
+            a, b = (0.0 - o[k]) / d[k], (1.0 - o[k]) / d[k]
+            lo_t, hi_t = max(lo_t, min(a, b)), min(hi_t, max(a, b))
+        t0, t1 = max(tmin, lo_t), hi_t
+        return (t1 > t0), t0, t1
+
+    def tap(self, p):
+        p = np.clip(p, 0.0, 1.0)
+        x = p * self.dims - 0.5
+        x = np.clip(x, 0.0, self.dims - 1.0)
+        i0 = np.floor(x).astype(int)
+        f = x - i0
+        i1 = np.minimum(i0 + 1, self.dims.astype(int) - 1)
+        v = self.vol
+        c00 = v[i0[2], i0[1], i0[0]] * (1 - f[0]) + v[i0[2], i0[1], i1[0]] * f[0]
+        c10 = v[i0[2], i1[1], i0[0]] * (1 - f[0]) + v[i0[2], i1[1], i1[0]] * f[0]
+        c01 = v[i1[2], i0[1], i0[0]] * (1 - f[0]) + v[i1[2], i0[1], i1[0]] * f[0]
+        c11 = v[i1[2], i1[1], i0[0]] * (1 - f[0]) + v[i1[2], i1[1], i1[0]] * f[0]
+        c0, c1 = c00 * (1 - f[1]) + c10 * f[1], c01 * (1 - f[1]) + c11 * f[1]
+        return c0 * (1 - f[2]) + c1 * f[2]
+
+    def tf(self, s):
+        v = (min(max(s, self.lower), self.upper) - self.lower) / (self.upper - self.lower)
+        v = min(max(v, 0.0), 1.0)
+        out = []
+        for table in (self.C, self.A):
+            x = v * (len(table) - 1)
+            i = int(math.floor(x))
+            j = min(i + 1, len(table) - 1)
+            out.append(table[i] + (table[j] - table[i]) * (x - i))
+        return out[0], float(out[1])
+
+    @staticmethod
+    def correct(a, dt):
+        return a if abs(dt - 1.0) < 1e-7 else min(max(1.0 - (1.0 - a) ** dt, 0.0), 1.0)
+
+    def shadow(self, pos):
+        o, d = self.to_object(pos), LIGHT / self.scale
+        hit, t0, t1 = self.box(o, d)
+        sh, n = 0.0, 0
+        if not hit:
+            return sh, n
+        stride = 10.0 * self.step * self.step
+        tx, ty = t0, min(t1, t0 + stride)
+        while ty > tx and sh < np.float32(0.9999):
+            s = self.tap(self.to_object(pos + 0.5 * (tx + ty) * LIGHT))
+            a = self.correct(self.tf(s)[1], ty - tx)
+            sh += (1 - sh) * a
+            n += 1
+            tx, ty = ty, min(ty + stride, t1)
+        return sh, n
+
+    def ray(self, ix, iy):
+        sx, sy = (ix + 0.5) / self.W, (iy + 0.5) / self.H
+        d = _normalize(self.D + (sx - 0.5) * self.Hh + (sy - 0.5) * self.Vv)
+        o, od = self.to_object(self.org), d / self.scale
+        hit, t0, t1 = self.box(o, od)
+        alpha, color, n, n_shaded = 0.0, np.zeros(3), 0, 0
+        if hit:
+            tx, ty = t0, min(t1, t0 + self.step)
+            while ty > tx and alpha < np.float32(0.9999):
+                pos = self.org + 0.5 * (tx + ty) * d
+                p = np.clip(self.to_object(pos), 0.0, 1.0)
+                s = self.tap(p)
+                rgb, a = self.tf(s)
+                a = self.correct(a, ty - tx)
+                n += 1
+                n_shaded += a > 0
+                if self.shading and a > 0:   # opacity 0 contributes nothing: the gradient may be skipped
+                    h = 1.0 / self.dims
+                    g = np.zeros(3)
+                    for k in range(3):
+                        hk = -h[k] if p[k] + h[k] > 1.0 else h[k]
+                        q = p.copy()
+                        q[k] += hk
+                        g[k] = (self.tap(q) - s) / hk
+                    with np.errstate(invalid="ignore", divide="ignore"):
+                        n_o = -g / np.sqrt(np.dot(g, g))
+                        n_w = n_o / self.scale
+                        n_w = n_w / np.sqrt(np.dot(n_w, n_w))
+                    sh = self.shadow(pos)[0] if self.shading == 2 else 0.0
+                    cos = abs(float(np.dot(LIGHT, n_w)))
+                    rgb = rgb * (0.5 + 0.5 * cos * 2.0 * (1.0 - sh))
+                    rgb = np.where(np.isnan(rgb), 0.0, rgb)   # clamp01(NaN) = 0 on the device
+                color += (1 - alpha) * np.clip(rgb, 0.0, 1.0) * a
+                alpha += (1 - alpha) * a
+                tx, ty = ty, min(ty + self.step, t1)
+        out = np.zeros(4)
+        out[3] = alpha
+        if alpha > 0:
+            out[:3] = color / alpha
+        return out, n, n_shaded
+
+
+@pytest.mark.parametrize("shading,dtype,cam,tf", [(0, np.float32, "oblique", "dense"), (1, np.float32, "front", "bumps"), (2, np.float32, "oblique", "bumps"),
+                                                  (2, np.uint8, "oblique", "dense"), (2, np.float32, "inside", "bumps")])
+def test_oracle_agrees_with_an_independent_float64_implementation(ovr, oracle, shading, dtype, cam, tf):
+    case = make_case(ovr, oracle, n=14, dtype=dtype, tf=tf, cam=cam, size=(14, 10), shading=shading, tf_n=64)
+    ref, _, cnt = oracle_scene(oracle, case).render()
+    sp = Spec(case["vol"], case["colors"], case["alphas"], case["vr"], case["cam"], case["size"], case["fovy"], case["rate"], shading)
+    w, h = case["size"]
+    n_tot = n_sh = 0
+    worst = 0.0
+    for iy in range(h):
+        for ix in range(w):
+            px, n, ns = sp.ray(ix, iy)
+            n_tot += n
+            n_sh += ns
+            worst = max(worst, float(np.abs(px - ref[iy, ix]).max()))
+    assert (n_tot, n_sh) == (cnt.samples, cnt.shaded_samples)
+    assert cnt.shaded_samples >= 8 and worst < 2e-5, (cnt.shaded_samples, worst)
+
+
+def test_homogeneous_volume_closed_forms(ovr, oracle):
+    """constant volume, constant opacity a: after n unit steps alpha = 1 - (1 - a)^n, the un-premultiplied colour is the table colour
+    (times the ambient term 0.5 when the gradient is zero: NaN normal -> |N.L| term dropped by clamp), ERT stops at 0.9999"""
+    n = 16
+    vol = np.full((n, n, n), 0.5, np.float32)
+    colors = np.tile(np.array([0.2, 0.6, 0.9], np.float32), 8)
+    for a, shading in ((0.05, 0), (0.3, 0), (0.7, 0)):
+        alphas = np.stack([np.linspace(0, 1, 8, dtype=np.float32), np.full(8, a, np.float32)], axis=1).ravel()
+        cam = ((n / 2, n / 2, n * 4.0), (n / 2, n / 2, n / 2), (0.0, 1.0, 0.0))
+        sc = oracle.OracleScene(vol, colors, alphas, (0.0, 1.0), cam, 9, 9, fovy=20.0, shading=shading)
+        rgba, _, cnt = sc.render()
+        centre = rgba[4, 4]
+        steps = 0
+        alpha = 0.0
+        while steps < n and alpha < np.float32(0.9999):   # the central ray runs n unit steps through the volume
+            alpha += (1 - alpha) * a
+            steps += 1
+        assert abs(centre[3] - alpha) < 1e-5 and abs(centre[3] - (1 - (1 - a) ** steps)) < 1e-5
+        assert np.allclose(centre[:3], [0.2, 0.6, 0.9], atol=1e-5)
+    # fractional last step: opacity correction 1 - (1 - a)^dt
+    assert abs(oracle.load().ovr_oracle_opacity_correction(0.3, 1.0, 0.25) - (1 - 0.7 ** 0.25)) < 1e-6
