@@ -318,7 +318,7 @@ def worker(args, world):
         leg["tot"] = tot
         return leg
 
-    def kernel_report(c, per_launch, ph, k_ms, pooled, traffic_by_kernel):
+    def kernel_report(c, per_launch, ph, k_ms, pooled, traffic_by_kernel, pool_chunks=0):
         """per kernel: algorithmic bytes of the taps that kernel executes / its own mean launch duration (HIP events around
         each kernel, recorded inside libovr_hip.so on the renderer's stream; profiles/*/kernel_stats.csv agrees)"""
         tap = 8 * VOXEL_BYTES[c["dtype"]]
@@ -339,6 +339,10 @@ def worker(args, world):
             if kms > 0:
                 kern[kname] = {"ms": kms, "algorithmic_bytes_per_launch": kb, "achieved": kb / (kms * 1e-3) / 1e9,
                                "frac": kb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_by_kernel.get(kname)}
+        if "composite_kernel" in kern:
+            # not algorithmic bytes but what this pipeline makes the kernel read besides the framebuffer: every request slot of the
+            # frame's chunks (32 B each) - the reason its measured traffic is ~3 x its framebuffer bytes
+            kern["composite_kernel"]["request_bytes_read"] = int(pool_chunks) * 2048
         dom = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
         return kern, dom, abytes
 
@@ -402,7 +406,7 @@ def worker(args, world):
             pl = {k: v / vsteps for k, v in leg["tot"].items()}
             ph = [p / vsteps for p in leg["phase_ms"]]
             vc = dict(cfg, cam=vcam, tf=vtf)
-            kern, dom, abytes = kernel_report(vc, pl, ph, leg["kernel_ms"] / vsteps, leg["last"].pipeline == 2, {})
+            kern, dom, abytes = kernel_report(vc, pl, ph, leg["kernel_ms"] / vsteps, leg["last"].pipeline == 2, {}, leg["last"].pool_chunks)
             views[f"{vcam}/{vtf}"] = {
                 "ms_per_step": leg["dt"] / vsteps * 1e3, "fps": vsteps / leg["dt"], "gsamples_per_s": leg["tot"]["samples"] / leg["dt"] / 1e9,
                 "samples_per_frame": pl["samples"], "shaded_samples_per_frame": pl["shaded_samples"], "shadow_samples_per_frame": pl["shadow_samples"],
@@ -441,7 +445,7 @@ def worker(args, world):
             load_traffic(f"{args.config}|{cfg['cam']}|{cfg['tf']}|{cfg['shading']}|{world}")
         pooled = last_stats.pipeline == 2
         ph = [p / steps for p in phase_ms]
-        kern, dom, abytes = kernel_report(cfg, per_launch, ph, k_ms, pooled, traffic_by_kernel)
+        kern, dom, abytes = kernel_report(cfg, per_launch, ph, k_ms, pooled, traffic_by_kernel, last_stats.pool_chunks)
         achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         # compulsory floor: every brick of the layout the frame reads once + the framebuffer traffic, at the HBM peak - an
         # upper bound of the unique bytes a frame can touch; what the march alone has to read when rays are sparser than voxels
