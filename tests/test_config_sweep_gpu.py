@@ -1,5 +1,6 @@
 """Seeded sweep over combinations the targeted tests do not pair up: dtype x grid shape x shading x samples per pixel x
-accumulation x pipeline x empty-space skipping x sparse sampling x image shard x camera x sampling rate - every case against
+accumulation x pipeline x empty-space skipping x sparse sampling x image shard x camera x sampling rate x (round 2) volume layout x
+pixel jitter x default transfer-function range - every case against
 the CPU oracle (frame within the parity bar, primary sample counts exact)."""
 import numpy as np
 import pytest
@@ -13,6 +14,7 @@ DTYPES = [np.float32, np.uint8, np.uint16, np.int16, np.int8]
 
 def _cases(n_cases=72, seed=20261003):
     rng = np.random.default_rng(seed)
+    rng2 = np.random.default_rng(seed + 2)   # round-2 dimensions, drawn from a second stream so that round 1's 72 cases stay as they were
     out = []
     for i in range(n_cases):
         dims = tuple(int(rng.integers(9, 44)) for _ in range(3))
@@ -24,7 +26,10 @@ def _cases(n_cases=72, seed=20261003):
             tf=str(rng.choice(["sparse", "dense", "bumps"])), size=(int(rng.integers(17, 90)), int(rng.integers(9, 70))),
             spacing=tuple(float(rng.choice([1.0, 0.5, 2.0])) for _ in range(3)), convention=int(rng.integers(2)),
         )
-        out.append(pytest.param(c, id=f"{i:02d}-" + "-".join(str(c[k].__name__ if k == "dtype" else c[k]) for k in ("dtype", "shading", "spp", "pipeline", "skip", "sparse", "cam"))))
+        # volume layout read (forced thin replicas exist for f32 / u16 only; elsewhere the renderer falls back to general), blue-noise
+        # pixel jitter, and the invalid transfer-function range that falls back to the data range
+        c.update(layout=int(rng2.choice([-1, 0, 1, 2])), jitter=bool(rng2.integers(4) == 0), default_range=bool(rng2.integers(5) == 0))
+        out.append(pytest.param(c, id=f"{i:02d}-" + "-".join(str(c[k].__name__ if k == "dtype" else c[k]) for k in ("dtype", "shading", "spp", "pipeline", "skip", "sparse", "cam", "layout", "jitter"))))
     return out
 
 
@@ -34,6 +39,11 @@ def test_config(ovr, oracle, hip_renderer_factory, c):
                      spp=c["spp"], convention=c["convention"], dims=c["dims"], spacing=c["spacing"], tf_n=128)
     kw = {}
     noise = focus = None
+    if c["default_range"]:
+        case["vr"] = (1.0, -1.0)
+    if c["jitter"]:
+        noise = np.random.default_rng(5).random((16, 16, 64), dtype=np.float32)
+        kw.update(jitter=1, noise=noise)
     if c["sparse"]:
         noise = np.random.default_rng(5).random((16, 16, 64), dtype=np.float32)
         focus = ((0.5, 0.45), 0.35, 0.15)
@@ -41,7 +51,13 @@ def test_config(ovr, oracle, hip_renderer_factory, c):
     if c["shard"]:
         kw.update(shard=c["shard"])
     ref, _, cnt = oracle_scene(oracle, case, **kw).render(frames=c["frames"], accumulate=True)
-    ren = hip_setup(ovr, hip_renderer_factory(), case, accumulate=True, pipeline=c["pipeline"])
+    ren = hip_renderer_factory()
+    ren.set_volume_layouts(2)
+    ren.set_layout_choice(c["layout"])
+    if c["jitter"]:
+        ren.set_noise_tile(noise)
+        ren.set_pixel_jitter(1)
+    hip_setup(ovr, ren, case, accumulate=True, pipeline=c["pipeline"])
     ren.set_empty_space_skipping(c["skip"])
     if c["sparse"]:
         ren.set_noise_tile(noise)
