@@ -179,7 +179,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)   # ... after 5 warm-up frames (apps/main_batch.cpp:278-289)
     ap.add_argument("--config", default=os.environ.get("OVR_BENCH_CONFIG", "c3"), choices=sorted(CONFIGS))
     ap.add_argument("--camera", default=None, choices=CAMERAS)
-    ap.add_argument("--tf", default=None, choices=["sparse", "dense", "bumps"])
+    ap.add_argument("--tf", default=None, choices=["sparse", "dense", "bumps", "opaque"])
     ap.add_argument("--shading", type=int, default=None, choices=[0, 1, 2])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile", type=int, default=16, help="image-shard tile size in pixels (16: best balance over 8 ranks, tools/shard_balance.py)")

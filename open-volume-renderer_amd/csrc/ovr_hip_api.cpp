@@ -269,16 +269,20 @@ int resize_framebuffers(ovr_hip_renderer* r, int w, int h)
 
 int ensure_pool(ovr_hip_renderer* r, size_t chunks)
 {
+  // kPoolSubs sub-pools of equal size, each a multiple of 16 chunks (the largest reservation)
+  const size_t sub = ((chunks + kPoolSubs - 1) / kPoolSubs + 15) / 16 * 16;
+  chunks = sub * kPoolSubs;
   if (r->pool.reqs && r->pool.capacity >= chunks) return 0;
   HIP_TRY(hipDeviceSynchronize());
   if (r->pool.reqs) HIP_TRY(hipFree(r->pool.reqs));
   if (r->pool.chunk_next) HIP_TRY(hipFree(r->pool.chunk_next));
   if (r->pool.chunk_n) HIP_TRY(hipFree(r->pool.chunk_n));
-  r->pool.reqs = nullptr; r->pool.chunk_next = nullptr; r->pool.chunk_n = nullptr; r->pool.capacity = 0;
+  r->pool.reqs = nullptr; r->pool.chunk_next = nullptr; r->pool.chunk_n = nullptr; r->pool.capacity = 0; r->pool.sub_capacity = 0;
   HIP_TRY(hipMalloc((void**)&r->pool.reqs, chunks * 64 * 32));
   HIP_TRY(hipMalloc((void**)&r->pool.chunk_next, chunks * sizeof(int)));
   HIP_TRY(hipMalloc((void**)&r->pool.chunk_n, chunks * sizeof(unsigned int)));
   r->pool.capacity = (unsigned int)chunks;
+  r->pool.sub_capacity = (unsigned int)sub;
   return 0;
 }
 
@@ -624,13 +628,13 @@ int enqueue_frame(ovr_hip_renderer* r)
   if (want_pool) {
     // first guess: room for 8 shaded samples per pixel; grown after an overflow (finish_frame)
     // (every tile reserves runs of 8 chunks, so add one run per tile)
-    size_t guess = std::min<size_t>(std::max<size_t>(n * 8 / 64, 4096) + r->pool_tiles * 4, (size_t)1 << 22);
+    size_t guess = std::min<size_t>((std::max<size_t>(n * 8 / 64, 4096) + r->pool_tiles * 4) * 5 / 4, (size_t)1 << 22); // x 1.25: sub-pools fill unevenly
     if (const char* pc = getenv("OVR_HIP_POOL_CHUNKS")) guess = std::max<size_t>(8, (size_t)atoll(pc)); // diagnostic: force the overflow path
     if (int e = ensure_pool(r, std::max<size_t>(guess, r->pool.capacity))) return e;
     if (!r->pool.ctrl) {
-      HIP_TRY(hipMalloc((void**)&r->pool.ctrl, 4 * sizeof(unsigned int)));
+      HIP_TRY(hipMalloc((void**)&r->pool.ctrl, (size_t)kPoolCtrlWords * sizeof(unsigned int)));
       HIP_TRY(hipMalloc((void**)&r->pool.shade_counters, pool_shade_blocks() * 2 * sizeof(unsigned int)));
-      HIP_TRY(hipHostMalloc((void**)&r->h_ctrl, 4 * sizeof(unsigned int), hipHostMallocDefault));
+      HIP_TRY(hipHostMalloc((void**)&r->h_ctrl, (size_t)kPoolCtrlWords * sizeof(unsigned int), hipHostMallocDefault));
     }
     P.pool = r->pool;
     if (P.spp > 1 && !r->d_spp_rgba) {
@@ -650,7 +654,7 @@ int launch_frame(ovr_hip_renderer* r)
   hipStream_t st = r->stream();
   HIP_TRY(launch_raymarch(r->P, st, r->ev));
   HIP_TRY(hipMemcpyAsync(r->h_counters, r->d_counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-  if (r->P.pool.reqs) HIP_TRY(hipMemcpyAsync(r->h_ctrl, r->pool.ctrl, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+  if (r->P.pool.reqs) HIP_TRY(hipMemcpyAsync(r->h_ctrl, r->pool.ctrl, (size_t)kPoolCtrlWords * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
   r->async_pending = true;
   return 0;
 }
@@ -662,18 +666,22 @@ int finish_frame(ovr_hip_renderer* r)
   if (r->P.pool.reqs) {
     // pool overflow: the march asked for more chunks than the pool holds; nothing was written to the framebuffer.
     // Grow the pool to what the frame needs (+25 %) and render the same frame again.
+    // the most chunks any sub-pool was asked for in any generation of the frame
+    auto asked = [&]() { return (size_t)r->h_ctrl[32 * (kPoolSubs + 1)]; };
     r->stats.stale_tiles = 0;
-    if (r->h_ctrl[3] > r->pool.capacity && r->packed_early) r->stats.stale_tiles = 1; // packed before this re-render: the caller must not use them
-    for (int attempt = 0; attempt < 4 && r->h_ctrl[3] > r->pool.capacity; ++attempt) {
-      const size_t need = (size_t)r->h_ctrl[3] + (size_t)r->h_ctrl[3] / 4 + 64;
+    if (asked() > r->pool.sub_capacity && r->packed_early) r->stats.stale_tiles = 1; // packed before this re-render: the caller must not use them
+    for (int attempt = 0; attempt < 4 && asked() > r->pool.sub_capacity; ++attempt) {
+      const size_t need = (asked() + asked() / 4 + 16) * kPoolSubs;
       if (int e = ensure_pool(r, need)) return e;
       r->P.pool = r->pool;
       if (int e = launch_frame(r)) return e;
       HIP_TRY(hipStreamSynchronize(r->stream()));
     }
-    if (r->h_ctrl[3] > r->pool.capacity) return fail(OVR_HIP_EDEVICE, "[hip] request pool overflow persists after re-sizing");
-    r->stats.pool_chunks = r->h_ctrl[3];
-    r->pool_roomy = (size_t)r->h_ctrl[3] * 2 <= (size_t)r->pool.capacity;
+    if (asked() > r->pool.sub_capacity) return fail(OVR_HIP_EDEVICE, "[hip] request pool overflow persists after re-sizing");
+    size_t used = 0; // chunks reserved by the last generation
+    for (int k = 0; k < kPoolSubs; ++k) used += r->h_ctrl[32 * (k + 1)];
+    r->stats.pool_chunks = used;
+    r->pool_roomy = asked() * 2 <= (size_t)r->pool.sub_capacity;
   }
   else {
     r->stats.pool_chunks = 0;

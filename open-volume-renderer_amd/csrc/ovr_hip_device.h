@@ -530,6 +530,10 @@ constexpr int kRun = 4;
 #define OVR_TICKET_RUNS 8
 #endif
 constexpr int kTicketRuns = OVR_TICKET_RUNS; // shade kernel: most runs a workgroup takes per ticket
+#ifndef OVR_TICKET_BLOCK
+#define OVR_TICKET_BLOCK 8
+#endif
+constexpr unsigned int kTicketBlock = OVR_TICKET_BLOCK; // shade kernel: consecutive tickets that stay in one sub-pool
 constexpr int kRunMax = OVR_RUN_MAX; // largest reservation (a multiple of kRun: the shade kernel takes kRun chunks per workgroup)
 
 struct ShadeReq { // 32 bytes; after shading the same slot holds the result (cx,cy,cz,gx,gy,gz,a,next)
@@ -964,6 +968,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
   // reservation: a tile that pushes a lot (dense transfer function: every sample is shaded) would otherwise hit the one
   // pool counter every round - 48 k same-address returning atomics per C3 frame, which serialise in L2
   unsigned int run_base = 0, run_left = 0, run_size = 0, run_next = kRun;
+  bool run_ok = true; // the current reservation lies inside its sub-pool
   int prev_chunk = -1;
   if (POOLED && lane == 0) Q.tile_first[tile] = -1;
   // per-ray request list (identical in the 4 lanes of the quad; the owner lane applies the contributions)
@@ -975,15 +980,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
   // pooled: spill the n oldest queued requests as one chunk of the global pool
   auto spill = [&](unsigned int n) {
     if (run_left == 0) {
+      const unsigned int sub = blockIdx.x & (unsigned int)(kPoolSubs - 1); // the workgroup's sub-pool (PoolDesc)
       unsigned int c0 = 0;
-      if (lane == 0) c0 = atomicAdd(&Q.ctrl[0], run_next);
-      run_base = (unsigned int)__builtin_amdgcn_readfirstlane((int)c0);
+      if (lane == 0) c0 = atomicAdd(&Q.ctrl[32u * (sub + 1u)], run_next);
+      c0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)c0);
       run_left = run_size = run_next;
+      run_ok = c0 + run_size <= Q.sub_capacity;
+      if (!run_ok && lane == 0) Q.ctrl[1] = 1u; // the counter keeps counting: the host sees how much was asked for
+      run_base = sub * Q.sub_capacity + c0;
       run_next = min(run_next * 2u, (unsigned int)kRunMax);
     }
     const unsigned int c = run_base + (run_size - run_left);
     --run_left;
-    if (run_base + run_size <= Q.capacity) {
+    if (run_ok) {
       __builtin_amdgcn_wave_barrier();
       if ((unsigned int)lane < n) Q.reqs[(size_t)c * 64 + lane] = queue[(q_head + lane) & (QCAP - 1)];
       if (lane == 0) {
@@ -993,7 +1002,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
       if (pend > 0 && (last - q_head) < n) last_gidx = c * 64u + (last - q_head);
       prev_chunk = (int)c;
     }
-    // beyond capacity: the pool is exhausted; ctrl[0] keeps counting so the host knows how much was needed, re-sizes
+    // beyond the sub-pool: it is exhausted; its counter keeps counting so the host knows how much was needed, re-sizes
     // the pool and renders the frame again (ovr_hip_api.cpp) - nothing of this frame is used
     q_head += n;
   };
@@ -1359,7 +1368,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_M
 
   if (POOLED) {
     if (q_tail != q_head) spill(q_tail - q_head); // the tile's last, partial chunk
-    if (lane == 0 && run_base + run_size <= Q.capacity)
+    if (lane == 0 && run_ok)
       for (unsigned int i = run_size - run_left; i < run_size && run_left != 0; ++i) Q.chunk_n[run_base + i] = 0; // unused tail of the reservation
     if (lane == 0) Q.tile_count[tile] = q_tail;
     if (active && owner) Q.pix_state[pixel_index] = make_float4(alpha, __uint_as_float(first), __int_as_float(pend), 0.f);
@@ -1398,7 +1407,22 @@ __global__ __launch_bounds__(kBlock) void shade_pool_kernel(const RayMarchParams
   const size_t tb = (stage_tables<VT, AM>(P, lds_raw, vc) + 15) & ~(size_t)15; // [offset tables][TF]
   stage_tf(P, lds_raw + tb, true, tf);
   const PoolDesc& Q = P.pool;
-  const unsigned int n_runs = Q.ctrl[0] > Q.capacity ? 0u : Q.ctrl[0] / (unsigned int)kRun; // overflow: the frame is re-rendered
+  // runs per sub-pool; tickets enumerate them block-cyclically - kTicketBlock consecutive tickets are kTicketBlock consecutive
+  // runs of ONE sub-pool (usually of one tile), the next kTicketBlock tickets belong to the next sub-pool; a ticket beyond its
+  // sub-pool's runs is idle
+  __shared__ unsigned int s_runs[kPoolSubs];
+  __shared__ unsigned int s_tot[2];
+  if (threadIdx.x < (unsigned int)kPoolSubs) s_runs[threadIdx.x] = min(Q.ctrl[32u * (threadIdx.x + 1u)], Q.sub_capacity) / (unsigned int)kRun;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int mx = 0, sum = 0;
+    for (int i = 0; i < kPoolSubs; ++i) { mx = max(mx, s_runs[i]); sum += s_runs[i]; }
+    s_tot[0] = mx; s_tot[1] = sum;
+  }
+  __syncthreads();
+  const bool overflow = Q.ctrl[1] != 0u; // a sub-pool ran out: the frame is re-rendered, nothing to shade
+  const unsigned int total_runs = overflow ? 0u : s_tot[1];
+  const unsigned int n_runs = overflow ? 0u : ((s_tot[0] + kTicketBlock - 1) / kTicketBlock) * kTicketBlock * (unsigned int)kPoolSubs; // tickets
   unsigned int n_shadow = 0, n_shadow_skipped = 0;
   __shared__ unsigned int s_run;
   // Guided self-scheduling: a workgroup takes a BATCH of consecutive runs per ticket - (runs left) / (2 x workgroups), at most
@@ -1408,25 +1432,28 @@ __global__ __launch_bounds__(kBlock) void shade_pool_kernel(const RayMarchParams
   // (run r, chunk `wave`): consecutive depth steps of ONE tile, whose gradient and shadow taps fall into the same bricks.
   // The cap follows the frame: 1 run per ticket up to 32 runs per workgroup (sparse transfer functions: 36 k runs per C3 frame -
   // there batches only cost balance, measured +3 ... 13 %), up to kTicketRuns beyond (dense: 174 k runs, shade 2.11 -> 1.13 ms)
-  const unsigned int ticket_cap = min((unsigned int)kTicketRuns, max(1u, n_runs / (32u * gridDim.x)));
+  const unsigned int ticket_cap = min((unsigned int)kTicketRuns, max(1u, total_runs / (32u * gridDim.x)));
   unsigned int seen = 0; // a lower bound of the global cursor: the end of this workgroup's last batch
   for (;;) {
     const unsigned int left = n_runs > seen ? n_runs - seen : 0u;
     const unsigned int batch = min(ticket_cap, max(1u, left / (2u * gridDim.x)));
     __syncthreads();
-    if (threadIdx.x == 0) s_run = atomicAdd(&Q.ctrl[1], batch);
+    if (threadIdx.x == 0) s_run = atomicAdd(&Q.ctrl[0], batch);
     __syncthreads();
     const unsigned int run0 = s_run;
     if (run0 >= n_runs) break; // every workgroup reaches this: the cursor only grows
     seen = run0 + batch;
     const unsigned int run1 = min(run0 + batch, n_runs);
-    for (unsigned int run = run0; run < run1; ++run) {
+    for (unsigned int ticket = run0; ticket < run1; ++ticket) {
 #ifndef OVR_TICKET_LOCKSTEP
 #define OVR_TICKET_LOCKSTEP 1
 #endif
-      if (OVR_TICKET_LOCKSTEP && run != run0) __syncthreads(); // the 4 waves stay on ONE run: its chunks share their bricks in L1
+      if (OVR_TICKET_LOCKSTEP && ticket != run0) __syncthreads(); // the 4 waves stay on ONE run: its chunks share their bricks in L1
+      const unsigned int grp = ticket / kTicketBlock, sub = grp & (unsigned int)(kPoolSubs - 1);
+      const unsigned int run = (grp / (unsigned int)kPoolSubs) * kTicketBlock + ticket % kTicketBlock;
+      if (run >= s_runs[sub]) continue; // idle ticket (workgroup-uniform)
       for (unsigned int i = (unsigned int)wave; i < (unsigned int)kRun; i += kWaves) {
-        const unsigned int c = run * kRun + i;
+        const unsigned int c = sub * Q.sub_capacity + run * kRun + i;
         const unsigned int n = Q.chunk_n[c];
         if ((unsigned int)lane < n) {
           ShadeReq r = Q.reqs[(size_t)c * 64 + lane];
@@ -1512,13 +1539,13 @@ inline hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
     return hipGetLastError();
   }
   // ---- pooled pipeline: march -> shade -> composite, once per sample-per-pixel generation
-  if ((e = hipMemsetAsync(p.pool.ctrl, 0, 4 * sizeof(unsigned int), stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(p.pool.ctrl, 0, (size_t)kPoolCtrlWords * sizeof(unsigned int), stream)) != hipSuccess) return e;
   if (p.block_counters && p.counters)
     if ((e = hipMemsetAsync(p.counters, 0, 8 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
   RayMarchParams q = p;
   for (int g = 0; g < p.spp; ++g) {
     q.spp_index = g;
-    if (g > 0 && (e = hipMemsetAsync(p.pool.ctrl, 0, 2 * sizeof(unsigned int), stream)) != hipSuccess) return e;
+    if (g > 0 && (e = hipMemsetAsync(p.pool.ctrl, 0, (size_t)32 * (kPoolSubs + 1) * sizeof(unsigned int), stream)) != hipSuccess) return e; // all but the frame's maximum
     {
       constexpr int SH = SHADE == 0 ? 1 : SHADE; // (never instantiated for SHADE == 0: pooled is false)
       const size_t lds = (size_t)kWaves * QCfg<SH, true>::QCAP * sizeof(ShadeReq) + table_lds_bytes(p, AM) + (size_t)p.n_alpha * sizeof(float) + 64;

@@ -44,11 +44,24 @@ struct VolumeDesc {
 struct float3_ { float x, y, z; };
 
 // global request pool of the pooled shading pipeline (see ovr_hip_kernels.hip): 2 KiB chunks of 64 requests
+// The pool is cut into kPoolSubs sub-pools with a chunk counter each, every counter on a 128-byte line of its own: a workgroup
+// of the march reserves from sub-pool (blockIdx.x % kPoolSubs).  One counter for the whole pool was a same-address returning
+// atomic per reservation - they serialise in L2: 26 k of them were ALL of the march's time (0.42 ms) on a frame whose rays end at
+// their first sample, and half of it with a dense transfer function.  8 sub-pools remove that (march 1.00 -> 0.57 ms, dense TF);
+// 16 or 64 bring nothing more and slow the shade kernel down (sparse TF: 1.12 -> 1.15 / 1.25 ms), profiles/r02_notes.md.
+#ifndef OVR_POOL_SUBS
+#define OVR_POOL_SUBS 8
+#endif
+constexpr int kPoolSubs = OVR_POOL_SUBS; // a power of two, at most 64
+constexpr int kPoolCtrlWords = 32 * (kPoolSubs + 2);
+// ctrl words: [0] shade ticket cursor, [1] overflow flag of this generation (a sub-pool ran out), [32 * (s + 1)] chunks reserved
+// from sub-pool s (all of these zeroed per generation), [32 * (kPoolSubs + 1)] the most any sub-pool was asked for in any
+// generation of the frame (zeroed per frame; > sub_capacity: the host grows the pool and renders the frame again)
 struct PoolDesc {
   struct ShadeReq* reqs;        // capacity * 64 requests of 32 bytes (null = pipeline disabled)
-  unsigned int capacity;        // chunks
-  unsigned int* ctrl;           // [0] chunks requested by the march  [1] shade cursor (both zeroed per generation)
-                                // [3] most chunks any generation of the frame requested (zeroed per frame)
+  unsigned int capacity;        // chunks = kPoolSubs * sub_capacity
+  unsigned int sub_capacity;    // chunks per sub-pool (a multiple of 16); sub-pool s owns chunks [s * sub_capacity, (s + 1) * sub_capacity)
+  unsigned int* ctrl;           // kPoolCtrlWords words, see above
   int* chunk_next;              // per chunk: next chunk of the same tile
   unsigned int* chunk_n;        // per chunk: requests in it (64 except a tile's last)
   int* tile_first;              // per tile (wave of the march grid): first chunk or -1

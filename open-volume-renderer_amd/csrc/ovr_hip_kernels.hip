@@ -17,6 +17,7 @@
 #include "ovr_hip_device.h"
 
 namespace ovrhip {
+static_assert(kPoolSubs <= 64 && (kPoolSubs & (kPoolSubs - 1)) == 0, "reduce_counters_kernel reduces the sub-pool counters with one wave");
 // ------------------------------------------------------------------------------------------------------------------
 // pooled pipeline, kernel C: every tile walks its chunks in order, composites and writes its pixels
 // ------------------------------------------------------------------------------------------------------------------
@@ -26,7 +27,7 @@ __global__ __launch_bounds__(kBlock) void composite_kernel(const RayMarchParams 
   int ix, iy;
   const bool active = assign_pixel_quad(P, lane, wave, ix, iy) && (lane & 3) == 0; // one owner lane per ray, as in the march
   const PoolDesc& Q = P.pool;
-  if (Q.ctrl[0] > Q.capacity) return; // pool overflow: the host re-renders this frame with a larger pool, nothing may be written
+  if (Q.ctrl[1] != 0u) return; // pool overflow: the host re-renders this frame with a larger pool, nothing may be written
   const unsigned int tile = blockIdx.x * kWaves + wave;
   const unsigned int pixel_index = (unsigned int)ix + (unsigned int)iy * (unsigned int)P.width;
   float alpha = 0.f;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void composite_kernel(const RayMarchParams 
         *sr = acc; sg[0] = accg.x; sg[1] = accg.y; sg[2] = accg.z;
         return;
       }
-      if (Q.ctrl[3] > Q.capacity) return; // an earlier generation overflowed the pool: the whole frame is re-rendered
+      if (Q.ctrl[32 * (kPoolSubs + 1)] > Q.sub_capacity) return; // an earlier generation overflowed the pool: the whole frame is re-rendered
       const float rspp = 1.f / (float)P.spp;
       o_a = acc.w * rspp;
       o_c = mk3(acc.x * rspp, acc.y * rspp, acc.z * rspp);
@@ -101,7 +102,12 @@ __global__ __launch_bounds__(kBlock) void composite_kernel(const RayMarchParams 
 __global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned int* __restrict__ partials, int n_blocks, const unsigned int* __restrict__ shade_partials,
                                                              int n_shade_blocks, unsigned long long* counters, unsigned int* pool_ctrl)
 {
-  if (pool_ctrl && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&pool_ctrl[3], pool_ctrl[0]); // most chunks any generation asked for
+  if (pool_ctrl && blockIdx.x == 0 && threadIdx.x < 64) { // most chunks any sub-pool was asked for in any generation (kPoolSubs == 64: one wave)
+    unsigned int v = threadIdx.x < (unsigned int)kPoolSubs ? pool_ctrl[32u * (threadIdx.x + 1u)] : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned int)__shfl_xor((int)v, off));
+    if (threadIdx.x == 0) atomicMax(&pool_ctrl[32 * (kPoolSubs + 1)], v);
+  }
   __shared__ unsigned long long red[4][kNC];
   unsigned long long acc[kNC] = { 0, 0, 0, 0, 0, 0, 0 };
   const int stride = gridDim.x * 256;

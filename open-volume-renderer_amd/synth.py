@@ -112,6 +112,8 @@ def make_tfn(kind="sparse", n=1024, dtype=np.float32):
         alpha = np.where(i < lo, 0.0, np.where(i < hi, 0.6 * (i - lo) / max(hi - lo, 1), 0.6))
     elif kind == "dense":
         alpha = 0.9 * i / max(n - 1, 1)
+    elif kind == "opaque":   # every sample ends its ray (alpha 1): a frame of fixed per-ray / per-workgroup costs only
+        alpha = np.ones(n)
     elif kind == "bumps":   # a few narrow iso-surface-like peaks: exercises the alpha>0 / alpha==0 divergence
         alpha = np.zeros(n)
         for c, w, a in ((0.35, 0.03, 0.3), (0.6, 0.04, 0.5), (0.85, 0.05, 0.8)):
