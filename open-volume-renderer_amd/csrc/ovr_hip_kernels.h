@@ -47,10 +47,11 @@ struct float3_ { float x, y, z; };
 // The pool is cut into kPoolSubs sub-pools with a chunk counter each, every counter on a 128-byte line of its own: a workgroup
 // of the march reserves from sub-pool (blockIdx.x % kPoolSubs).  One counter for the whole pool was a same-address returning
 // atomic per reservation - they serialise in L2: 26 k of them were ALL of the march's time (0.42 ms) on a frame whose rays end at
-// their first sample, and half of it with a dense transfer function.  8 sub-pools remove that (march 1.00 -> 0.57 ms, dense TF);
-// 16 or 64 bring nothing more and slow the shade kernel down (sparse TF: 1.12 -> 1.15 / 1.25 ms), profiles/r02_notes.md.
+// their first sample, and half of it with a dense transfer function.  4 sub-pools remove that (march 1.00 -> 0.59 ms, dense TF);
+// more bring little (8: 0.57) and slow the shade kernel down - its requests lose their creation order - by 1.7 % (8), 2 % (16),
+// 11 % (64) on the sparse-TF headline; profiles/r02_notes.md, profiles/r02_ab/r02_ab_ps*.txt.
 #ifndef OVR_POOL_SUBS
-#define OVR_POOL_SUBS 8
+#define OVR_POOL_SUBS 4
 #endif
 constexpr int kPoolSubs = OVR_POOL_SUBS; // a power of two, at most 64
 constexpr int kPoolCtrlWords = 32 * (kPoolSubs + 2);
