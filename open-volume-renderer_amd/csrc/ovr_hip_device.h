@@ -846,7 +846,11 @@ template <int SHADE, bool POOLED> struct QCfg {
 constexpr int kLdsBrickCap = 384;                       // 48 KiB of bricks per workgroup: two workgroups per CU
 struct LdsRegion { int bx0, by0, bz0, ebx, eby, ebz, nbr, ok; };
 template <int VT, int SHADE, int AM, bool POOLED, bool SKIP, bool LDSB = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, OVR_MARCH_WPE))) void raymarch_kernel(const RayMarchParams P)
+#ifndef OVR_PIN_AM
+#define OVR_PIN_AM 1 /* the 64-bit addressing modes would spill to scratch under the pin */
+#endif
+// (the skipping pooled march sits at the edge of the 3-waves budget: 169 VGPRs - one too many - cost it 15 %; it is pinned to 3)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP && POOLED && AM <= OVR_PIN_AM) ? OVR_MARCH_WPE : 1, OVR_MARCH_WPE))) void raymarch_kernel(const RayMarchParams P)
 {
   static_assert(!LDSB || (SHADE == 0 && !POOLED && !SKIP && AM <= 1 && !Vox<VT>::kTransposed), "LDS-staged bricks: unshaded in-place march only");
   using Cfg = QCfg<SHADE, POOLED>;

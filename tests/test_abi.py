@@ -60,3 +60,38 @@ def test_plugin_exports_the_reference_factory_symbol():
     import subprocess
     out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
     assert " T ovr_create_renderer__hip" in out
+
+
+def test_march_kernels_keep_their_register_budget(tmp_path):
+    """The march is fragile under the compiler's register allocation (compiler note): the pooled march must stay within
+    the 3-waves-per-SIMD budget (<= 168 VGPRs - at 169 the skipping variant lost 15 %) and no march / shade kernel may spill to
+    scratch.  Read from the code objects embedded in the built library (no GPU, no recompilation)."""
+    import shutil
+    import subprocess
+    lib = os.path.join(ROOT, "open-volume-renderer_amd", "libovr_hip.so")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(lib) and os.path.exists(os.path.join(llvm, "llvm-objdump"))):
+        pytest.skip("library or llvm tools not present")
+    shutil.copy(lib, tmp_path / "lib.so")
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", "lib.so"], cwd=tmp_path, capture_output=True, check=True)
+    kernels = {}
+    for f in sorted(os.listdir(tmp_path)):
+        if "gfx950" not in f:
+            continue
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", f], cwd=tmp_path, capture_output=True, text=True, check=True).stdout
+        name = None
+        for line in notes.splitlines():
+            line = line.strip()
+            if line.startswith(".name:"):
+                name = line.split(":", 1)[1].strip()
+                kernels[name] = {}
+            elif name and (line.startswith(".vgpr_count:") or line.startswith(".private_segment_fixed_size:")):
+                k, v = line.split(":")
+                kernels[name][k.strip()] = int(v)
+    march = {n: k for n, k in kernels.items() if "raymarch_kernel" in n or "shade_pool_kernel" in n}
+    assert len(march) > 200, len(march)
+    for n, k in march.items():
+        assert k[".private_segment_fixed_size"] == 0, (n, k)
+        # raymarch_kernel<VT, SHADE, AM, POOLED = true, SKIP, LDSB>: ...ILi<vt>ELi<shade>ELi<am>ELb1E...
+        if "raymarch_kernel" in n and re.search(r"raymarch_kernelILi\d+ELi\d+ELi[012]ELb1E", n):
+            assert k[".vgpr_count"] <= 168, (n, k)
