@@ -91,7 +91,10 @@ def test_march_kernels_keep_their_register_budget(tmp_path):
     march = {n: k for n, k in kernels.items() if "raymarch_kernel" in n or "shade_pool_kernel" in n}
     assert len(march) > 200, len(march)
     for n, k in march.items():
-        assert k[".private_segment_fixed_size"] == 0, (n, k)
+        # no scratch - but for the pinned skipping variants, where 3 spilled dwords in a cold path were measured 27 % faster than
+        # giving up the third wave (transposed thin layout, C3 side view: march 0.345 vs 0.439 ms)
+        pinned = re.search(r"raymarch_kernelILi\d+ELi\d+ELi[01]ELb1ELb1E", n) is not None
+        assert k[".private_segment_fixed_size"] <= (16 if pinned else 0), (n, k)
         # raymarch_kernel<VT, SHADE, AM, POOLED = true, SKIP, LDSB>: ...ILi<vt>ELi<shade>ELi<am>ELb1E...; the 64-bit addressing modes
         # (AM 2, 3) may take more (measured: no difference on C4, the only configuration that uses them)
         if "raymarch_kernel" in n and re.search(r"raymarch_kernelILi\d+ELi\d+ELi[01]ELb1E", n):
