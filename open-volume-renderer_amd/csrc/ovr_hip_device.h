@@ -845,7 +845,12 @@ template <int SHADE, bool POOLED> struct QCfg {
 // Built for the in-place, unshaded march of the general f32 layout (BASELINE C2, where rays are denser than voxels).
 constexpr int kLdsBrickCap = 384;                       // 48 KiB of bricks per workgroup: two workgroups per CU
 struct LdsRegion { int bx0, by0, bz0, ebx, eby, ebz, nbr, ok; };
-template <int VT, int SHADE, int AM, bool POOLED, bool SKIP, bool LDSB = false>
+// DEEP = true (plain pooled march only): 6 instead of 4 instructions (x 4 steps) per round - 24 pair loads in flight per lane at 2
+// waves per SIMD (198 VGPRs) instead of 16 at 3.  On a full frame the two are within 1 % of each other (and 4 is better with dense
+// transfer functions and on axis views), but a ray's chain of dependent rounds is the floor of an image SHARD's march, and there 6
+// wins: 8-way shard of C3 0.295 -> 0.250 ms, 4-way 0.451 -> 0.423 (profiles/r02_notes.md).  launch_vsbs picks it when world > 1.
+constexpr int kDeepK = 6;
+template <int VT, int SHADE, int AM, bool POOLED, bool SKIP, bool LDSB = false, bool DEEP = false>
 #ifndef OVR_PIN_AM
 #define OVR_PIN_AM 1 /* the 64-bit addressing modes would spill to scratch under the pin */
 #endif
@@ -854,7 +859,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
 {
   static_assert(!LDSB || (SHADE == 0 && !POOLED && !SKIP && AM <= 1 && !Vox<VT>::kTransposed), "LDS-staged bricks: unshaded in-place march only");
   using Cfg = QCfg<SHADE, POOLED>;
-  constexpr int K = Cfg::K;
+  static_assert(!DEEP || (POOLED && !SKIP && !LDSB), "the deep variant exists for the plain pooled march");
+  constexpr int K = DEEP ? kDeepK : Cfg::K;
   constexpr int QCAP = Cfg::QCAP;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1553,9 +1559,20 @@ inline hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
     {
       constexpr int SH = SHADE == 0 ? 1 : SHADE; // (never instantiated for SHADE == 0: pooled is false)
       const size_t lds = (size_t)kWaves * QCfg<SH, true>::QCAP * sizeof(ShadeReq) + table_lds_bytes(p, AM) + (size_t)p.n_alpha * sizeof(float) + 64;
-      auto kern = raymarch_kernel<VT, SH, AM, true, SKIP>;
-      if ((e = set_lds(kern, lds)) != hipSuccess) return e;
-      if (grid.x > 0) hipLaunchKernelGGL(kern, grid, block, lds, stream, q);
+      bool launched = false;
+      if constexpr (!SKIP) {
+        if (p.world > 1) { // an image shard: fewer rays, the longest ray's chain of rounds is the floor - deeper rounds
+          auto kern = raymarch_kernel<VT, SH, AM, true, SKIP, false, true>;
+          if ((e = set_lds(kern, lds)) != hipSuccess) return e;
+          if (grid.x > 0) hipLaunchKernelGGL(kern, grid, block, lds, stream, q);
+          launched = true;
+        }
+      }
+      if (!launched) {
+        auto kern = raymarch_kernel<VT, SH, AM, true, SKIP>;
+        if ((e = set_lds(kern, lds)) != hipSuccess) return e;
+        if (grid.x > 0) hipLaunchKernelGGL(kern, grid, block, lds, stream, q);
+      }
       if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (ev && g == p.spp - 1) (void)hipEventRecord(ev[1], stream);
