@@ -840,6 +840,7 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
     r->vd_replica[k] = VolumeDesc{};
   }
   r->d_volume = nullptr;
+  r->have_volume = false; // until the new one is completely resident: a failure below must not leave a half-built volume renderable
   HIP_TRY(hipMalloc(&r->d_replica[0], bytes + 64)); // + slack: the pair load of the very last element
   HIP_TRY(hipMemset(r->d_replica[0], 0, bytes + 64));  // padding voxels are never sampled, but must be finite
   r->d_volume = r->d_replica[0];
