@@ -417,6 +417,35 @@ def worker(args, world):
         ren.set_camera(*cam)
         ren.commit()
 
+    # the other settings SURVEY 8d wants beside the headline (N = 1): the frame without the shadow march, at the scene files' fovy
+    # of 45 degrees (renderbatch renders 60: renderer.h:149-152), and at the scene files' sampling rate 4 (sampleDistance 0.25)
+    variants = None
+    if views is not None:
+        variants = {}
+        for vname, vkw in (("no_shadow_march", dict(shading=1)), ("fovy_45", dict(fovy=45.0)), ("sampling_rate_4", dict(rate=4.0))):
+            if "shading" in vkw and cfg["shading"] != 2:
+                continue
+            vc = dict(cfg, **{k: v for k, v in vkw.items() if k != "fovy"})
+            ren.set_shading(vc["shading"])
+            ren.set_volume_sampling_rate(vc["rate"])
+            ren.set_camera(ovr.Camera(*cam, fovy=vkw.get("fovy", 60.0)))
+            ren.commit()
+            vsteps = 5 if vname == "sampling_rate_4" else 10
+            leg = timed_leg(vsteps, 3)
+            pl = {k: v / vsteps for k, v in leg["tot"].items()}
+            ph = [p / vsteps for p in leg["phase_ms"]]
+            kern, dom, abytes = kernel_report(vc, pl, ph, leg["kernel_ms"] / vsteps, leg["last"].pipeline == 2, {}, leg["last"].pool_chunks)
+            variants[vname] = {
+                "ms_per_step": leg["dt"] / vsteps * 1e3, "fps": vsteps / leg["dt"], "gsamples_per_s": leg["tot"]["samples"] / leg["dt"] / 1e9,
+                "samples_per_frame": pl["samples"], "shaded_samples_per_frame": pl["shaded_samples"], "shadow_samples_per_frame": pl["shadow_samples"],
+                "phase_ms": {"march": ph[0], "shade": ph[1], "composite": ph[2]},
+                "kernel": dom, "frac": kern[dom]["frac"] if dom else None,
+                "pipeline_frac": abytes / (leg["kernel_ms"] / vsteps * 1e-3) / 1e9 / HBM_PEAK_GBS if leg["kernel_ms"] > 0 else None}
+        ren.set_shading(cfg["shading"])
+        ren.set_volume_sampling_rate(cfg["rate"])
+        ren.set_camera(*cam)
+        ren.commit()
+
     # max over ranks of the elapsed time, sum over ranks of the work
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -493,6 +522,8 @@ def worker(args, world):
             out["backend"] = dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")
         if views is not None:
             out["roofline"]["views"] = views
+        if variants:
+            out["roofline"]["variants"] = variants
         if skip_leg is not None:
             out["with_empty_space_skipping"] = skip_leg
         if want_cpu:

@@ -114,6 +114,7 @@ struct ovr_hip_renderer {
   size_t volume_bytes = 0; // all resident replicas
   VolumeDesc vd{};
   void* d_replica[3] = { nullptr, nullptr, nullptr };
+  void* d_axis[3] = { nullptr, nullptr, nullptr }; // per layout: its per-axis offset tables (VolumeDesc::axis_ab / axis_z)
   VolumeDesc vd_replica[3] = {};
   Queued<int> layouts;      // ovr_hip_set_volume_layouts: which replicas the next ovr_hip_set_volume builds
   Queued<int> layout_choice; // -1 = by the camera direction, 0..2 = forced (falls back to general if not resident)
@@ -778,8 +779,10 @@ void ovr_hip_destroy(ovr_hip_renderer* r)
   (void)hipSetDevice(r->device);
   (void)hipDeviceSynchronize();
   (void)free_framebuffers(r);
-  for (int k = 0; k < 3; ++k)
+  for (int k = 0; k < 3; ++k) {
     if (r->d_replica[k]) (void)hipFree(r->d_replica[k]);
+    if (r->d_axis[k]) (void)hipFree(r->d_axis[k]);
+  }
   if (r->d_tf_color) (void)hipFree(r->d_tf_color);
   if (r->d_tf_alpha) (void)hipFree(r->d_tf_alpha);
   if (r->d_noise) (void)hipFree(r->d_noise);
@@ -837,6 +840,8 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
   for (int k = 0; k < 3; ++k) {
     if (r->d_replica[k]) HIP_TRY(hipFree(r->d_replica[k]));
     r->d_replica[k] = nullptr;
+    if (r->d_axis[k]) HIP_TRY(hipFree(r->d_axis[k]));
+    r->d_axis[k] = nullptr;
     r->vd_replica[k] = VolumeDesc{};
   }
   r->d_volume = nullptr;
@@ -885,6 +890,11 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
       }
     }
   }
+  for (int k = 0; k < n_layouts; ++k) { // the layouts' per-axis offset tables, staged into LDS by every march / shade workgroup
+    HIP_TRY(hipMalloc(&r->d_axis[k], axis_table_bytes(r->vd_replica[k])));
+    HIP_TRY(launch_axis_tables(r->vd_replica[k], r->d_axis[k], st_));
+  }
+  vd = r->vd_replica[0];
   auto relayout_all = [&](const void* src, int z0, int nzc) -> hipError_t {
     for (int k = 0; k < n_layouts; ++k)
       if (hipError_t e = launch_relayout(src, value_type, r->d_replica[k], r->vd_replica[k], z0, nzc, st_)) return e;

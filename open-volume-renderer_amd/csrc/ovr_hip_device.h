@@ -215,6 +215,8 @@ __device__ __forceinline__ unsigned int tap_cell(const VolConsts& vc, const Tap&
   return (unsigned int)cx + (unsigned int)(vc.mcx1 + 1) * ((unsigned int)cy + (unsigned int)(vc.mcy1 + 1) * (unsigned int)cz);
 }
 
+// (A non-temporal hint on these loads - `global_load ... nt` - was measured: the march takes 3.50 instead of 1.51 ms, the shade
+// kernel 3.17 instead of 1.13 ms on C3: neighbouring quads and consecutive rounds do re-use the lines; profiles/r02_notes.md §7.)
 template <int VT, int AM>
 __device__ __forceinline__ void tap_loads(const VolConsts& vc, Tap& t)
 {
@@ -569,41 +571,35 @@ __device__ __forceinline__ void setup_consts(const RayMarchParams& P, VolConsts&
   mc.step = P.step; mc.base = P.base; mc.shadow_stride = P.shadow_stride;
 }
 
-// build the per-axis offset tables in LDS (all threads of the workgroup); returns the bytes used
+// copy the layout's per-axis offset tables (VolumeDesc::axis_ab / axis_z, built once per volume by axis_tables_kernel) into LDS,
+// scaled to what the addressing mode adds to its base (all threads of the workgroup); returns the bytes used
 template <int VT, int AM>
 __device__ __forceinline__ size_t stage_tables(const RayMarchParams& P, unsigned char* base, VolConsts& vc)
 {
-  typedef BrickMap<VT> M;
   vc.tab_x = vc.tab_y = vc.tab_z = nullptr;
   vc.tab_z64 = nullptr;
   if (AM == 3) return 0;
   // layout axes: a = pair axis, b = the other one (x and y, exchanged in a transposed replica)
   const int na = Vox<VT>::kTransposed ? P.vol.ny : P.vol.nx, nb = Vox<VT>::kTransposed ? P.vol.nx : P.vol.ny;
-  if (AM == 2) { // [z: nz + 1 x u64][a: na x u32][b: nb + 1 x u32], element offsets
+  const unsigned int* __restrict__ gab = P.vol.axis_ab;
+  const unsigned long long* __restrict__ gz = P.vol.axis_z;
+  const int nab = na + nb + 1;
+  if (AM == 2) { // [z: nz + 1 x u64][a: na x u32][b: nb + 1 x u32], element offsets: the global tables as they are
     unsigned long long* tz = reinterpret_cast<unsigned long long*>(base);
     unsigned int* tx = reinterpret_cast<unsigned int*>(tz + P.vol.nz + 1);
-    unsigned int* ty = tx + na;
-    for (int i = threadIdx.x; i < na; i += kBlock) tx[i] = M::X((unsigned)i);
-    for (int i = threadIdx.x; i <= nb; i += kBlock) ty[i] = M::Y((unsigned)min(i, nb - 1), vc.macro_y);
-    for (int i = threadIdx.x; i <= P.vol.nz; i += kBlock) {
-      const unsigned z = (unsigned)min(i, P.vol.nz - 1);
-      tz[i] = (unsigned long long)M::Zlo(z) + (unsigned long long)(z >> 5) * vc.macro_z;
-    }
-    vc.tab_x = tx; vc.tab_y = ty; vc.tab_z64 = tz;
-    return (size_t)(P.vol.nz + 1) * sizeof(unsigned long long) + (size_t)(na + nb + 1) * sizeof(unsigned int);
+    for (int i = threadIdx.x; i < nab; i += kBlock) tx[i] = gab[i];
+    for (int i = threadIdx.x; i <= P.vol.nz; i += kBlock) tz[i] = gz[i];
+    vc.tab_x = tx; vc.tab_y = tx + na; vc.tab_z64 = tz;
+    return (size_t)(P.vol.nz + 1) * sizeof(unsigned long long) + (size_t)nab * sizeof(unsigned int);
   }
+  // AM 0: byte offsets (the volume is <= 4 GiB), AM 1: element offsets (< 2^32 stored voxels) - 32 bits hold every entry
   unsigned int* tx = reinterpret_cast<unsigned int*>(base);
-  unsigned int* ty = tx + na;
-  unsigned int* tz = ty + nb + 1;
+  unsigned int* tz = tx + nab;
   const unsigned int mul = AM == 0 ? (unsigned int)sizeof(typename Vox<VT>::T) : 1u;
-  for (int i = threadIdx.x; i < na; i += kBlock) tx[i] = M::X((unsigned)i) * mul;
-  for (int i = threadIdx.x; i <= nb; i += kBlock) ty[i] = M::Y((unsigned)min(i, nb - 1), vc.macro_y) * mul;
-  for (int i = threadIdx.x; i <= P.vol.nz; i += kBlock) {
-    const unsigned z = (unsigned)min(i, P.vol.nz - 1);
-    tz[i] = (M::Zlo(z) + (z >> 5) * (unsigned)vc.macro_z) * mul;
-  }
-  vc.tab_x = tx; vc.tab_y = ty; vc.tab_z = tz;
-  return (size_t)(na + nb + P.vol.nz + 2) * sizeof(unsigned int);
+  for (int i = threadIdx.x; i < nab; i += kBlock) tx[i] = gab[i] * mul;
+  for (int i = threadIdx.x; i <= P.vol.nz; i += kBlock) tz[i] = (unsigned int)gz[i] * mul;
+  vc.tab_x = tx; vc.tab_y = tx + na; vc.tab_z = tz;
+  return (size_t)(nab + P.vol.nz + 1) * sizeof(unsigned int);
 }
 __host__ inline size_t table_lds_bytes(const RayMarchParams& p, int am)
 {
@@ -1609,6 +1605,7 @@ inline hipError_t launch_vs(const RayMarchParams& p, hipStream_t stream, const h
   int am = p.vol.bytes <= 0x100000000ull ? 0 : (p.vol.bytes / voxel_size(p.vol.type) < 0xffffffffull) ? 1 : 2;
   if (const char* f = getenv("OVR_HIP_ADDRESSING")) am = std::max(am, atoi(f)); // diagnostic: a more general mode than needed (tests)
   if (am == 2 && table_lds_bytes(p, 2) > 64 * 1024) am = 3;
+  if (am < 3 && (!p.vol.axis_ab || !p.vol.axis_z)) return hipErrorInvalidValue; // the layout's offset tables (launch_axis_tables)
   switch (am) {
   case 0: return launch_vsb<VT, SHADE, 0>(p, stream, ev);
   case 1: return launch_vsb<VT, SHADE, 1>(p, stream, ev);

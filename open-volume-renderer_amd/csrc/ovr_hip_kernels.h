@@ -39,6 +39,13 @@ struct VolumeDesc {
   unsigned long long bytes;         // macros_x * macros_y * macros_z * macro_elems * sizeof(voxel)
   float value_scale; // multiplier turning a filtered raw value into what the reference's texture read returns
   float value_min_clamp; // raw clamp applied per voxel before filtering (i8: -127) - see array.h:83-90
+  // per-axis ELEMENT offsets of this layout, built once per volume (launch_axis_tables): off(a, b, z) = axis_ab[a] +
+  // axis_ab[na + b] + axis_z[z] with (a, b) = (x, y), exchanged in a transposed replica; the b and z tables hold one extra
+  // entry equal to their last one (clamp-to-edge).  The march / shade workgroups copy them into LDS (stage_tables) instead of
+  // computing ~3 k entries with 64-bit multiplies each (fewer instructions and 0.5 MB less code; the frame time did not move:
+  // the prologue hides behind the other workgroups of the CU - profiles/r02_notes.md §7)
+  const unsigned int* axis_ab;       // [na][nb + 1]
+  const unsigned long long* axis_z;  // [nz + 1]
 };
 
 struct float3_ { float x, y, z; };
@@ -143,6 +150,10 @@ void volume_layout(int voxel_type, int nx, int ny, int nz, VolumeDesc& vd); // f
 size_t voxel_size(int voxel_type);
 hipError_t launch_relayout(const void* src_linear, int ovr_value_type, void* dst, const VolumeDesc& vd, int z0, int nz_chunk,
                            hipStream_t stream);
+// per-axis offset tables of a layout: bytes of the device buffer, and the kernel that fills it ([z: nz + 1 x u64][a: na x u32]
+// [b: nb + 1 x u32]) and points vd.axis_z / vd.axis_ab into it
+size_t axis_table_bytes(const VolumeDesc& vd);
+hipError_t launch_axis_tables(VolumeDesc& vd, void* d_tables, hipStream_t stream);
 
 // sparse-sampling mask (generate_mask.cu:55-120): writes compacted (x,y) pairs, count (int32 elements) to *count
 struct SparseMaskParams {

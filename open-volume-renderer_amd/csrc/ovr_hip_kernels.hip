@@ -423,6 +423,53 @@ hipError_t launch_relayout(const void* src, int vt, void* dst, const VolumeDesc&
   }
 }
 
+// per-axis offset tables of a layout (VolumeDesc::axis_ab / axis_z), once per volume
+template <int VT>
+__global__ __launch_bounds__(256) void axis_tables_kernel(VolumeDesc vd, unsigned int* __restrict__ ab, unsigned long long* __restrict__ tz)
+{
+  typedef BrickMap<VT> M;
+  const int na = Vox<VT>::kTransposed ? vd.ny : vd.nx, nb = Vox<VT>::kTransposed ? vd.nx : vd.ny;
+  const unsigned int macro_y = vd.macro_elems * (unsigned int)vd.macros_x;
+  const unsigned long long macro_z = (unsigned long long)vd.macro_elems * (unsigned long long)vd.macros_x * (unsigned long long)vd.macros_y;
+  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (i < na) ab[i] = M::X((unsigned)i);
+  if (i <= nb) ab[na + i] = M::Y((unsigned)min(i, nb - 1), macro_y);
+  if (i <= vd.nz) {
+    const unsigned z = (unsigned)min(i, vd.nz - 1);
+    tz[i] = (unsigned long long)M::Zlo(z) + (unsigned long long)(z >> 5) * macro_z;
+  }
+}
+size_t axis_table_bytes(const VolumeDesc& vd)
+{
+  return (size_t)(vd.nz + 1) * sizeof(unsigned long long) + (size_t)(vd.nx + vd.ny + 1) * sizeof(unsigned int);
+}
+template <int VT>
+static hipError_t axis_tables_t(const VolumeDesc& vd, unsigned int* ab, unsigned long long* tz, hipStream_t stream)
+{
+  const int n = std::max(std::max(vd.nx, vd.ny), vd.nz) + 1;
+  hipLaunchKernelGGL(axis_tables_kernel<VT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, vd, ab, tz);
+  return hipGetLastError();
+}
+hipError_t launch_axis_tables(VolumeDesc& vd, void* d_tables, hipStream_t stream)
+{
+  unsigned long long* tz = static_cast<unsigned long long*>(d_tables);
+  unsigned int* ab = reinterpret_cast<unsigned int*>(tz + vd.nz + 1);
+  vd.axis_z = tz;
+  vd.axis_ab = ab;
+  switch (vd.type) {
+  case VOX_U8: return axis_tables_t<VOX_U8>(vd, ab, tz, stream);
+  case VOX_I8: return axis_tables_t<VOX_I8>(vd, ab, tz, stream);
+  case VOX_U16: return axis_tables_t<VOX_U16>(vd, ab, tz, stream);
+  case VOX_I16: return axis_tables_t<VOX_I16>(vd, ab, tz, stream);
+  case VOX_F32: return axis_tables_t<VOX_F32>(vd, ab, tz, stream);
+  case VOX_F32_T: return axis_tables_t<VOX_F32_T>(vd, ab, tz, stream);
+  case VOX_F32_TT: return axis_tables_t<VOX_F32_TT>(vd, ab, tz, stream);
+  case VOX_U16_T: return axis_tables_t<VOX_U16_T>(vd, ab, tz, stream);
+  case VOX_U16_TT: return axis_tables_t<VOX_U16_TT>(vd, ab, tz, stream);
+  default: return hipErrorInvalidValue;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // macrocells (reference ovr/devices/optix7/accel/sp_singlemc.cu): 16^3-voxel cells with a value range and, per transfer
 // function, the largest opacity any sample inside can get.  The reference builds both grids but only its path tracer uses
