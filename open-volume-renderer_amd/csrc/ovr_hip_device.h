@@ -844,7 +844,7 @@ struct LdsRegion { int bx0, by0, bz0, ebx, eby, ebz, nbr, ok; };
 // DEEP = true (plain pooled march only): 6 instead of 4 instructions (x 4 steps) per round - 24 pair loads in flight per lane at 2
 // waves per SIMD (198 VGPRs) instead of 16 at 3.  On a full frame the two are within 1 % of each other (and 4 is better with dense
 // transfer functions and on axis views), but a ray's chain of dependent rounds is the floor of an image SHARD's march, and there 6
-// wins: 8-way shard of C3 0.295 -> 0.250 ms, 4-way 0.451 -> 0.423 (profiles/r02_notes.md).  launch_vsbs picks it when world > 1.
+// wins: 8-way shard of C3 0.295 -> 0.250 ms, 4-way 0.451 -> 0.423 (profiles/r02_notes.md).  launch_vsbs picks it for small shards (use_deep_rounds).
 constexpr int kDeepK = 6;
 template <int VT, int SHADE, int AM, bool POOLED, bool SKIP, bool LDSB = false, bool DEEP = false>
 #ifndef OVR_PIN_AM
@@ -1508,6 +1508,21 @@ inline hipError_t set_lds(KernT kern, size_t lds)
 
 constexpr int kShadeBlocks = 1024; // persistent shade grid: 4 workgroups per CU
 
+// The deep variant of the pooled march (6 instead of 4 instructions per round, 2 instead of 3 waves per SIMD) pays when the launch is
+// bound by its longest ray's chain of dependent rounds rather than by throughput: image shards with few blocks.  Measured
+// (profiles/r02_ab/r02b_deep.txt, march ms plain -> deep): C3 4-way 0.443 -> 0.422, 8-way 0.288 -> 0.254, 2-way (16 200 blocks) equal;
+// but C5 (4K: 16 200 blocks even 8-way, throughput-bound) 0.508 -> 0.607 and C4 8-way (64-bit addressing) 0.604 -> 0.632: so only
+// shards of at most 10 000 blocks with 32-bit addressing take it.  OVR_HIP_DEEP=0|1 overrides the choice (measurements).
+#ifndef OVR_DEEP_MAX_BLOCKS
+#define OVR_DEEP_MAX_BLOCKS 10000
+#endif
+inline bool use_deep_rounds(const RayMarchParams& p)
+{
+  static const int forced = getenv("OVR_HIP_DEEP") ? atoi(getenv("OVR_HIP_DEEP")) : -1;
+  if (forced >= 0) return forced != 0;
+  return p.world > 1 && !p.sparse_xy && p.n_schedule <= (unsigned int)OVR_DEEP_MAX_BLOCKS;
+}
+
 template <int VT, int SHADE, int AM, bool SKIP>
 inline hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const hipEvent_t* ev)
 {
@@ -1556,8 +1571,8 @@ inline hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
       constexpr int SH = SHADE == 0 ? 1 : SHADE; // (never instantiated for SHADE == 0: pooled is false)
       const size_t lds = (size_t)kWaves * QCfg<SH, true>::QCAP * sizeof(ShadeReq) + table_lds_bytes(p, AM) + (size_t)p.n_alpha * sizeof(float) + 64;
       bool launched = false;
-      if constexpr (!SKIP) {
-        if (p.world > 1) { // an image shard: fewer rays, the longest ray's chain of rounds is the floor - deeper rounds
+      if constexpr (!SKIP && AM <= 1) {
+        if (use_deep_rounds(p)) { // a small image shard: the longest ray's chain of rounds is the floor - deeper rounds
           auto kern = raymarch_kernel<VT, SH, AM, true, SKIP, false, true>;
           if ((e = set_lds(kern, lds)) != hipSuccess) return e;
           if (grid.x > 0) hipLaunchKernelGGL(kern, grid, block, lds, stream, q);

@@ -1,14 +1,28 @@
 """Per-rank render time of an image-sharded frame, all 'ranks' run one after the other on ONE card: how well does the
-tile -> rank assignment balance the work?  usage: python tools/shard_balance.py [n] [tile ...]"""
+tile -> rank assignment balance the work?  usage: python tools/shard_balance.py [n] [tile ...]
+OVR_SHARD_CONFIG=c4 | c5 rehearses BASELINE's 8-GPU configurations (2048^3 u16 at 1920x1080; 1024^3 f32 at 3840x2160 with the
+blue-noise pixel jitter) instead of C3."""
+import os
 import sys
 sys.path[:0] = ['/root/repo', '/root/repo/tests']
 import numpy as np, torch, ovr_amd as ovr
 from test_full_size_gpu import _setup
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+_cfg = os.environ.get('OVR_SHARD_CONFIG', 'c3')
+n = int(sys.argv[1]) if len(sys.argv) > 1 else (2048 if _cfg == 'c4' else 1024)
 tiles = [int(a) for a in sys.argv[2:]] or [64, 32, 16]
-size = (1920, 1080)
-vol = ovr.synth.make_volume_torch(n, torch.device('cuda', 0), 'float32')
+size = (3840, 2160) if _cfg == 'c5' else (1920, 1080)
+_dt = 'uint16' if _cfg == 'c4' else 'float32'
+_np_dt = np.uint16 if _cfg == 'c4' else np.float32
+vol = ovr.synth.make_volume_torch(n, torch.device('cuda', 0), _dt)
+_setup0 = _setup
+
+
+def _setup(ovr_, ren, vol_, n_, size_, shading, **kw):
+    if _cfg == 'c5':  # blue-noise pixel jitter, one sample per pixel and frame (bench.py's c5)
+        ren.set_noise_tile(ovr.synth.make_noise_tile(64))
+        ren.set_pixel_jitter(ovr.JITTER_BLUE_NOISE)
+    return _setup0(ovr_, ren, vol_, n_, size_, shading, dtype=_np_dt, **kw)
 
 
 def kernel_ms(ren, frames=6):
@@ -22,7 +36,8 @@ def kernel_ms(ren, frames=6):
 full = _setup(ovr, ovr.create_renderer('hip'), vol, n, size, 2, accumulate=True)
 t_full = kernel_ms(full)
 print(f'unsharded: {t_full:.3f} ms')
-for world in (2, 4, 8):
+full.close()
+for world in (() if os.environ.get('OVR_SHARD_PHASES_ONLY') == '1' else (2, 4, 8)):
     for tile in tiles:
         ms, work = [], []
         ren = ovr.create_renderer('hip')
