@@ -126,6 +126,7 @@ struct ovr_hip_renderer {
   float* d_mc_minmax = nullptr;
   float* d_mc_majorant = nullptr;
   unsigned char* d_mc_occupancy = nullptr; // coarse, dilated occupancy (skip intervals of the march)
+  unsigned char* d_mc_fine = nullptr;      // per-macrocell dilated occupancy (the primary rays' refinement of those intervals)
   size_t mc_cells = 0;
   bool mc_ranges_valid = false, mc_majorant_valid = false;
   float data_lower = 0.f, data_upper = 0.f; // the volume's data range as the voxel read returns it (array.cpp:297)
@@ -428,12 +429,15 @@ int update_macrocell_ranges(ovr_hip_renderer* r, hipStream_t st)
     if (r->d_mc_minmax) HIP_TRY(hipFree(r->d_mc_minmax));
     if (r->d_mc_majorant) HIP_TRY(hipFree(r->d_mc_majorant));
     if (r->d_mc_occupancy) HIP_TRY(hipFree(r->d_mc_occupancy));
+    if (r->d_mc_fine) HIP_TRY(hipFree(r->d_mc_fine));
+    r->d_mc_fine = nullptr;
     r->d_mc_minmax = r->d_mc_majorant = nullptr;
     r->d_mc_occupancy = nullptr;
     r->mc_cells = 0;
     HIP_TRY(hipMalloc((void**)&r->d_mc_minmax, cells * 2 * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&r->d_mc_majorant, cells * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&r->d_mc_occupancy, cells));
+    HIP_TRY(hipMalloc((void**)&r->d_mc_fine, cells));
     r->mc_cells = cells;
     r->mc_ranges_valid = r->mc_majorant_valid = false;
   }
@@ -455,7 +459,7 @@ int update_macrocells(ovr_hip_renderer* r, hipStream_t st)
   if (!r->mc_majorant_valid) {
     // tfn.value_range / range_rcp_norm of the reference (volume.cpp:147-153) - the TF range, normalised like the data
     HIP_TRY(launch_macrocell_majorants(r->d_mc_minmax, (unsigned int)cells, r->d_tf_alpha, r->n_alpha, r->P.tf_lower, r->P.tf_upper, r->d_mc_majorant, st));
-    HIP_TRY(launch_macrocell_coarse(r->d_mc_majorant, r->vd.nx, r->vd.ny, r->vd.nz, r->d_mc_occupancy, st));
+    HIP_TRY(launch_macrocell_coarse(r->d_mc_majorant, r->vd.nx, r->vd.ny, r->vd.nz, r->d_mc_occupancy, r->d_mc_fine, st));
     r->mc_majorant_valid = true;
   }
   return 0;
@@ -594,10 +598,12 @@ int enqueue_frame(ovr_hip_renderer* r)
   P.counters = r->d_counters;
   P.majorant = nullptr;
   P.occupancy = nullptr;
+  P.occupancy_fine = nullptr;
   if (r->skipping.current) {
     if (int e = update_macrocells(r, st)) return e;
     P.majorant = r->d_mc_majorant;
     P.occupancy = r->d_mc_occupancy;
+    P.occupancy_fine = r->d_mc_fine;
   }
   P.block_counters = r->d_block_counters;
   P.trace = r->d_trace;
@@ -789,6 +795,7 @@ void ovr_hip_destroy(ovr_hip_renderer* r)
   if (r->d_mc_minmax) (void)hipFree(r->d_mc_minmax);
   if (r->d_mc_majorant) (void)hipFree(r->d_mc_majorant);
   if (r->d_mc_occupancy) (void)hipFree(r->d_mc_occupancy);
+  if (r->d_mc_fine) (void)hipFree(r->d_mc_fine);
   if (r->d_counters) (void)hipFree(r->d_counters);
   if (r->d_sparse_count) (void)hipFree(r->d_sparse_count);
   if (r->d_data_range) (void)hipFree(r->d_data_range);

@@ -170,6 +170,7 @@ struct VolConsts {
   int nx1, ny1, nz1; // n - 1
   const float* majorant; // per-macrocell max TF opacity (null: empty-space skipping off)
   const unsigned char* occupancy; // per 4^3 macrocells: 1 if one of them, or a macrocell next to them, has majorant > 0
+  const unsigned char* occupancy_fine; // the same per macrocell
   int mcx1, mcy1, mcz1;  // macrocell grid dims - 1
   unsigned int macro_y;          // stored elements between macro rows: MV * macros_x
   unsigned long long macro_z;    // stored elements between macro layers: MV * macros_x * macros_y
@@ -386,16 +387,19 @@ __device__ __forceinline__ f3 to_object(const MarchConsts& mc, f3 p)
 }
 
 // Empty-space skipping, per ray: the t interval outside of which every sample lies in a macrocell with majorant 0.
-// skip_walk: one lane walks the ray's [ta, tb] through the coarse occupancy grid (3-D DDA; accel/dda.h is the reference's
-// walker for its path tracer) and widens [first, last] by the entry / exit of every set entry it crosses.
+// skip_walk: one lane walks the ray's [ta, tb] through an occupancy grid (3-D DDA; accel/dda.h is the reference's walker for
+// its path tracer) and widens [first, last] by the entry / exit of every set entry it crosses.  FINE = false: the coarse grid
+// (4^3 macrocells = 64 voxels per entry), FINE = true: one entry per macrocell (16 voxels); both are dilated by one macrocell.
 // Sample coordinates: x = p * cs + cb (tap_coords), macrocell = (floor(x) + 1) >> 4 (tap_cell), i.e. the regular 16-voxel
-// grid in w = x + 1; a coarse entry is 64 voxels of w.
+// grid in w = x + 1.
+template <bool FINE>
 __device__ __forceinline__ void skip_walk(const VolConsts& vc, f3 oo, f3 od, float ta, float tb, float& first, float& last)
 {
   const float w0[3] = { fmaf(oo.x, vc.cs.x, vc.cb.x + 1.f), fmaf(oo.y, vc.cs.y, vc.cb.y + 1.f), fmaf(oo.z, vc.cs.z, vc.cb.z + 1.f) };
   const float dw[3] = { od.x * vc.cs.x, od.y * vc.cs.y, od.z * vc.cs.z };
-  const int m1[3] = { vc.mcx1 >> 2, vc.mcy1 >> 2, vc.mcz1 >> 2 }; // coarse grid dims - 1
-  constexpr float G = 64.f;
+  const int m1[3] = { FINE ? vc.mcx1 : vc.mcx1 >> 2, FINE ? vc.mcy1 : vc.mcy1 >> 2, FINE ? vc.mcz1 : vc.mcz1 >> 2 }; // grid dims - 1
+  const unsigned char* grid = FINE ? vc.occupancy_fine : vc.occupancy;
+  constexpr float G = FINE ? 16.f : 64.f;
   int ci[3], st[3];
   float tmax[3], tdel[3];
 #pragma unroll
@@ -410,7 +414,7 @@ __device__ __forceinline__ void skip_walk(const VolConsts& vc, f3 oo, f3 od, flo
   float t = ta;
   const int limit = m1[0] + m1[1] + m1[2] + 8; // a ray crosses at most this many entries: every lane leaves the loop
   for (int it = 0; it < limit && t < tb; ++it) {
-    const bool occ = vc.occupancy[(size_t)ci[0] + (size_t)(m1[0] + 1) * ((size_t)ci[1] + (size_t)(m1[1] + 1) * (size_t)ci[2])] != 0;
+    const bool occ = grid[(size_t)ci[0] + (size_t)(m1[0] + 1) * ((size_t)ci[1] + (size_t)(m1[1] + 1) * (size_t)ci[2])] != 0;
     const int ax = (tmax[0] <= tmax[1]) ? (tmax[0] <= tmax[2] ? 0 : 2) : (tmax[1] <= tmax[2] ? 1 : 2);
     const float tn = ax == 0 ? tmax[0] : ax == 1 ? tmax[1] : tmax[2];
     if (occ) { first = fminf(first, t); last = fmaxf(last, fminf(tn, tb)); }
@@ -442,7 +446,7 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
   bool live = true;
   // empty-space skipping: the shadow ray's own skip interval (a handful of coarse entries: the ray is a few hundred voxels)
   float skip_first = FLT_MAX, skip_last = -FLT_MAX;
-  if (SKIP) skip_walk(vc, oo, od, t0, t1, skip_first, skip_last);
+  if (SKIP) skip_walk<false>(vc, oo, od, t0, t1, skip_first, skip_last);
   while (live) {
     Tap taps[KS];
     float dts[KS], mj[KS];
@@ -564,6 +568,7 @@ __device__ __forceinline__ void setup_consts(const RayMarchParams& P, VolConsts&
   vc.vscale = P.vol.value_scale; vc.vmin = P.vol.value_min_clamp;
   vc.majorant = P.majorant;
   vc.occupancy = P.occupancy;
+  vc.occupancy_fine = P.occupancy_fine;
   vc.mcx1 = (P.vol.nx + 15) / 16 - 1; vc.mcy1 = (P.vol.ny + 15) / 16 - 1; vc.mcz1 = (P.vol.nz + 15) / 16 - 1;
   mc.inv_scale = ld3(P.inv_scale); mc.wto_p = ld3(P.wto_p); mc.otw_it = ld3(P.otw_it); mc.light = ld3(P.light);
   mc.gstep = ld3(P.grad_step);
@@ -807,17 +812,32 @@ __device__ __forceinline__ bool assign_pixel_quad(const RayMarchParams& P, int l
   return active;
 }
 
-// the primary rays' form: the 4 lanes of the quad each walk a quarter of [t0, t1]; min / max over the quad
-__device__ __forceinline__ void skip_interval(const VolConsts& vc, f3 oo, f3 od, float t0, float t1, int sub, bool live, float& t_first, float& t_last)
+// the primary rays' form: the 4 lanes of the quad each walk a quarter of [t0, t1]; min / max over the quad.  Two levels: the
+// coarse grid over the whole ray, then - only inside the coarse interval - the per-macrocell grid: a primary ray is long (its
+// coarse interval is up to 80 voxels too wide at either end, and a ray that only grazes the dilated coarse entries gets an
+// interval although it meets nothing), and every round inside the interval costs ~330 instead of ~45 instructions.
+#ifndef OVR_SKIP_FINE
+#define OVR_SKIP_FINE 1
+#endif
+template <bool FINE>
+__device__ __forceinline__ void skip_interval_level(const VolConsts& vc, f3 oo, f3 od, float t0, float t1, int sub, bool live, float& t_first, float& t_last)
 {
   float first = FLT_MAX, last = -FLT_MAX;
   if (live) {
     const float len = t1 - t0;
     const float ta = fmaf((float)sub * 0.25f, len, t0), tb = sub == 3 ? t1 : fmaf((float)(sub + 1) * 0.25f, len, t0);
-    skip_walk(vc, oo, od, ta, tb, first, last);
+    skip_walk<FINE>(vc, oo, od, ta, tb, first, last);
   }
   t_first = fminf(fminf(quad_bcast<0>(first), quad_bcast<1>(first)), fminf(quad_bcast<2>(first), quad_bcast<3>(first)));
   t_last = fmaxf(fmaxf(quad_bcast<0>(last), quad_bcast<1>(last)), fmaxf(quad_bcast<2>(last), quad_bcast<3>(last)));
+}
+__device__ __forceinline__ void skip_interval(const VolConsts& vc, f3 oo, f3 od, float t0, float t1, int sub, bool live, float& t_first, float& t_last)
+{
+  skip_interval_level<false>(vc, oo, od, t0, t1, sub, live, t_first, t_last);
+  if (OVR_SKIP_FINE) {
+    const float c0 = t_first, c1 = t_last; // quad-uniform
+    if (__ballot(live && c0 <= c1) != 0ull) skip_interval_level<true>(vc, oo, od, c0, c1, sub, live && c0 <= c1, t_first, t_last);
+  }
 }
 
 template <int SHADE, bool POOLED> struct QCfg {

@@ -125,6 +125,7 @@ struct RayMarchParams {
   unsigned long long* counters;
   const float* majorant;        // per-macrocell max TF opacity: empty-space skipping (null = off)
   const unsigned char* occupancy; // per 4^3 macrocells: majorant > 0 in one of them or next to them (set with majorant)
+  const unsigned char* occupancy_fine; // the same per macrocell (primary rays refine their skip interval with it)
   unsigned long long* trace;    // diagnostic (OVR_HIP_TRACE=1): 4 words per wave, null otherwise
   unsigned int* block_counters; // workspace: raymarch_grid_blocks() * 7 per-workgroup partial sums
   PoolDesc pool;
@@ -178,8 +179,8 @@ hipError_t launch_macrocell_majorants(const float* minmax, unsigned int count, c
 // (compute_scalar_range + cuda_scalar_range, array.cpp:27-66,92-108); out = 2 floats on the device
 hipError_t launch_minmax_reduce(const float* minmax, unsigned long long cells, float* out, hipStream_t stream);
 
-// coarse occupancy (one byte per 4^3 macrocells, dilated by one macrocell) for the march's per-ray skip intervals
-hipError_t launch_macrocell_coarse(const float* majorant, int nx, int ny, int nz, unsigned char* out, hipStream_t stream);
+// occupancy grids (one byte per 4^3 macrocells / per macrocell, both dilated by one macrocell) for the march's per-ray skip intervals
+hipError_t launch_macrocell_coarse(const float* majorant, int nx, int ny, int nz, unsigned char* out_coarse, unsigned char* out_fine, hipStream_t stream);
 
 // tile pack/unpack for the RCCL gather payload
 hipError_t launch_pack_tiles(const float* frame, float* dst, int width, int height, int tile_w, int tile_h, int rank, int world,

@@ -588,28 +588,30 @@ hipError_t launch_minmax_reduce(const float* minmax, unsigned long long cells, f
   return hipGetLastError();
 }
 
-// occupancy for the per-ray skip interval (skip_interval): a coarse grid of 4^3 macrocells (64^3 voxels) per entry - small
-// enough (4 KiB at 1024^3) to stay in L1 while every ray walks it.  An entry is set if any of its macrocells, or any macrocell
-// next to one of them (dilation by one macrocell), can hold a sample with opacity > 0.  The dilation is the safety margin of the
-// walk: a ray's cell sequence is right to ~1e-4 voxel of position, the nearest non-empty sample is >= 16 voxels inside a set entry.
-__global__ __launch_bounds__(256) void macrocell_coarse_kernel(const float* __restrict__ majorant, int mcx, int mcy, int mcz, unsigned char* __restrict__ out)
+// occupancy for the per-ray skip interval (skip_interval), two levels: a coarse grid of 4^3 macrocells (64^3 voxels) per entry -
+// small enough (4 KiB at 1024^3) to stay in L1 while every ray walks it - and a fine grid of one entry per macrocell, walked only
+// inside the coarse interval.  An entry is set if any of its macrocells, or any macrocell next to one of them (dilation by one
+// macrocell), can hold a sample with opacity > 0.  The dilation is the safety margin of the walk: a ray's cell sequence is right
+// to ~1e-4 voxel of position, the nearest non-empty sample is >= 16 voxels inside a set entry.   S = macrocells per entry and axis
+__global__ __launch_bounds__(256) void macrocell_coarse_kernel(const float* __restrict__ majorant, int mcx, int mcy, int mcz, int S, unsigned char* __restrict__ out)
 {
-  const int gx = (mcx + 3) / 4, gy = (mcy + 3) / 4, gz = (mcz + 3) / 4;
+  const int gx = (mcx + S - 1) / S, gy = (mcy + S - 1) / S, gz = (mcz + S - 1) / S;
   const unsigned int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= (unsigned int)(gx * gy * gz)) return;
-  const int cx = (int)(i % (unsigned int)gx) * 4, cy = (int)((i / (unsigned int)gx) % (unsigned int)gy) * 4, cz = (int)(i / (unsigned int)(gx * gy)) * 4;
+  const int cx = (int)(i % (unsigned int)gx) * S, cy = (int)((i / (unsigned int)gx) % (unsigned int)gy) * S, cz = (int)(i / (unsigned int)(gx * gy)) * S;
   bool any = false;
-  for (int z = max(cz - 1, 0); z <= min(cz + 4, mcz - 1); ++z)
-    for (int y = max(cy - 1, 0); y <= min(cy + 4, mcy - 1); ++y)
-      for (int x = max(cx - 1, 0); x <= min(cx + 4, mcx - 1); ++x)
+  for (int z = max(cz - 1, 0); z <= min(cz + S, mcz - 1); ++z)
+    for (int y = max(cy - 1, 0); y <= min(cy + S, mcy - 1); ++y)
+      for (int x = max(cx - 1, 0); x <= min(cx + S, mcx - 1); ++x)
         any = any || (majorant[(size_t)x + (size_t)mcx * ((size_t)y + (size_t)mcy * (size_t)z)] > 0.f);
   out[i] = any ? 1 : 0;
 }
-hipError_t launch_macrocell_coarse(const float* majorant, int nx, int ny, int nz, unsigned char* out, hipStream_t stream)
+hipError_t launch_macrocell_coarse(const float* majorant, int nx, int ny, int nz, unsigned char* out_coarse, unsigned char* out_fine, hipStream_t stream)
 {
   const int mcx = (nx + 15) / 16, mcy = (ny + 15) / 16, mcz = (nz + 15) / 16;
-  const unsigned int cells = (unsigned int)(((mcx + 3) / 4) * ((mcy + 3) / 4) * ((mcz + 3) / 4));
-  hipLaunchKernelGGL(macrocell_coarse_kernel, dim3((cells + 255) / 256), dim3(256), 0, stream, majorant, mcx, mcy, mcz, out);
+  const unsigned int coarse = (unsigned int)(((mcx + 3) / 4) * ((mcy + 3) / 4) * ((mcz + 3) / 4)), fine = (unsigned int)(mcx * mcy * mcz);
+  hipLaunchKernelGGL(macrocell_coarse_kernel, dim3((coarse + 255) / 256), dim3(256), 0, stream, majorant, mcx, mcy, mcz, 4, out_coarse);
+  hipLaunchKernelGGL(macrocell_coarse_kernel, dim3((fine + 255) / 256), dim3(256), 0, stream, majorant, mcx, mcy, mcz, 1, out_fine);
   return hipGetLastError();
 }
 
