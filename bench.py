@@ -418,17 +418,26 @@ def worker(args, world):
         ren.commit()
 
     # the other settings SURVEY 8d wants beside the headline (N = 1): the frame without the shadow march, at the scene files' fovy
-    # of 45 degrees (renderbatch renders 60: renderer.h:149-152), and at the scene files' sampling rate 4 (sampleDistance 0.25)
+    # of 45 degrees (renderbatch renders 60: renderer.h:149-152), at the scene files' sampling rate 4 (sampleDistance 0.25), and the
+    # sparse (foveated) sampling mode of SURVEY 8 f3
     variants = None
     if views is not None:
         variants = {}
-        for vname, vkw in (("no_shadow_march", dict(shading=1)), ("fovy_45", dict(fovy=45.0)), ("sampling_rate_4", dict(rate=4.0))):
+        for vname, vkw in (("no_shadow_march", dict(shading=1)), ("fovy_45", dict(fovy=45.0)), ("sampling_rate_4", dict(rate=4.0)),
+                           ("sparse_sampling", dict(sparse=True))):
             if "shading" in vkw and cfg["shading"] != 2:
                 continue
-            vc = dict(cfg, **{k: v for k, v in vkw.items() if k != "fovy"})
+            vc = dict(cfg, **{k: v for k, v in vkw.items() if k in cfg})
             ren.set_shading(vc["shading"])
             ren.set_volume_sampling_rate(vc["rate"])
             ren.set_camera(ovr.Camera(*cam, fovy=vkw.get("fovy", 60.0)))
+            if vkw.get("sparse"):
+                # the foveated mode of the interactive app with its default focus (apps/main_app.cpp:123-124,184): mask from the
+                # noise tile (generate_mask.cu:55-120), ballot / prefix compaction, sparse launch
+                if noise is None:
+                    ren.set_noise_tile(ovr.synth.make_noise_tile(64))
+                ren.set_focus((0.5, 0.5), 0.06, 0.07)
+                ren.set_sparse_sampling(True)
             ren.commit()
             vsteps = 5 if vname == "sampling_rate_4" else 10
             leg = timed_leg(vsteps, 3)
@@ -438,9 +447,12 @@ def worker(args, world):
             variants[vname] = {
                 "ms_per_step": leg["dt"] / vsteps * 1e3, "fps": vsteps / leg["dt"], "gsamples_per_s": leg["tot"]["samples"] / leg["dt"] / 1e9,
                 "samples_per_frame": pl["samples"], "shaded_samples_per_frame": pl["shaded_samples"], "shadow_samples_per_frame": pl["shadow_samples"],
+                "rendered_pixels_per_frame": pl["active_pixels"],
                 "phase_ms": {"march": ph[0], "shade": ph[1], "composite": ph[2]},
                 "kernel": dom, "frac": kern[dom]["frac"] if dom else None,
                 "pipeline_frac": abytes / (leg["kernel_ms"] / vsteps * 1e-3) / 1e9 / HBM_PEAK_GBS if leg["kernel_ms"] > 0 else None}
+            if vkw.get("sparse"):
+                ren.set_sparse_sampling(False)
         ren.set_shading(cfg["shading"])
         ren.set_volume_sampling_rate(cfg["rate"])
         ren.set_camera(*cam)

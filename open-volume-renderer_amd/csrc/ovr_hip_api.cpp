@@ -624,7 +624,9 @@ int enqueue_frame(ovr_hip_renderer* r)
   if (sparse) { // createSparseSamples, device_impl.cpp:304-342
     if (!r->d_noise) return fail(OVR_HIP_ESTATE, "[hip] sparse sampling enabled but no noise tile was set (ovr_hip_set_noise_tile)");
     if (int e = ensure_sparse_buffers(r)) return e;
-    HIP_TRY(launch_sparse_mask(make_mask_params(r, r->frame_index, r->d_sparse_xy), st));
+    SparseMaskParams mp = make_mask_params(r, r->frame_index, r->d_sparse_xy);
+    mp.tile_major = 1; // the frame's own list: 4x4-pixel blocks per wave where the mask is dense (the kept pixels are the same)
+    HIP_TRY(launch_sparse_mask(mp, st));
     P.sparse_xy = r->d_sparse_xy;
     P.sparse_count = r->d_sparse_count;
   }

@@ -162,8 +162,13 @@ struct SparseMaskParams {
   int width, height, frame_index;
   float mean_x, mean_y, sigma_rcp2, base_noise;
   int32_t* out_xy;
-  unsigned int* block_counts;   // workspace: ceil(W*H/256) + 1
+  unsigned int* block_counts;   // workspace: sparse_mask_workspace_elems()
   unsigned long long* count;    // out: number of int32 written
+  // order of the compacted list.  0: row-major pixel order - what thrust::remove leaves in the reference (generate_mask.cu:100-120;
+  // ovr_hip_sparse_mask, the parity entry).  1: tile-major - 16x16-pixel tiles row by row, inside a tile its sixteen 4x4 sub-tiles
+  // one after the other: the frame path's order, so that the 16 rays of a wave are a 4x4 pixel block wherever the mask is dense
+  // (the same kept pixels, the same frame: pixels are independent)
+  int tile_major;
 };
 size_t sparse_mask_workspace_elems(int width, int height);
 hipError_t launch_sparse_mask(const SparseMaskParams& p, hipStream_t stream);

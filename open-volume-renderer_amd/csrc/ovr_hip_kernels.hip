@@ -653,13 +653,32 @@ __device__ __forceinline__ void stage_noise_rows(const SparseMaskParams& p, floa
   __syncthreads();
 }
 
+// enumeration index -> pixel.  Row-major: i = x + y * W.  Tile-major (p.tile_major): 256 consecutive indices are one 16x16-pixel tile,
+// 16 consecutive indices one of its 4x4 sub-tiles (row-major inside both levels); pixels beyond the image edge are never kept
+__device__ __forceinline__ bool mask_pixel(const SparseMaskParams& p, unsigned int i, int& x, int& y)
+{
+  if (!p.tile_major) {
+    x = (int)(i % (unsigned int)p.width);
+    y = (int)(i / (unsigned int)p.width);
+    return i < (unsigned int)p.width * (unsigned int)p.height;
+  }
+  const unsigned int tiles_x = ((unsigned int)p.width + 15u) / 16u;
+  const unsigned int tile = i >> 8, in = i & 255u, st = in >> 4, px = in & 15u;
+  x = (int)((tile % tiles_x) * 16u + (st & 3u) * 4u + (px & 3u));
+  y = (int)((tile / tiles_x) * 16u + (st >> 2) * 4u + (px >> 2));
+  return x < p.width && y < p.height;
+}
+
 __device__ __forceinline__ bool mask_keep(const SparseMaskParams& p, const float* lds_noise, unsigned int first_pixel, unsigned int i, int& x, int& y)
 {
-  x = (int)(i % (unsigned int)p.width);
-  y = (int)(i / (unsigned int)p.width);
+  if (!mask_pixel(p, i, x, y)) return false;
   const int xy = p.noise_xy;
-  const int r = y - (int)(first_pixel / (unsigned int)p.width); // 0 or 1 (a third row only if width < 128: read the slice directly)
-  const float val = r < 2 ? lds_noise[r * xy + (x % xy)] : p.noise[(size_t)(p.frame_index % 64) * xy * xy + (size_t)(y % xy) * xy + (x % xy)];
+  float val;
+  if (p.tile_major) val = p.noise[(size_t)(p.frame_index % 64) * xy * xy + (size_t)(y % xy) * xy + (x % xy)]; // a 16x16 patch of the slice: cached
+  else {
+    const int r = y - (int)(first_pixel / (unsigned int)p.width); // 0 or 1 (a third row only if width < 128: read the slice directly)
+    val = r < 2 ? lds_noise[r * xy + (x % xy)] : p.noise[(size_t)(p.frame_index % 64) * xy * xy + (size_t)(y % xy) * xy + (x % xy)];
+  }
   const float aspect = (float)p.width / p.height;
   const float fx = ((float)x / p.width - p.mean_x);
   const float fy = ((float)y / p.height - p.mean_y) / aspect;
@@ -671,11 +690,10 @@ __global__ __launch_bounds__(256) void mask_count_kernel(const SparseMaskParams 
 {
   __shared__ unsigned int wave_cnt[4];
   __shared__ float lds_noise[2 * 128];
-  const unsigned int n = (unsigned int)p.width * (unsigned int)p.height;
   const unsigned int i = blockIdx.x * 256 + threadIdx.x;
-  stage_noise_rows(p, lds_noise, blockIdx.x * 256);
+  if (!p.tile_major) stage_noise_rows(p, lds_noise, blockIdx.x * 256);
   int x, y;
-  const bool keep = (i < n) && mask_keep(p, lds_noise, blockIdx.x * 256, i, x, y);
+  const bool keep = mask_keep(p, lds_noise, blockIdx.x * 256, i, x, y);
   const unsigned long long b = __ballot(keep);
   if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = (unsigned int)__popcll(b);
   __syncthreads();
@@ -716,11 +734,10 @@ __global__ __launch_bounds__(256) void mask_write_kernel(const SparseMaskParams 
 {
   __shared__ unsigned int wave_cnt[4];
   __shared__ float lds_noise[2 * 128];
-  const unsigned int n = (unsigned int)p.width * (unsigned int)p.height;
   const unsigned int i = blockIdx.x * 256 + threadIdx.x;
-  stage_noise_rows(p, lds_noise, blockIdx.x * 256);
+  if (!p.tile_major) stage_noise_rows(p, lds_noise, blockIdx.x * 256);
   int x = 0, y = 0;
-  const bool keep = (i < n) && mask_keep(p, lds_noise, blockIdx.x * 256, i, x, y);
+  const bool keep = mask_keep(p, lds_noise, blockIdx.x * 256, i, x, y);
   const unsigned long long b = __ballot(keep);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // prefix of the ballot below this lane = v_mbcnt
@@ -736,11 +753,17 @@ __global__ __launch_bounds__(256) void mask_write_kernel(const SparseMaskParams 
   }
 }
 
-size_t sparse_mask_workspace_elems(int width, int height) { return ((size_t)width * height + 255) / 256 + 1; }
+static int mask_blocks(const SparseMaskParams& p)
+{
+  if (p.tile_major) return ((p.width + 15) / 16) * ((p.height + 15) / 16);
+  return (int)(((size_t)p.width * p.height + 255) / 256);
+}
+// per-block counts of either enumeration order (+ 1): the tile-major order has at least as many blocks as the row-major one
+size_t sparse_mask_workspace_elems(int width, int height) { return (size_t)((width + 15) / 16) * ((height + 15) / 16) + ((size_t)width * height + 255) / 256 + 1; }
 
 hipError_t launch_sparse_mask(const SparseMaskParams& p, hipStream_t stream)
 {
-  const int n_blocks = (int)(((size_t)p.width * p.height + 255) / 256);
+  const int n_blocks = mask_blocks(p);
   hipLaunchKernelGGL(mask_count_kernel, dim3(n_blocks), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(mask_scan_kernel, dim3(1), dim3(1024), 0, stream, p.block_counts, n_blocks, p.count);
   hipLaunchKernelGGL(mask_write_kernel, dim3(n_blocks), dim3(256), 0, stream, p);
