@@ -108,3 +108,19 @@ def test_plugin_sparse_spp_swap_through_the_reference_interface(tmp_path, ovr, h
     assert 0.02 < (sparse[..., 3] > 0).mean() < 0.9
     assert np.abs(got[0] - sparse).max() <= 2e-5
     assert np.abs(got[1] - dense).max() <= 2e-5 and (dense[..., 3] > 0).mean() > 0.03
+
+
+def test_c3_through_the_unmodified_reference_app():
+    """BASELINE C3 measured by the reference's own harness: `renderbatch --device hip --fbsize 1920,1080` on a scene JSON holding the
+    bench's 1024^3 f32 volume (tools/renderbatch_c3.py), once with the plugin's empty-space skipping off and once with its default
+    (on).  Both runs print the app's `fps =` line and write byte-identical PNGs."""
+    import re
+    import sys
+    if not (os.path.exists(RENDERBATCH) and os.path.exists(PLUGIN)):
+        pytest.skip("oracle/_ref/renderbatch or plugin/libdevice_hip.so missing (built by __graft_entry__.build() where the reference tree is present)")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "renderbatch_c3.py"), "1024", "1920,1080", "float32"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    fps = [float(m) for m in re.findall(r"fps = ([0-9.]+)", out.stdout)]
+    assert len(fps) == 2 and min(fps) > 50.0, out.stdout[-2000:]
+    assert "byte-identical" in out.stdout and "NOT identical" not in out.stdout
