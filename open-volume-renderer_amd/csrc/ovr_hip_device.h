@@ -1458,7 +1458,10 @@ __global__ __launch_bounds__(kBlock) void shade_pool_kernel(const RayMarchParams
   // (run r, chunk `wave`): consecutive depth steps of ONE tile, whose gradient and shadow taps fall into the same bricks.
   // The cap follows the frame: 1 run per ticket up to 32 runs per workgroup (sparse transfer functions: 36 k runs per C3 frame -
   // there batches only cost balance, measured +3 ... 13 %), up to kTicketRuns beyond (dense: 174 k runs, shade 2.11 -> 1.13 ms)
-  const unsigned int ticket_cap = min((unsigned int)kTicketRuns, max(1u, total_runs / (32u * gridDim.x)));
+  // Without the shadow march (SHADE == 1) a run is three gradient taps per request - so cheap that even 36 k single-run tickets ARE the
+  // kernel's time (0.45 ms on C3: ~16 ns per same-address atomic); there the cap is always kTicketRuns (shade 0.45 -> 0.20 ms, profiles/r02_notes.md §11)
+  // (with the shadow march the batches cost more in balance and locality than the tickets do - also in the skipping kernel: 0.668 -> 0.729 ms)
+  const unsigned int ticket_cap = SHADE == 1 ? (unsigned int)kTicketRuns : min((unsigned int)kTicketRuns, max(1u, total_runs / (32u * gridDim.x)));
   unsigned int seen = 0; // a lower bound of the global cursor: the end of this workgroup's last batch
   for (;;) {
     const unsigned int left = n_runs > seen ? n_runs - seen : 0u;
