@@ -498,7 +498,7 @@ int build_schedule_list(ovr_hip_renderer* r)
   r->n_sched = (unsigned int)list.size();
   if (!list.empty()) {
     HIP_TRY(hipMalloc((void**)&r->d_sched_src, list.size() * sizeof(unsigned int)));
-    HIP_TRY(hipMalloc((void**)&r->d_sched, list.size() * sizeof(unsigned int)));
+    HIP_TRY(hipMalloc((void**)&r->d_sched, (list.size() + schedule_workspace_elems((unsigned int)list.size())) * sizeof(unsigned int))); // + the sort's histograms
     HIP_TRY(hipMemcpy(r->d_sched_src, list.data(), list.size() * sizeof(unsigned int), hipMemcpyHostToDevice));
   }
   r->sched_list_dirty = false;
@@ -615,7 +615,7 @@ int enqueue_frame(ovr_hip_renderer* r)
     if (r->sched_list_dirty)
       if (int e = build_schedule_list(r)) return e;
     if (r->sched_dirty) {
-      HIP_TRY(launch_schedule(P, r->d_sched_src, r->n_sched, r->d_sched, st));
+      HIP_TRY(launch_schedule(P, r->d_sched_src, r->n_sched, r->d_sched, r->d_sched + r->n_sched, st));
       r->sched_dirty = false;
     }
     P.schedule = r->d_sched;

@@ -141,7 +141,9 @@ size_t raymarch_lds_bytes(int n_color, int n_alpha);
 // number of workgroups launch_raymarch will use (size of the block_counters workspace / 7)
 size_t raymarch_grid_blocks(const RayMarchParams& p);
 // sorts the n owned blocks of src (bx | by << 16, any order) by descending ray length into dst; uses p's camera and box
-hipError_t launch_schedule(const RayMarchParams& p, const unsigned int* src, unsigned int n, unsigned int* dst, hipStream_t stream);
+// (workspace: schedule_workspace_elems(n) words)
+size_t schedule_workspace_elems(unsigned int n);
+hipError_t launch_schedule(const RayMarchParams& p, const unsigned int* src, unsigned int n, unsigned int* dst, unsigned int* workspace, hipStream_t stream);
 
 // linear (x fastest) -> bricked layout; src may be any reference ValueType, dst is laid out as vd.type says (the VoxelType
 // chosen by device_voxel_type() or one of its replicas).  z0/nz_chunk allow chunked uploads from host staging.

@@ -161,73 +161,88 @@ __device__ __forceinline__ unsigned int schedule_class(const RayMarchParams& P, 
   return (unsigned int)min(kSchedClasses - 1, 1 + (int)(rel * (float)(kSchedClasses - 2)));
 }
 
-__global__ __launch_bounds__(1024) void schedule_kernel(const RayMarchParams P, const unsigned int* __restrict__ src, unsigned int n,
-                                                        unsigned int* __restrict__ dst)
+// Two launches of ceil(n / 1024) workgroups (a single workgroup needed 0.35 ms for the 32 400 blocks of a 1080p frame - on every
+// camera change, i.e. on every frame of an interactive session; now ~10 us):
+//   schedule_hist_kernel     class of every block, one histogram per workgroup: hist[wg][class]
+//   schedule_scatter_kernel  workgroup wg's blocks of class c start at (all blocks of longer classes) + (class-c blocks of the
+//                            workgroups before wg); inside the workgroup they keep their list order (stable: the host lists the
+//                            blocks supertile by supertile, 4x4 blocks = 32x32 pixels, so blocks that run at the same time are
+//                            compact squares of the image and share their bricks in L2 / Infinity Cache)
+// (Mapping the 16 blocks of a supertile to ONE XCD - workgroup s runs on XCD s % 8 - was measured slower: C3 march 1.63 vs 1.57 ms.)
+__global__ __launch_bounds__(1024) void schedule_hist_kernel(const RayMarchParams P, const unsigned int* __restrict__ src, unsigned int n,
+                                                             unsigned int* __restrict__ hist)
 {
-  __shared__ unsigned int count[kSchedClasses], cursor[kSchedClasses];
+  __shared__ unsigned int count[kSchedClasses];
   VolConsts vc;
   MarchConsts mc;
   setup_consts(P, vc, mc);
   if (threadIdx.x < kSchedClasses) count[threadIdx.x] = 0u;
   __syncthreads();
-  for (unsigned int i = threadIdx.x; i < n; i += 1024u) atomicAdd(&count[schedule_class(P, mc, src[i])], 1u);
+  const unsigned int i = blockIdx.x * 1024u + threadIdx.x;
+  if (i < n) atomicAdd(&count[schedule_class(P, mc, src[i])], 1u);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned int at = 0u;
-    for (int c = kSchedClasses - 1; c >= 0; --c) { cursor[c] = at; at += count[c]; }
-  }
-  __syncthreads();
-  // Stable scatter, 1024 entries at a time: inside a class the blocks keep their list order (the host lists them supertile
-  // by supertile, 4x4 blocks = 32x32 pixels), so blocks that run at the same time are compact squares of the image and
-  // share their bricks in L2 / Infinity Cache.
-  // OVR_SCHED_XCD=1 (experiment, off): transpose the final slot inside aligned groups of 128 so that the 16 blocks of a
-  // supertile land on ONE XCD (workgroup s -> XCD s % 8, each XCD has its own L2): sorted position g*128 + x*16 + j -> slot
-  // g*128 + j*8 + x.  Measured: C3 march 1.63 instead of 1.57 ms - the march is bound by L1 lookups, not by L2 misses.
-#ifndef OVR_SCHED_XCD
-#define OVR_SCHED_XCD 0
-#endif
-  __shared__ unsigned int wave_count[16][kSchedClasses];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned int n_full = n & ~127u; // the transposition is applied to whole groups only
-  for (unsigned int c0 = 0; c0 < n; c0 += 1024u) {
-    for (int k = threadIdx.x; k < 16 * kSchedClasses; k += 1024) (&wave_count[0][0])[k] = 0u;
-    __syncthreads();
-    const unsigned int i = c0 + threadIdx.x;
-    const bool valid = i < n;
-    const unsigned int e = valid ? src[i] : 0u;
-    const unsigned int cls = valid ? schedule_class(P, mc, e) : 0u;
-    // rank among the lanes of this wave with the same class (lower lanes first), wave totals to LDS
-    unsigned int rank = 0u;
-    unsigned long long todo = __ballot(valid);
-    while (todo != 0ull) {
-      const int leader = __builtin_ctzll(todo);
-      const unsigned int lc = (unsigned int)__builtin_amdgcn_readlane((int)cls, leader);
-      const unsigned long long same = __ballot(valid && cls == lc);
-      if (valid && cls == lc) rank = (unsigned int)__popcll(same & ((1ull << lane) - 1ull));
-      if (lane == leader) wave_count[wave][lc] = (unsigned int)__popcll(same);
-      todo &= ~same;
-    }
-    __syncthreads();
-    // exclusive prefix over the 16 waves, per class; the class cursor moves on by the chunk's total
-    if (threadIdx.x < kSchedClasses) {
-      unsigned int run = cursor[threadIdx.x];
-      for (int w = 0; w < 16; ++w) { const unsigned int t = wave_count[w][threadIdx.x]; wave_count[w][threadIdx.x] = run; run += t; }
-      cursor[threadIdx.x] = run;
-    }
-    __syncthreads();
-    if (valid) {
-      unsigned int pos = wave_count[wave][cls] + rank;
-      if (OVR_SCHED_XCD && pos < n_full) pos = (pos & ~127u) | ((pos & 15u) << 3) | ((pos >> 4) & 7u);
-      dst[pos] = e;
-    }
-    __syncthreads();
-  }
+  if (threadIdx.x < kSchedClasses) hist[blockIdx.x * kSchedClasses + threadIdx.x] = count[threadIdx.x];
 }
 
-hipError_t launch_schedule(const RayMarchParams& p, const unsigned int* src, unsigned int n, unsigned int* dst, hipStream_t stream)
+__global__ __launch_bounds__(1024) void schedule_scatter_kernel(const RayMarchParams P, const unsigned int* __restrict__ src, unsigned int n,
+                                                                const unsigned int* __restrict__ hist, unsigned int* __restrict__ dst)
+{
+  __shared__ unsigned int base[kSchedClasses], total[kSchedClasses];
+  __shared__ unsigned int wave_count[16][kSchedClasses];
+  VolConsts vc;
+  MarchConsts mc;
+  setup_consts(P, vc, mc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // per class: blocks in the workgroups before this one, and in all of them
+  if (threadIdx.x < kSchedClasses) {
+    unsigned int before = 0u, all = 0u;
+    for (unsigned int w = 0; w < gridDim.x; ++w) {
+      const unsigned int h = hist[w * kSchedClasses + threadIdx.x];
+      before += w < blockIdx.x ? h : 0u;
+      all += h;
+    }
+    base[threadIdx.x] = before;
+    total[threadIdx.x] = all;
+  }
+  for (int k = threadIdx.x; k < 16 * kSchedClasses; k += 1024) (&wave_count[0][0])[k] = 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) { // descending classes: the longest rays first
+    unsigned int at = 0u;
+    for (int c = kSchedClasses - 1; c >= 0; --c) { const unsigned int t = total[c]; base[c] += at; at += t; }
+  }
+  const unsigned int i = blockIdx.x * 1024u + threadIdx.x;
+  const bool valid = i < n;
+  const unsigned int e = valid ? src[i] : 0u;
+  const unsigned int cls = valid ? schedule_class(P, mc, e) : 0u;
+  // rank among the lanes of this wave with the same class (lower lanes first), wave totals to LDS
+  unsigned int rank = 0u;
+  unsigned long long todo = __ballot(valid);
+  while (todo != 0ull) {
+    const int leader = __builtin_ctzll(todo);
+    const unsigned int lc = (unsigned int)__builtin_amdgcn_readlane((int)cls, leader);
+    const unsigned long long same = __ballot(valid && cls == lc);
+    if (valid && cls == lc) rank = (unsigned int)__popcll(same & ((1ull << lane) - 1ull));
+    if (lane == leader) wave_count[wave][lc] = (unsigned int)__popcll(same);
+    todo &= ~same;
+  }
+  __syncthreads();
+  // exclusive prefix over the 16 waves, per class
+  if (threadIdx.x < kSchedClasses) {
+    unsigned int run = base[threadIdx.x];
+    for (int w = 0; w < 16; ++w) { const unsigned int t = wave_count[w][threadIdx.x]; wave_count[w][threadIdx.x] = run; run += t; }
+  }
+  __syncthreads();
+  if (valid) dst[wave_count[wave][cls] + rank] = e;
+}
+
+size_t schedule_workspace_elems(unsigned int n) { return (size_t)((n + 1023u) / 1024u) * kSchedClasses; }
+
+hipError_t launch_schedule(const RayMarchParams& p, const unsigned int* src, unsigned int n, unsigned int* dst, unsigned int* workspace, hipStream_t stream)
 {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, stream, p, src, n, dst);
+  const dim3 grid((n + 1023u) / 1024u);
+  hipLaunchKernelGGL(schedule_hist_kernel, grid, dim3(1024), 0, stream, p, src, n, workspace);
+  hipLaunchKernelGGL(schedule_scatter_kernel, grid, dim3(1024), 0, stream, p, src, n, workspace, dst);
   return hipGetLastError();
 }
 
