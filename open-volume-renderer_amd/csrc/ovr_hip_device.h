@@ -501,7 +501,7 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
 // the ray-march kernels
 //
 // Work decomposition: four lanes per ray (a quad = 4 consecutive steps), 16 rays = a 4x4 pixel tile per wave64, four waves
-// = 8x8 pixels per workgroup; workgroups are launched longest rays first (schedule_kernel).  Details at raymarch_kernel.
+// = 8x8 pixels per workgroup; workgroups are launched longest rays first (launch_schedule).  Details at raymarch_kernel.
 //  * primary march: K instructions x 4 steps per round, all their voxel loads in flight before the first is consumed.
 //  * deferred, compacted shading (SHADE != 0): a sample whose opacity is > 0 is not shaded by its own lane; the lane
 //    pushes a 32-byte request into its wave's queue in LDS (slot = tail + prefix-of-ballot, v_mbcnt) and keeps
@@ -790,7 +790,7 @@ __device__ __forceinline__ void jitter_global(const RayMarchParams& P, int ix, i
 
 // which pixel does this QUAD own?  (4x4 pixels per wave, 8x8 per workgroup; sparse mode: 64 list entries per workgroup)
 // Dense mode: workgroup s of the 1-D grid renders the 8x8 block P.schedule[s] = bx | by << 16 - the blocks this rank owns,
-// longest rays first (schedule_kernel) - compute_screen_position of the reference (shaders_common.h:394-451) is the
+// longest rays first (launch_schedule) - compute_screen_position of the reference (shaders_common.h:394-451) is the
 // identity on the launch index, which fixes neither an order nor a grouping.
 __device__ __forceinline__ bool assign_pixel_quad(const RayMarchParams& P, int lane, int wave, int& ix, int& iy)
 {

@@ -10,7 +10,7 @@
 //   sparse-sampling mask ......... ovr/common/generate_mask.cu:55-120, ovr/common/random/blue_noise.h:81-102
 //
 // Kernel shape: FOUR LANES PER RAY - the 4 lanes of a quad are 4 consecutive steps of one ray - so a wave64 marches 16 rays
-// (a 4x4-pixel tile) and a workgroup of four waves an 8x8-pixel block; workgroups run longest rays first (schedule_kernel).
+// (a 4x4-pixel tile) and a workgroup of four waves an 8x8-pixel block; workgroups run longest rays first (launch_schedule).
 // Shaded samples become 32-byte requests that a second, persistent kernel shades from a global pool and a third kernel
 // composites in ray order (pooled pipeline), or that the tile's own wave shades (in-place pipeline).  The transfer
 // function (colour float4 table + alpha table, 20 KiB at the shipped resolution of 1024), the per-axis brick-offset tables,
