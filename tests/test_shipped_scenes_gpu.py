@@ -1,0 +1,90 @@
+"""Parity on the reference's own scene files: for each of the 21 VIDI3D scenes the reference ships (tests/golden/scenes, data files
+copied from data/configs) the transfer function as the reference's loader rasterises it (pinned against the real loader in
+tests/test_scene_ingest.py), the scene's value range, voxel type, grid spacing, field of view, sampling rate and camera drive the HIP
+path and the CPU oracle on a synthetic volume of the scene's type and aspect (the scenes' raw volumes do not ship; the synthetic field is
+mapped into the scene's value range so that its transfer function meets data, and the camera is scaled with the grid)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import hip_frame, hip_setup, oracle_scene
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+SCENE_DIR = os.path.join(HERE, "golden", "scenes")
+SCENES = sorted(f for f in os.listdir(SCENE_DIR) if f.endswith(".json"))
+
+
+def scene_case(ovr, name, longest=36, size=(96, 64)):
+    d = ovr.vidi3d.read_scene(os.path.join(SCENE_DIR, name), load_volume=False)
+    dims = np.array(d["dims"], dtype=np.float64)
+    small = tuple(int(max(6, round(x * longest / dims.max()))) for x in dims)
+    v01 = ovr.synth.make_volume(max(small), np.float32, dims=small)          # (nz, ny, nx) in [0, 1]
+    lo, hi = d["value_range"]
+    dtype = np.dtype(d["dtype"])
+    if dtype.kind == "f":
+        if not (np.isfinite(lo) and np.isfinite(hi) and hi > lo):
+            lo, hi = 0.0, 1.0
+        vol = (np.float64(lo) + v01.astype(np.float64) * (np.float64(hi) - np.float64(lo))).astype(dtype)
+    else:
+        info = np.iinfo(dtype)
+        a, b = max(float(lo), float(info.min)), min(float(hi), float(info.max))
+        if not b > a:
+            a, b = float(info.min), float(info.max)
+        vol = np.clip(np.round(a + v01.astype(np.float64) * (b - a)), info.min, info.max).astype(dtype)
+    n = len(d["tfn_opacity"])
+    colors = np.ascontiguousarray(d["tfn_color"][:, :3], dtype=np.float32).ravel()
+    alphas = np.stack([np.linspace(0.0, 1.0, n, dtype=np.float32), d["tfn_opacity"].astype(np.float32)], axis=1).ravel()
+    eye, at, up, fovy = d["camera"]
+    f = np.array(small, dtype=np.float64) / dims                                  # the camera moves with the grid
+    eye, at = tuple(np.array(eye) * f), tuple(np.array(at) * f)
+    return dict(vol=vol, colors=colors, alphas=alphas, vr=(float(d["value_range"][0]), float(d["value_range"][1])), cam=(eye, at, up), size=size, shading=2,
+                rate=float(d["volume_sampling_rate"]), spp=1, convention=0, spacing=tuple(float(s) for s in d["grid_spacing"]),
+                origin=tuple(float(o) for o in d["grid_origin"]), fovy=float(fovy))
+
+
+def compare_visible(O, got, ref, name):
+    """The parity bar of tests/helpers.py::compare, applied to what a frame SHOWS.  The reference's output colour is un-premultiplied
+    (`color / alpha`, shaders_raymarching.cu:260-321), and the scenes' sampling rates (4, 20) send every opacity through
+    `1 - (1 - a)^dt`: for a <~ 1e-6 that is a difference of two floats next to 1, quantised in steps of 6e-8, and any two pow
+    implementations (CUDA's __powf, libm's powf, v_exp(dt * v_log)) differ there by a whole step.  A pixel whose total alpha is a
+    handful of such steps gets a colour that is the ratio of two such sums - ill-conditioned in the reference's own formulation, and
+    invisible (its 8-bit alpha is 0).  So: alpha and the PREMULTIPLIED colour must meet the bar everywhere (<= 1 on 8 bits, 2e-4 in
+    float), the un-premultiplied colour wherever the pixel is visible at all (8-bit alpha >= 1)."""
+    assert not np.isnan(got).any(), f"{name}: NaN in HIP frame"
+    q = lambda x: np.floor(np.clip(x, 0.0, 1.0) * 255.0 + 0.5).astype(np.int32)   # imageio.cpp:146-181 per channel (pinned in tests/test_oracle_vs_ref.py)
+    da = np.abs(got[..., 3] - ref[..., 3]).max()
+    pg, pr = got[..., :3] * got[..., 3:4], ref[..., :3] * ref[..., 3:4]
+    dp = np.abs(pg - pr).max()
+    assert da <= 2e-4 and dp <= 2e-4, f"{name}: alpha differs by {da}, premultiplied colour by {dp}"
+    assert np.abs(q(got[..., 3]) - q(ref[..., 3])).max() <= 1 and np.abs(q(pg) - q(pr)).max() <= 1, name
+    vis = q(ref[..., 3]) >= 1
+    if vis.any():
+        d8 = np.abs(q(got[..., :3]) - q(ref[..., :3]))[vis].max()
+        # at 8-bit alpha 1 (alpha ~ 0.004) a 6e-8 step of alpha is 1.5e-5 of the colour: far inside one 8-bit step
+        assert d8 <= 1, f"{name}: un-premultiplied 8-bit colour of a visible pixel differs by {d8}"
+    return vis.mean()
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_shipped_scene(ovr, oracle, hip_renderer_factory, name):
+    case = scene_case(ovr, name)
+    ref, _, cnt = oracle_scene(oracle, case).render(frames=1, accumulate=True)
+    frames = {}
+    for skip in (False, True):
+        ren = hip_renderer_factory()
+        hip_setup(ovr, ren, case, accumulate=True)
+        ren.set_empty_space_skipping(skip)
+        ren.commit()
+        ren.render()
+        frames[skip] = hip_frame(ovr, ren)[0]
+        st = ren.stats()
+        compare_visible(oracle, frames[skip], ref, name=f"{name} skip={skip}")
+        assert st.samples + st.skipped_samples == cnt.samples, name
+        # the scenes' sampling rates are 4 and 20, so every opacity goes through 1 - (1 - a)^(dt) - `v_exp(dt * v_log(1 - a))` on the GPU, powf in
+        # the oracle: a sample whose opacity is a few ulp above 0 on one side can be exactly 0 on the other.  Such a
+        # sample changes no pixel (the frame comparison above is the parity bar) but it is or is not counted as shaded
+        assert abs(int(st.shaded_samples) - int(cnt.shaded_samples)) <= max(8, int(0.02 * cnt.shaded_samples)), (name, st.shaded_samples, cnt.shaded_samples)
+        ren.close()
+    assert np.array_equal(frames[False], frames[True]), f"{name}: empty-space skipping changed the frame"
