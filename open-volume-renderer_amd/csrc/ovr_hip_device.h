@@ -1582,48 +1582,51 @@ inline hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
     }
     return hipGetLastError();
   }
-  // ---- pooled pipeline: march -> shade -> composite, once per sample-per-pixel generation
-  if ((e = hipMemsetAsync(p.pool.ctrl, 0, (size_t)kPoolCtrlWords * sizeof(unsigned int), stream)) != hipSuccess) return e;
-  if (p.block_counters && p.counters)
-    if ((e = hipMemsetAsync(p.counters, 0, 8 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
-  RayMarchParams q = p;
-  for (int g = 0; g < p.spp; ++g) {
-    q.spp_index = g;
-    if (g > 0 && (e = hipMemsetAsync(p.pool.ctrl, 0, (size_t)32 * (kPoolSubs + 1) * sizeof(unsigned int), stream)) != hipSuccess) return e; // all but the frame's maximum
-    {
-      constexpr int SH = SHADE == 0 ? 1 : SHADE; // (never instantiated for SHADE == 0: pooled is false)
-      const size_t lds = (size_t)kWaves * QCfg<SH, true>::QCAP * sizeof(ShadeReq) + table_lds_bytes(p, AM) + (size_t)p.n_alpha * sizeof(float) + 64;
-      bool launched = false;
-      if constexpr (!SKIP && AM <= 1) {
-        if (use_deep_rounds(p)) { // a small image shard: the longest ray's chain of rounds is the floor - deeper rounds
-          auto kern = raymarch_kernel<VT, SH, AM, true, SKIP, false, true>;
+  if constexpr (SHADE != 0) { // (no pooled kernels are built for SHADE == 0: the in-place march above is its only pipeline)
+    // ---- pooled pipeline: march -> shade -> composite, once per sample-per-pixel generation
+    if ((e = hipMemsetAsync(p.pool.ctrl, 0, (size_t)kPoolCtrlWords * sizeof(unsigned int), stream)) != hipSuccess) return e;
+    if (p.block_counters && p.counters)
+      if ((e = hipMemsetAsync(p.counters, 0, 8 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+    RayMarchParams q = p;
+    for (int g = 0; g < p.spp; ++g) {
+      q.spp_index = g;
+      if (g > 0 && (e = hipMemsetAsync(p.pool.ctrl, 0, (size_t)32 * (kPoolSubs + 1) * sizeof(unsigned int), stream)) != hipSuccess) return e; // all but the frame's maximum
+      {
+        constexpr int SH = SHADE;
+        const size_t lds = (size_t)kWaves * QCfg<SH, true>::QCAP * sizeof(ShadeReq) + table_lds_bytes(p, AM) + (size_t)p.n_alpha * sizeof(float) + 64;
+        bool launched = false;
+        if constexpr (!SKIP && AM <= 1) {
+          if (use_deep_rounds(p)) { // a small image shard: the longest ray's chain of rounds is the floor - deeper rounds
+            auto kern = raymarch_kernel<VT, SH, AM, true, SKIP, false, true>;
+            if ((e = set_lds(kern, lds)) != hipSuccess) return e;
+            if (grid.x > 0) hipLaunchKernelGGL(kern, grid, block, lds, stream, q);
+            launched = true;
+          }
+        }
+        if (!launched) {
+          auto kern = raymarch_kernel<VT, SH, AM, true, SKIP>;
           if ((e = set_lds(kern, lds)) != hipSuccess) return e;
           if (grid.x > 0) hipLaunchKernelGGL(kern, grid, block, lds, stream, q);
-          launched = true;
         }
+        if ((e = hipGetLastError()) != hipSuccess) return e;
       }
-      if (!launched) {
-        auto kern = raymarch_kernel<VT, SH, AM, true, SKIP>;
+      if (ev && g == p.spp - 1) (void)hipEventRecord(ev[1], stream);
+      {
+        const size_t lds = std::max<size_t>(tf_lds + table_lds_bytes(p, AM), 64);
+        auto kern = shade_pool_kernel<VT, SHADE, AM, SKIP>;
         if ((e = set_lds(kern, lds)) != hipSuccess) return e;
-        if (grid.x > 0) hipLaunchKernelGGL(kern, grid, block, lds, stream, q);
+        hipLaunchKernelGGL(kern, dim3(kShadeBlocks), block, lds, stream, q);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
       }
-      if ((e = hipGetLastError()) != hipSuccess) return e;
+      if (ev && g == p.spp - 1) (void)hipEventRecord(ev[2], stream);
+      if (grid.x > 0 && (e = launch_composite(q, grid, stream)) != hipSuccess) return e;
+      if (p.block_counters && p.counters)
+        if ((e = launch_reduce_counters(p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)p.pool.shade_counters, kShadeBlocks, p.counters,
+                                        p.pool.ctrl, stream)) != hipSuccess) return e;
     }
-    if (ev && g == p.spp - 1) (void)hipEventRecord(ev[1], stream);
-    {
-      const size_t lds = std::max<size_t>(tf_lds + table_lds_bytes(p, AM), 64);
-      auto kern = shade_pool_kernel<VT, SHADE, AM, SKIP>;
-      if ((e = set_lds(kern, lds)) != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(kShadeBlocks), block, lds, stream, q);
-      if ((e = hipGetLastError()) != hipSuccess) return e;
-    }
-    if (ev && g == p.spp - 1) (void)hipEventRecord(ev[2], stream);
-    if (grid.x > 0 && (e = launch_composite(q, grid, stream)) != hipSuccess) return e;
-    if (p.block_counters && p.counters)
-      if ((e = launch_reduce_counters(p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)p.pool.shade_counters, kShadeBlocks, p.counters,
-                                      p.pool.ctrl, stream)) != hipSuccess) return e;
+    return hipGetLastError();
   }
-  return hipGetLastError();
+  else return hipErrorInvalidValue;
 }
 
 template <int VT, int SHADE, int AM>
