@@ -1529,7 +1529,14 @@ inline hipError_t set_lds(KernT kern, size_t lds)
   return hipSuccess;
 }
 
-constexpr int kShadeBlocks = 1024; // persistent shade grid: 4 workgroups per CU
+constexpr int kShadeBlocks = 1024; // persistent shade grid: at most 4 workgroups per CU (size of the shade_counters workspace)
+// workgroups of the persistent shade kernel for this frame; OVR_HIP_SHADE_BLOCKS overrides it (measurements)
+inline int shade_grid_blocks(const RayMarchParams& p)
+{
+  static const int forced = getenv("OVR_HIP_SHADE_BLOCKS") ? atoi(getenv("OVR_HIP_SHADE_BLOCKS")) : 0;
+  if (forced > 0) return std::min(forced, kShadeBlocks);
+  return p.shade_blocks > 0 ? std::min(p.shade_blocks, kShadeBlocks) : kShadeBlocks;
+}
 
 // The deep variant of the pooled march (6 instead of 4 instructions per round, 2 instead of 3 waves per SIMD) pays when the launch is
 // bound by its longest ray's chain of dependent rounds rather than by throughput: image shards with few blocks.  Measured
@@ -1615,13 +1622,13 @@ inline hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
         const size_t lds = std::max<size_t>(tf_lds + table_lds_bytes(p, AM), 64);
         auto kern = shade_pool_kernel<VT, SHADE, AM, SKIP>;
         if ((e = set_lds(kern, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(kShadeBlocks), block, lds, stream, q);
+        hipLaunchKernelGGL(kern, dim3((unsigned)shade_grid_blocks(p)), block, lds, stream, q);
         if ((e = hipGetLastError()) != hipSuccess) return e;
       }
       if (ev && g == p.spp - 1) (void)hipEventRecord(ev[2], stream);
       if (grid.x > 0 && (e = launch_composite(q, grid, stream)) != hipSuccess) return e;
       if (p.block_counters && p.counters)
-        if ((e = launch_reduce_counters(p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)p.pool.shade_counters, kShadeBlocks, p.counters,
+        if ((e = launch_reduce_counters(p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)p.pool.shade_counters, shade_grid_blocks(p), p.counters,
                                         p.pool.ctrl, stream)) != hipSuccess) return e;
     }
     return hipGetLastError();

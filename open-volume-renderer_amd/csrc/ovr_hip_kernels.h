@@ -120,6 +120,9 @@ struct RayMarchParams {
   const float* jitter_noise;
   // LDS-staged bricks (raymarch_kernel<.., LDSB>): on / off, and where the brick area starts in the workgroup's dynamic LDS
   int lds_staging;
+  // workgroups of the persistent shade kernel (0 = the default, 1024): the host takes 768 when the previous frame had few runs of
+  // chunks (sparse transfer functions: a smaller window of concurrently shaded requests keeps more of their bricks in L2)
+  int shade_blocks;
   unsigned int lds_brick_offset;
   // counters: [0] rays [1] samples [2] shaded samples [3] shadow samples [4] active pixels [5] skipped samples [6] skipped shadow samples
   unsigned long long* counters;
