@@ -181,6 +181,8 @@ def main():
     ap.add_argument("--camera", default=None, choices=CAMERAS)
     ap.add_argument("--tf", default=None, choices=["sparse", "dense", "bumps", "opaque"])
     ap.add_argument("--shading", type=int, default=None, choices=[0, 1, 2])
+    ap.add_argument("--dtype", default=None, choices=sorted(VOXEL_BYTES), help="voxel type override (exploration: the named configurations fix it)")
+    ap.add_argument("--n", type=int, default=None, help="volume edge override (exploration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile", type=int, default=16, help="image-shard tile size in pixels (16: best balance over 8 ranks, tools/shard_balance.py)")
     ap.add_argument("--no-skip-leg", action="store_true", help="do not time the extra leg with empty-space skipping (N = 1 only)")
@@ -212,6 +214,10 @@ def worker(args, world):
         cfg["tf"] = args.tf
     if args.shading is not None:
         cfg["shading"] = args.shading
+    if args.dtype or args.n:
+        cfg["dtype"] = args.dtype or cfg["dtype"]
+        cfg["n"] = args.n or cfg["n"]
+        cfg["workload"] += f" [overridden: {cfg['n']}^3 {cfg['dtype']}]"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OVR_HIP_ABI_VERSION 5
+#define OVR_HIP_ABI_VERSION 6
 
 /* error codes */
 #define OVR_HIP_OK 0
@@ -79,6 +79,10 @@ typedef struct ovr_hip_stats {
   uint64_t lds_fallback_taps;   /* LDS-staged bricks: taps of live samples that fell outside the staged box (read from L1/L2 instead) */
   uint64_t lds_unstaged_rounds; /* LDS-staged bricks: workgroup rounds whose box exceeded the LDS budget (ordinary path)            */
   uint64_t lds_rounds;          /* LDS-staged bricks: workgroup rounds in total                                                      */
+  int32_t skipping_kernels;     /* 1: the frame ran the empty-space-skipping kernels; 0: the plain ones - skipping disabled, or enabled but
+                                   suspended because the last probed frame skipped < 10 % of its sample steps (probed again after 32 ... 256
+                                   frames and on every transfer-function / volume change; the frames are bit-identical either way)      */
+  int32_t reserved0;
 } ovr_hip_stats;
 
 const char* ovr_hip_last_error(void);
@@ -142,7 +146,10 @@ int ovr_hip_set_shading_pipeline(ovr_hip_renderer* r, int32_t mode);
 /* extension: empty-space skipping with the reference's macrocell grids (16^3 value-range cells +
  * per-TF max-opacity cells, ovr/devices/optix7/accel/sp_singlemc.cu:10-97 - the reference computes them but only its path
  * tracer uses them).  Samples whose cell has majorant 0 have opacity exactly 0: their voxel fetch is skipped, frames stay
- * bit-identical.  Off by default (the reference's ray marcher visits every sample). */
+ * bit-identical.  Off by default (the reference's ray marcher visits every sample).  While it is enabled the renderer keeps the
+ * skipping kernels only where they pay: a frame that skipped < 10 % of its sample steps (a dense transfer function, a camera inside the
+ * data - there the skipping kernels cost 20-50 % more than the plain ones) switches to the plain kernels and the skipping ones are
+ * probed again later (ovr_hip_stats::skipping_kernels says which ran; OVR_HIP_SKIP_ADAPTIVE=0 keeps them on regardless). */
 int ovr_hip_set_empty_space_skipping(ovr_hip_renderer* r, int32_t enabled);
 /* extension (BASELINE C5, north_star "blue-noise jitter staged in LDS"): how the sub-pixel position of a sample is drawn.
  * 0 (default) = the reference: RandomTEA(frame_index, pixel_index), applied iff sample_per_pixel > 1

@@ -44,6 +44,8 @@ class Stats(C.Structure):
         ("lds_fallback_taps", C.c_uint64),
         ("lds_unstaged_rounds", C.c_uint64),
         ("lds_rounds", C.c_uint64),
+        ("skipping_kernels", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 

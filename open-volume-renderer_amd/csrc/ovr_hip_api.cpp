@@ -127,6 +127,13 @@ struct ovr_hip_renderer {
   float* d_mc_majorant = nullptr;
   unsigned char* d_mc_occupancy = nullptr; // coarse, dilated occupancy (skip intervals of the march)
   unsigned char* d_mc_fine = nullptr;      // per-macrocell dilated occupancy (the primary rays' refinement of those intervals)
+  // Empty-space skipping pays only where there is empty space: with nothing to skip its kernels cost 20-50 % more than the plain ones
+  // (dense transfer functions, a camera inside the data).  While skipping is enabled the renderer therefore watches what it skips: a
+  // frame that skipped < 10 % of its sample steps switches to the plain kernels (the frames are bit-identical either way) and the
+  // skipping kernels are probed again after 32, 64, ... 256 frames, or at once when the transfer function or the volume changes.
+  // OVR_HIP_SKIP_ADAPTIVE=0 keeps the skipping kernels whatever they skip (measurements).
+  bool skip_adaptive = true, skip_active = true, frame_used_skip = false;
+  int skip_reprobe_in = 0, skip_backoff = 32;
   size_t mc_cells = 0;
   bool mc_ranges_valid = false, mc_majorant_valid = false;
   float data_lower = 0.f, data_upper = 0.f; // the volume's data range as the voxel read returns it (array.cpp:297)
@@ -592,8 +599,6 @@ int enqueue_frame(ovr_hip_renderer* r)
   // Shade grid: with at most 64 runs of 4 chunks per workgroup in the previous frame (sparse transfer functions; C3: 36 k runs) 768
   // workgroups shade 4 % faster than 1024 - a smaller window of requests in flight, more of their bricks still in L2 - with many
   // runs (dense transfer functions, 4K frames) 1024 hide more latency (profiles/r02_ab/r02b_ab_shadeblocks.txt)
-  // (not with empty-space skipping: its shade kernel is bound by instructions, not by memory, and wants every wave - 0.67 vs 0.77 ms)
-  P.shade_blocks = (!r->skipping.current && r->stats.pool_chunks > 0 && r->stats.pool_chunks <= (size_t)64 * 1024 * 4) ? 768 : 1024;
   P.lds_brick_offset = 0;
   P.jitter_mode = r->jitter.current;
   P.jitter_noise = r->d_noise;
@@ -604,12 +609,22 @@ int enqueue_frame(ovr_hip_renderer* r)
   P.majorant = nullptr;
   P.occupancy = nullptr;
   P.occupancy_fine = nullptr;
-  if (r->skipping.current) {
+  bool use_skip = r->skipping.current != 0;
+  if (use_skip && r->skip_adaptive) {
+    if (!r->mc_majorant_valid) { r->skip_active = true; r->skip_backoff = 32; } // new transfer function / volume: what is empty has changed
+    else if (!r->skip_active && --r->skip_reprobe_in <= 0) r->skip_active = true; // probe the skipping kernels again with this frame
+    use_skip = r->skip_active;
+  }
+  r->frame_used_skip = use_skip;
+  if (use_skip) {
     if (int e = update_macrocells(r, st)) return e;
     P.majorant = r->d_mc_majorant;
     P.occupancy = r->d_mc_occupancy;
     P.occupancy_fine = r->d_mc_fine;
   }
+  // (the shade grid, continued: not with empty-space skipping - that shade kernel is bound by instructions, not by memory, and wants
+  // every wave: 0.67 vs 0.77 ms)
+  P.shade_blocks = (!use_skip && r->stats.pool_chunks > 0 && r->stats.pool_chunks <= (size_t)64 * 1024 * 4) ? 768 : 1024;
   P.block_counters = r->d_block_counters;
   P.trace = r->d_trace;
   P.sparse_xy = nullptr;
@@ -726,6 +741,17 @@ int finish_frame(ovr_hip_renderer* r)
     r->stats.skipped_samples = r->stats.skipped_shadow_samples = r->stats.shadow_samples = 0;
   }
   r->stats.frame_index = r->frame_index;
+  r->stats.skipping_kernels = r->frame_used_skip ? 1 : 0;
+  if (r->frame_used_skip && r->skip_adaptive) { // did skipping pay?  (see skip_active)
+    const double skipped = (double)r->stats.skipped_samples + (double)r->stats.skipped_shadow_samples;
+    const double all = skipped + (double)r->stats.samples + (double)r->stats.shadow_samples;
+    if (all > 0.0 && skipped < 0.10 * all) {
+      r->skip_active = false;
+      r->skip_reprobe_in = r->skip_backoff;
+      r->skip_backoff = std::min(r->skip_backoff * 2, 256);
+    }
+    else r->skip_backoff = 32;
+  }
   if (r->d_trace) {
     if (const char* path = getenv("OVR_HIP_TRACE_FILE")) {
       std::vector<unsigned long long> h(r->trace_words);
@@ -782,6 +808,7 @@ int ovr_hip_create(ovr_hip_renderer** out, int device_id)
   r->layouts.current = r->layouts.queued = 1;
   r->layout_choice.current = r->layout_choice.queued = -1;
   if (const char* f = getenv("OVR_HIP_LAYOUTS")) r->layouts.current = r->layouts.queued = atoi(f); // diagnostic override
+  if (const char* f = getenv("OVR_HIP_SKIP_ADAPTIVE")) r->skip_adaptive = atoi(f) != 0;
   *out = r;
   return 0;
 }
@@ -1115,7 +1142,7 @@ int ovr_hip_commit(ovr_hip_renderer* r)
   (void)r->lds_staging.update(); // same frame either way
   (void)r->layout_choice.update(); // every layout gives the same frame: no accumulation reset
   (void)r->pipeline.update(); // both pipelines produce the same frame: no accumulation reset
-  (void)r->skipping.update(); // skipping does not change the frame either
+  if (r->skipping.update()) { r->skip_active = true; r->skip_backoff = 32; } // skipping does not change the frame either
   if (r->shard.update()) {
     r->sched_list_dirty = true;
     r->fb_reset = true;

@@ -28,8 +28,14 @@ def test_library_exports_every_declared_symbol(ovr):
 
 
 def test_stats_struct_layout_matches_header(ovr):
-    # 5 x u64, 2 x f64, 2 x i32, 3 x f64, 3 x u64, 2 x i32, 3 x u64
-    assert C.sizeof(ovr._lib.Stats) == 5 * 8 + 2 * 8 + 2 * 4 + 3 * 8 + 3 * 8 + 2 * 4 + 3 * 8
+    # 5 x u64, 2 x f64, 2 x i32, 3 x f64, 3 x u64, 2 x i32, 3 x u64, 2 x i32 (ABI v6: skipping_kernels + reserved)
+    assert C.sizeof(ovr._lib.Stats) == 5 * 8 + 2 * 8 + 2 * 4 + 3 * 8 + 3 * 8 + 2 * 4 + 3 * 8 + 2 * 4
+    # the same fields, in the same order, as the header's struct
+    import re
+    hdr = open(os.path.join(ROOT, "include", "ovr_hip.h")).read()
+    body = hdr[hdr.index("typedef struct ovr_hip_stats {"):hdr.index("} ovr_hip_stats;")]
+    names = re.findall(r"^\s*(?:uint64_t|int32_t|double)\s+(\w+);", body, flags=re.M)
+    assert names == [f[0] for f in ovr._lib.Stats._fields_]
 
 
 def test_no_cpu_fallback(ovr):

@@ -369,3 +369,38 @@ def test_lds_staged_bricks_are_bit_identical(ovr, oracle, hip_renderer_factory, 
     ren.render()
     assert ren.stats().lds_fallback_taps == 0 and ren.stats().lds_unstaged_rounds == 0
     ren.close()
+
+
+def test_skipping_kernels_are_suspended_where_nothing_is_skipped(ovr, oracle, hip_renderer_factory):
+    """With empty-space skipping enabled a frame that skipped < 10 % of its sample steps (here: a dense transfer function - every
+    macrocell can hold opacity) switches the renderer to the plain kernels; a transfer-function change probes the skipping kernels at
+    once, and a scene with empty space keeps them.  Frames are bit-identical whichever kernels run."""
+    case = make_case(ovr, oracle, n=48, tf="dense", cam="oblique", size=(96, 72), shading=2)
+    plain = hip_setup(ovr, hip_renderer_factory(), case, accumulate=True)
+    for _ in range(4):
+        plain.render()
+    want = hip_frame(ovr, plain)[0]
+    ren = hip_setup(ovr, hip_renderer_factory(), case, accumulate=True)
+    ren.set_empty_space_skipping(True)
+    ren.commit()
+    used = []
+    for _ in range(4):
+        ren.render()
+        st = ren.stats()
+        used.append(st.skipping_kernels)
+        assert st.samples + st.skipped_samples == plain.stats().samples
+    assert used == [1, 0, 0, 0], used
+    assert np.array_equal(hip_frame(ovr, ren)[0], want)          # 4 accumulated frames each
+    colors, alphas, vr = ovr.synth.make_tfn("sparse", 1024, np.float32)
+    ren.set_transfer_function(colors, alphas, vr)                # what is empty has changed: probe at once - and keep them
+    ren.commit()
+    used = []
+    for _ in range(3):
+        ren.render()
+        used.append(ren.stats().skipping_kernels)
+    assert used == [1, 1, 1] and ren.stats().skipped_samples > 0, used
+    sparse_case = dict(case, colors=colors, alphas=alphas, vr=vr)
+    ref = hip_setup(ovr, hip_renderer_factory(), sparse_case, accumulate=True)
+    for _ in range(3):
+        ref.render()
+    assert np.array_equal(hip_frame(ovr, ren)[0], hip_frame(ovr, ref)[0])
