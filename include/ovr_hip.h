@@ -139,7 +139,8 @@ int ovr_hip_set_focus(ovr_hip_renderer* r, float center_x, float center_y, float
 int ovr_hip_set_noise_tile(ovr_hip_renderer* r, const float* tile, int32_t xy);
 /* extension: select the sub-mode BASELINE.json's configs name; default OVR_HIP_SHADE_FULL (= reference) */
 int ovr_hip_set_shading(ovr_hip_renderer* r, int32_t mode);
-/* extension: how shaded samples are processed.  0 = automatic (pooled whenever shading is on), 1 = in place
+/* extension: how shaded samples are processed.  0 = automatic (pooled, or in place once a frame shaded >= 50 % of its samples - back to
+ * pooled below 35 %: ovr_hip_stats::pipeline says which ran), 1 = in place
  * (the tile's own wave shades its request batches), 2 = pooled (request chunks go through a global pool and are shaded
  * by a separate, load-balanced kernel).  Both produce bit-identical frames. */
 int ovr_hip_set_shading_pipeline(ovr_hip_renderer* r, int32_t mode);
