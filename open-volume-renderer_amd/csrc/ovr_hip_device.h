@@ -188,9 +188,9 @@ __device__ __forceinline__ void axis_tap(float po, float cs, float cb, float fn1
   const float p = clamp01(po);                       // sample_volume_object_space clamps p to [0,1]
   float x = fmaf(p, cs, cb);                         // cell-centred: p*N - 0.5
   x = clampf(x, 0.f, fn1);                           // == clamp-to-edge addressing: taps (i0, min(i0+1, n-1))
-  const float fl = floorf(x);
-  f = x - fl;
-  i0 = (int)fl;
+  // x >= 0: truncation is floor, and v_fract_f32 = x - floor(x) (an exact subtraction) - two instructions instead of floor, sub, cvt
+  f = __builtin_amdgcn_fractf(x);
+  i0 = (int)x;
   i1 = min(i0 + 1, n1);
 }
 
@@ -331,17 +331,15 @@ __device__ __forceinline__ float tf_coord(const TfConsts& tf, float sample)
 }
 __device__ __forceinline__ float tf_alpha(const TfConsts& tf, float v)
 {
-  const float x = v * tf.fna1;
-  const float fl = floorf(x);
-  const int i0 = (int)fl, i1 = min(i0 + 1, tf.na1);
-  return lerpf(tf.alpha[i0], tf.alpha[i1], x - fl);
+  const float x = v * tf.fna1;                      // v in [0, 1]: x >= 0, see axis_tap
+  const int i0 = (int)x, i1 = min(i0 + 1, tf.na1);
+  return lerpf(tf.alpha[i0], tf.alpha[i1], __builtin_amdgcn_fractf(x));
 }
 __device__ __forceinline__ f3 tf_color(const TfConsts& tf, float v)
 {
   const float x = v * tf.fnc1;
-  const float fl = floorf(x);
-  const int i0 = (int)fl, i1 = min(i0 + 1, tf.nc1);
-  const float f = x - fl;
+  const int i0 = (int)x, i1 = min(i0 + 1, tf.nc1);
+  const float f = __builtin_amdgcn_fractf(x);
   const float4 a = tf.color[i0], b = tf.color[i1];
   return mk3(lerpf(a.x, b.x, f), lerpf(a.y, b.y, f), lerpf(a.z, b.z, f));
 }
