@@ -78,6 +78,8 @@ def layout_bytes(dtype, n, layout):
     axis, thin = 1"""
     if layout == 0:
         cells, stored = (28, 4 * 8) if dtype == "uint8" else (30, 10 * 4)
+    elif layout == 3:
+        cells, stored = 32, 32 * 4   # quad: every cell stores its 2 x 2 (x, y) voxels
     else:
         cells, stored = 32, 32 * 2
     m = -(-n // 32)
@@ -187,10 +189,13 @@ def main():
     ap.add_argument("--tile", type=int, default=16, help="image-shard tile size in pixels (16: best balance over 8 ranks, tools/shard_balance.py)")
     ap.add_argument("--no-skip-leg", action="store_true", help="do not time the extra leg with empty-space skipping (N = 1 only)")
     ap.add_argument("--no-views", action="store_true", help="do not time the camera x transfer-function matrix (N = 1 only)")
-    ap.add_argument("--layout", type=int, default=-1, choices=[-1, 0, 1, 2], help="volume layout a frame reads: -1 by camera direction (default), 0 general, 1 thin, 2 thin transposed")
+    ap.add_argument("--layout", type=int, default=-1, choices=[-1, 0, 1, 2, 3], help="volume layout a frame reads: -1 automatic (default), 0 general, 1 thin, 2 thin transposed, 3 quad")
     ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2], help="shading pipeline: 0 automatic, 1 in place, 2 pooled")
     ap.add_argument("--lds-staging", action="store_true", help="unshaded march of float volumes: stage the bricks of each round through LDS (measurement switch)")
     ap.add_argument("--skip-empty", action="store_true", help="enable macrocell empty-space skipping (not the headline: fewer samples are fetched)")
+    ap.add_argument("--rate", type=float, default=None, help="volume sampling rate override (the scene files say 4: serializer_vidi3d.cpp:402; renderbatch's default is 1)")
+    ap.add_argument("--fovy", type=float, default=60.0, help="vertical field of view (renderbatch renders 60: renderer.h:149-152; the scene files say 45)")
+    ap.add_argument("--sparse-sampling", action="store_true", help="the foveated mode with the interactive app's default focus (apps/main_app.cpp:123-124)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -214,6 +219,8 @@ def worker(args, world):
         cfg["tf"] = args.tf
     if args.shading is not None:
         cfg["shading"] = args.shading
+    if args.rate is not None:
+        cfg["rate"] = args.rate
     if args.dtype or args.n:
         cfg["dtype"] = args.dtype or cfg["dtype"]
         cfg["n"] = args.n or cfg["n"]
@@ -269,8 +276,21 @@ def worker(args, world):
     ren.set_lds_staging(args.lds_staging)
     scene = ovr.Scene(volume=vol, transfer_function=None, volume_sampling_rate=cfg["rate"])
     ren.init(scene, ovr.Camera(*cam))
-    ren.set_camera(*cam)  # fovy 60, as renderbatch ends up with (renderer.h:149-152)
+
+    def set_cam():
+        if args.fovy == 60.0:
+            ren.set_camera(*cam)  # fovy 60, as renderbatch ends up with (renderer.h:149-152)
+        else:
+            ren.set_camera(ovr.Camera(*cam, fovy=args.fovy))
+
+    set_cam()
     ren.set_sparse_sampling(False)
+    if args.sparse_sampling:
+        # the foveated mode of the interactive app with its default focus (apps/main_app.cpp:123-124,184)
+        if noise is None:
+            ren.set_noise_tile(ovr.synth.make_noise_tile(64))
+        ren.set_focus((0.5, 0.5), 0.06, 0.07)
+        ren.set_sparse_sampling(True)
     ren.commit()
     vinfo = ren.volume_info()
     vol_host = None
@@ -368,14 +388,14 @@ def worker(args, world):
     skip_leg = None
     if not multi and not args.skip_empty and not args.no_skip_leg:
         fb = ovr.FrameBufferData()
-        ren.set_camera(*cam)   # any camera commit resets the accumulation (device_impl.cpp:125-144)
+        set_cam()   # any camera commit resets the accumulation (device_impl.cpp:125-144)
         ren.commit()
         for _ in range(args.warmup + args.steps):
             ren.render()
         ren.mapframe(fb, device=True)
         plain = fb.rgba.data().clone()
         ren.set_empty_space_skipping(True)
-        ren.set_camera(*cam)
+        set_cam()
         ren.commit()
         for _ in range(args.warmup):
             ren.render()
@@ -420,7 +440,7 @@ def worker(args, world):
                 "kernel": dom, "frac": kern[dom]["frac"] if dom else None, "kernel_fracs": {k: v["frac"] for k, v in kern.items()},
                 "pipeline_frac": abytes / (leg["kernel_ms"] / vsteps * 1e-3) / 1e9 / HBM_PEAK_GBS if leg["kernel_ms"] > 0 else None}
         ren.set_transfer_function(colors, alphas, vr)
-        ren.set_camera(*cam)
+        set_cam()
         ren.commit()
 
     # the other settings SURVEY 8d wants beside the headline (N = 1): the frame without the shadow march, at the scene files' fovy
@@ -461,7 +481,7 @@ def worker(args, world):
                 ren.set_sparse_sampling(False)
         ren.set_shading(cfg["shading"])
         ren.set_volume_sampling_rate(cfg["rate"])
-        ren.set_camera(*cam)
+        set_cam()
         ren.commit()
 
     # max over ranks of the elapsed time, sum over ranks of the work
@@ -513,10 +533,10 @@ def worker(args, world):
             "dtype": DTYPE_NAME[cfg["dtype"]],
             "data": "synthetic",
             "config": {"workload": cfg["workload"], "name": args.config, "volume": f"{n}^3 {cfg['dtype']}", "image": f"{W}x{H}",
-                       "transfer_function": cfg["tf"], "camera": cfg["cam"], "fovy": 60, "sampling_rate": cfg["rate"],
+                       "transfer_function": cfg["tf"], "camera": cfg["cam"], "fovy": args.fovy, "sparse_sampling": bool(args.sparse_sampling), "sampling_rate": cfg["rate"],
                        "spp": cfg["spp"], "pixel_jitter": "blue-noise tile (synthetic 64x64x64), slice = frame % 64" if noise is not None else "RandomTEA iff spp > 1 (reference)",
                        "shading": ["none", "gradient", "gradient+shadow"][cfg["shading"]],
-                       "frame_accumulation": True, "empty_space_skipping": bool(args.skip_empty), "volume_layout_read": ["general", "thin", "thin transposed"][last_stats.layout], "parallelism": f"image tiles {args.tile}x{args.tile} over {world} rank(s)"},
+                       "frame_accumulation": True, "empty_space_skipping": bool(args.skip_empty), "volume_layout_read": ["general", "thin", "thin transposed", "quad"][last_stats.layout], "parallelism": f"image tiles {args.tile}x{args.tile} over {world} rank(s)"},
             "per_frame": {k: per_step[k] for k in sorted(per_step)},
             # the dominant kernel of the frame (longest mean launch); the whole pipeline and the other kernels beside it
             "roofline": {"bound": "hbm", "achieved": kern[dom]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -109,15 +109,33 @@ struct ovr_hip_renderer {
   Queued<float> rate;
   Queued<ShardP> shard;
 
-  // volume: d_volume / vd = the general layout (always resident); replica[1..2] = the thin layouts (ovr_hip_kernels.h), if built
+  // volume: d_volume / vd = the general layout (always resident); replica[1..2] = the thin layouts, [3] = the quad layout (ovr_hip_kernels.h), if built
   void* d_volume = nullptr;
   size_t volume_bytes = 0; // all resident replicas
   VolumeDesc vd{};
-  void* d_replica[3] = { nullptr, nullptr, nullptr };
-  void* d_axis[3] = { nullptr, nullptr, nullptr }; // per layout: its per-axis offset tables (VolumeDesc::axis_ab / axis_z)
-  VolumeDesc vd_replica[3] = {};
+  void* d_replica[kLayouts] = {};  // [3] = the quad replica (f32 volumes)
+  void* d_axis[kLayouts] = {}; // per layout: its per-axis offset tables (VolumeDesc::axis_ab / axis_z)
+  VolumeDesc vd_replica[kLayouts] = {};
   Queued<int> layouts;      // ovr_hip_set_volume_layouts: which replicas the next ovr_hip_set_volume builds
-  Queued<int> layout_choice; // -1 = by the camera direction, 0..2 = forced (falls back to general if not resident)
+  Queued<int> layout_choice; // -1 = automatic (camera direction / the previous frame's work), 0..3 = forced (falls back to general if not resident)
+  // Automatic choice of the volume layout and of the shading pipeline, second stage (round 3).  The rules of round 2 - thin replicas for
+  // axis views, in place once half the samples are shaded - were fitted on frames bound by HBM bytes.  Frames that shade (nearly) every
+  // sample - most of the reference's shipped scenes, every frame at the scene files' sampling rate 4 - are bound by the gather rate and
+  // the instruction stream instead, and what is fastest there depends on the volume's size, the view and the sampling rate in ways no
+  // rule captured (profiles/r03_notes.md: quad replica -7 ... -16 % on the big scenes, +25 % on C3 dense at rate 1; pooled 16 ms vs in place
+  // 24 ms on C3 front / dense at rate 4, the opposite at rate 1).  Every layout and both pipelines give the same frame bit for bit, so the
+  // renderer measures: the first frame of a configuration runs what the rules say; if its shading taps outnumber its primary taps, the
+  // following frames try the alternatives - first the other pipeline, then the other candidate layouts (general, quad) under the better
+  // pipeline - two frames each, the second one timed (the first one pages the replica in and sizes the request pool), and the fastest
+  // (hipEvent kernel time) is kept until the configuration changes.  OVR_HIP_TUNE=0 keeps the rules alone.
+  struct TuneCand { int layout, pipeline, frames; float ms; };
+  int tune_state = 0;          // 0 = the next frame is the first of a configuration, 1 = probing, 2 = decided
+  int tune_phase = 0;          // probing: 0 = pipelines, 1 = layouts
+  TuneCand tune_cand[6] = {};
+  int tune_n = 0, tune_cur = 0;
+  int tune_layout = -1, tune_pipeline = 0; // decided (-1 / 0 = leave it to the rules)
+  int tune_frame = -1;         // candidate index of the frame in flight, -1 = not a tuned frame
+  bool tune_on = true;
   int value_type = 0;
   float origin[3] = { 0, 0, 0 }, spacing[3] = { 1, 1, 1 };
   bool have_volume = false;
@@ -367,7 +385,10 @@ void update_tfn_range(ovr_hip_renderer* r)
     P.tf_upper = integer_normalize(t.hi, dt);
     P.tf_lower = integer_normalize(t.lo, dt);
   }
-  P.tf_scale = 1.f / (P.tf_upper - P.tf_lower);
+  // a degenerate range (upper == lower: a constant volume under the data-range fallback) gives the reference scale = inf and the
+  // coordinate clamp01((lower - lower) * inf) = clamp01(NaN) = 0 for every sample; scale = 0 yields the same 0 without the NaN, which
+  // the shadow march's transfer-function lookup (tf_alpha2: no clamp) relies on
+  P.tf_scale = P.tf_upper == P.tf_lower ? 0.f : 1.f / (P.tf_upper - P.tf_lower);
 }
 
 int upload_tfn(ovr_hip_renderer* r)
@@ -586,7 +607,26 @@ int enqueue_frame(ovr_hip_renderer* r)
       else if (ay >= kAxis) choice = LAYOUT_THIN;
       else if (az >= kAxis) choice = ax >= ay ? LAYOUT_THIN_T : LAYOUT_THIN;
     }
-    if (choice < 0 || choice > 2 || !r->d_replica[choice]) choice = LAYOUT_GENERAL;
+    // second stage (see tune_state): the layout / pipeline under test, or the measured winner
+    r->tune_frame = -1;
+    const bool tune_l = r->layout_choice.current < 0, tune_p = r->pipeline.current == 0;
+    if (r->tune_on && (tune_l || tune_p)) {
+      if (choice < 0 || choice >= kLayouts || !r->d_replica[choice]) choice = LAYOUT_GENERAL;
+      if (r->tune_state == 0) { // the rules' candidate
+        r->tune_cand[0] = { tune_l ? choice : -1, 0, 0, 0.f };
+        r->tune_n = 1; r->tune_cur = 0; r->tune_phase = 0;
+        r->tune_layout = -1; r->tune_pipeline = 0;
+        r->tune_frame = 0;
+      }
+      else if (r->tune_state == 1) {
+        const auto& c = r->tune_cand[r->tune_cur];
+        if (c.layout >= 0) choice = c.layout;
+        r->tune_pipeline = c.pipeline;
+        r->tune_frame = r->tune_cur;
+      }
+      else if (r->tune_layout >= 0 && tune_l) choice = r->tune_layout;
+    }
+    if (choice < 0 || choice >= kLayouts || !r->d_replica[choice]) choice = LAYOUT_GENERAL;
     const float vs = P.vol.value_scale, vm = P.vol.value_min_clamp;
     P.vol = r->vd_replica[choice];
     P.vol.value_scale = vs;
@@ -658,7 +698,8 @@ int enqueue_frame(ovr_hip_renderer* r)
   }
   // ---- shading pipeline: pooled (march -> shade -> composite) when it applies, else in place
   const int pipe = r->pipeline.current;
-  const bool want_pool = P.shading != 0 && pipe != 1 && !(pipe == 0 && r->auto_inplace);
+  bool want_pool = P.shading != 0 && pipe != 1 && !(pipe == 0 && r->auto_inplace);
+  if (P.shading != 0 && pipe == 0 && r->tune_on && r->tune_state != 0 && r->tune_pipeline != 0) want_pool = r->tune_pipeline == 2; // measured (tune_state)
   P.pool = PoolDesc{};
   if (want_pool) {
     // first guess: room for 8 shaded samples per pixel; grown after an overflow (finish_frame)
@@ -698,12 +739,12 @@ int finish_frame(ovr_hip_renderer* r)
 {
   if (!r->async_pending) return 0;
   HIP_TRY(hipStreamSynchronize(r->stream()));
+  r->stats.stale_tiles = 0;
   if (r->P.pool.reqs) {
     // pool overflow: the march asked for more chunks than the pool holds; nothing was written to the framebuffer.
     // Grow the pool to what the frame needs (+25 %) and render the same frame again.
     // the most chunks any sub-pool was asked for in any generation of the frame
     auto asked = [&]() { return (size_t)r->h_ctrl[32 * (kPoolSubs + 1)]; };
-    r->stats.stale_tiles = 0;
     if (asked() > r->pool.sub_capacity && r->packed_early) r->stats.stale_tiles = 1; // packed before this re-render: the caller must not use them
     for (int attempt = 0; attempt < 4 && asked() > r->pool.sub_capacity; ++attempt) {
       const size_t need = (asked() + asked() / 4 + 16) * kPoolSubs;
@@ -719,8 +760,11 @@ int finish_frame(ovr_hip_renderer* r)
     r->pool_roomy = asked() * 2 <= (size_t)r->pool.sub_capacity;
   }
   else {
+    // no pool: this frame is never rendered twice - but it proves nothing about the pool: only a pooled frame of the same
+    // configuration does (the automatic pipeline may flip the NEXT frame back to pooled without a commit in between, and
+    // ovr_hip_pack_tiles packs right behind a frame only when pool_roomy says it cannot overflow)
     r->stats.pool_chunks = 0;
-    r->pool_roomy = true; // no pool: a frame is never rendered twice
+    r->pool_roomy = false;
   }
   float ms = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, r->ev[0], r->ev[3]));
@@ -748,6 +792,63 @@ int finish_frame(ovr_hip_renderer* r)
   }
   r->stats.frame_index = r->frame_index;
   r->stats.skipping_kernels = r->frame_used_skip ? 1 : 0;
+  if (r->tune_frame >= 0 && r->tune_state < 2) { // measured choice of layout and pipeline (see tune_state)
+    static const bool trace = getenv("OVR_HIP_TUNE_TRACE") != nullptr;
+    auto& c = r->tune_cand[r->tune_frame];
+    c.frames++;
+    c.ms = ms;
+    if (trace) fprintf(stderr, "[hip] tune: state %d phase %d candidate %d (layout %d pipeline %d) frame %d: layout %d pipeline %d kernel %.3f ms\n", r->tune_state, r->tune_phase,
+                       r->tune_frame, c.layout, c.pipeline, c.frames, r->stats.layout, r->stats.pipeline, ms);
+    const bool tune_l = r->layout_choice.current < 0, tune_p = r->pipeline.current == 0;
+    auto decide = [&]() {
+      int best = 0;
+      for (int k = 1; k < r->tune_n; ++k)
+        if (r->tune_cand[k].frames >= 2 && r->tune_cand[k].ms < r->tune_cand[best].ms) best = k;
+      r->tune_layout = tune_l ? r->tune_cand[best].layout : -1;
+      r->tune_pipeline = tune_p ? r->tune_cand[best].pipeline : 0;
+      r->tune_state = 2;
+      if (trace) fprintf(stderr, "[hip] tune: decided layout %d pipeline %d (%.3f ms)\n", r->tune_layout, r->tune_pipeline, r->tune_cand[best].ms);
+    };
+    // the layouts worth a try besides the rules' one: the general layout and the quad replica (a thin replica the camera did not ask
+    // for loses 30-60 %: profiles/r02_notes.md section 2)
+    auto add_layouts = [&](int pipeline) {
+      const int base = r->tune_cand[0].layout;
+      for (int l : { (int)LAYOUT_GENERAL, (int)LAYOUT_QUAD })
+        if (tune_l && l != base && r->d_replica[l] && r->tune_n < 6) r->tune_cand[r->tune_n++] = { l, pipeline, 0, 0.f };
+      r->tune_phase = 1;
+    };
+    if (r->tune_state == 0) {
+      c.layout = tune_l ? r->stats.layout : -1;
+      c.pipeline = r->stats.pipeline;
+      // shade-heavy: the gradient (3 per shaded sample) and shadow taps outnumber the primary taps
+      const double shade_taps = 3.0 * (double)r->stats.shaded_samples + (double)r->stats.shadow_samples;
+      const bool heavy = r->P.shading != 0 && r->stats.samples > 0 && shade_taps >= 3.0 * (double)r->stats.samples;
+      if (!heavy) { r->tune_state = 2; r->tune_layout = -1; r->tune_pipeline = 0; } // the rules stay in charge
+      else {
+        r->tune_state = 1;
+        r->tune_cur = 0;          // the rules' candidate runs once more, timed
+        r->tune_pipeline = c.pipeline;
+        // the other pipeline: pooled is never far off, but shading in place is only worth a frame when most samples are shaded (with
+        // few, a handful of waves shade alone for many milliseconds: DESIGN.md section 4)
+        const bool try_other = tune_p && r->P.spp == 1 &&
+                               (c.pipeline == 1 || (double)r->stats.shaded_samples >= 0.35 * ((double)r->stats.samples + (double)r->stats.skipped_samples));
+        if (try_other) r->tune_cand[r->tune_n++] = { c.layout, c.pipeline == 2 ? 1 : 2, 0, 0.f };
+        else add_layouts(c.pipeline);
+        if (r->tune_n == 1) decide();
+      }
+    }
+    else if (c.frames >= 2) {
+      r->tune_cur++;
+      if (r->tune_cur >= r->tune_n) {
+        if (r->tune_phase == 0) {
+          const int pbest = (r->tune_n > 1 && r->tune_cand[1].ms < r->tune_cand[0].ms) ? r->tune_cand[1].pipeline : r->tune_cand[0].pipeline;
+          add_layouts(pbest);
+          if (r->tune_cur >= r->tune_n) decide();
+        }
+        else decide();
+      }
+    }
+  }
   { // automatic shading pipeline of the next frame (see auto_inplace)
     const double steps = (double)r->stats.samples + (double)r->stats.skipped_samples, shaded = (double)r->stats.shaded_samples;
     if (steps > 0.0) {
@@ -822,6 +923,7 @@ int ovr_hip_create(ovr_hip_renderer** out, int device_id)
   r->layout_choice.current = r->layout_choice.queued = -1;
   if (const char* f = getenv("OVR_HIP_LAYOUTS")) r->layouts.current = r->layouts.queued = atoi(f); // diagnostic override
   if (const char* f = getenv("OVR_HIP_SKIP_ADAPTIVE")) r->skip_adaptive = atoi(f) != 0;
+  if (const char* f = getenv("OVR_HIP_TUNE")) r->tune_on = atoi(f) != 0;
   *out = r;
   return 0;
 }
@@ -832,7 +934,7 @@ void ovr_hip_destroy(ovr_hip_renderer* r)
   (void)hipSetDevice(r->device);
   (void)hipDeviceSynchronize();
   (void)free_framebuffers(r);
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < kLayouts; ++k) {
     if (r->d_replica[k]) (void)hipFree(r->d_replica[k]);
     if (r->d_axis[k]) (void)hipFree(r->d_axis[k]);
   }
@@ -891,7 +993,7 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
   if (vt == VOX_I8) { vd.value_scale = 1.f / 127.f; vd.value_min_clamp = -127.f; }
   const size_t bytes = (size_t)vd.bytes;
 
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < kLayouts; ++k) {
     if (r->d_replica[k]) HIP_TRY(hipFree(r->d_replica[k]));
     r->d_replica[k] = nullptr;
     if (r->d_axis[k]) HIP_TRY(hipFree(r->d_axis[k]));
@@ -944,14 +1046,42 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
       }
     }
   }
-  for (int k = 0; k < n_layouts; ++k) { // the layouts' per-axis offset tables, staged into LDS by every march / shade workgroup
+  // quad replica (ovr_hip_kernels.h: a tap is two 16-byte loads; 4 x the memory) for the frames that shade every sample: same modes,
+  // same 40 % rule (all replicas together); OVR_HIP_QUAD=0 leaves it out (measurements)
+  static const bool want_quad = !(getenv("OVR_HIP_QUAD") && atoi(getenv("OVR_HIP_QUAD")) == 0);
+  if (want_quad && r->layouts.current != 0 && replica_voxel_type(vt, LAYOUT_QUAD) >= 0) {
+    VolumeDesc tq = vd;
+    volume_layout(replica_voxel_type(vt, LAYOUT_QUAD), vd.nx, vd.ny, vd.nz, tq);
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const double built = (double)(r->volume_bytes - bytes); // the thin replicas, already allocated
+    if (r->layouts.current == 2 || (double)tq.bytes + built <= 0.4 * ((double)free_b + built)) {
+      hipError_t e = hipMalloc(&r->d_replica[LAYOUT_QUAD], (size_t)tq.bytes + 64);
+      if (e == hipSuccess) e = hipMemset(r->d_replica[LAYOUT_QUAD], 0, (size_t)tq.bytes + 64);
+      if (e == hipSuccess) {
+        r->vd_replica[LAYOUT_QUAD] = tq;
+        r->vd_replica[LAYOUT_QUAD].data = r->d_replica[LAYOUT_QUAD];
+        r->volume_bytes += (size_t)tq.bytes;
+      }
+      else {
+        (void)hipGetLastError();
+        if (r->d_replica[LAYOUT_QUAD]) (void)hipFree(r->d_replica[LAYOUT_QUAD]);
+        r->d_replica[LAYOUT_QUAD] = nullptr;
+        if (r->layouts.current == 2) return fail(OVR_HIP_EDEVICE, std::string("[hip] volume replicas requested (layouts mode 2) but the quad replica's allocation failed: ") + hipGetErrorString(e));
+      }
+    }
+  }
+  (void)n_layouts;
+  for (int k = 0; k < kLayouts; ++k) { // the layouts' per-axis offset tables, staged into LDS by every march / shade workgroup
+    if (!r->d_replica[k]) continue;
     HIP_TRY(hipMalloc(&r->d_axis[k], axis_table_bytes(r->vd_replica[k])));
     HIP_TRY(launch_axis_tables(r->vd_replica[k], r->d_axis[k], st_));
   }
   vd = r->vd_replica[0];
   auto relayout_all = [&](const void* src, int z0, int nzc) -> hipError_t {
-    for (int k = 0; k < n_layouts; ++k)
-      if (hipError_t e = launch_relayout(src, value_type, r->d_replica[k], r->vd_replica[k], z0, nzc, st_)) return e;
+    for (int k = 0; k < kLayouts; ++k)
+      if (r->d_replica[k])
+        if (hipError_t e = launch_relayout(src, value_type, r->d_replica[k], r->vd_replica[k], z0, nzc, st_)) return e;
     return hipSuccess;
   };
 
@@ -1002,6 +1132,8 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
   update_tfn_range(r);
   r->sched_dirty = true;
   r->fb_reset = true;
+  r->tune_state = 0;
+  r->pool_roomy = false; // a pooled frame of THIS volume has to prove the pool (ovr_hip_pack_tiles packs early only then)
   return 0;
 }
 
@@ -1070,7 +1202,7 @@ OVR_SIMPLE_SETTER(ovr_hip_set_shading, shading, int32_t, v >= 0 && v <= 2, "[hip
 OVR_SIMPLE_SETTER(ovr_hip_set_shading_pipeline, pipeline, int32_t, v >= 0 && v <= 2, "[hip] unknown shading pipeline")
 OVR_SIMPLE_SETTER(ovr_hip_set_empty_space_skipping, skipping, int32_t, true, "")
 OVR_SIMPLE_SETTER(ovr_hip_set_volume_layouts, layouts, int32_t, v >= 0 && v <= 2, "[hip] unknown volume-layout mode")
-OVR_SIMPLE_SETTER(ovr_hip_set_layout_choice, layout_choice, int32_t, v >= -1 && v <= 2, "[hip] unknown layout choice")
+OVR_SIMPLE_SETTER(ovr_hip_set_layout_choice, layout_choice, int32_t, v >= -1 && v < kLayouts, "[hip] unknown layout choice")
 OVR_SIMPLE_SETTER(ovr_hip_set_lds_staging, lds_staging, int32_t, v == 0 || v == 1, "[hip] unknown LDS-staging mode")
 OVR_SIMPLE_SETTER(ovr_hip_set_pixel_jitter, jitter, int32_t, v == 0 || v == 1, "[hip] unknown pixel-jitter mode")
 
@@ -1120,6 +1252,8 @@ int ovr_hip_commit(ovr_hip_renderer* r)
   if (int e = set_device(r)) return e;
   if (int e = finish_frame(r)) return e;
   std::lock_guard<std::mutex> lk(r->mtx);
+  const bool reset_pending = r->fb_reset; // (without accumulation the flag is never consumed)
+  r->fb_reset = false;
   bool fb_size_updated = false;
   if (r->fbsize.update()) { // device_impl.cpp:116-122
     if (int e = resize_framebuffers(r, r->fbsize.current.w, r->fbsize.current.h)) return e;
@@ -1160,7 +1294,11 @@ int ovr_hip_commit(ovr_hip_renderer* r)
     r->sched_list_dirty = true;
     r->fb_reset = true;
   }
-  if (r->fb_reset) r->pool_roomy = false; // something changed: the next frame's request count is unknown
+  if (r->fb_reset) {
+    r->pool_roomy = false; // something changed: the next frame's request count is unknown
+    r->tune_state = 0;     // ... and so are the fastest layout and pipeline
+  }
+  r->fb_reset = r->fb_reset || reset_pending;
   return 0;
 }
 

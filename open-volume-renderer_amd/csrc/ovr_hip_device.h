@@ -86,6 +86,7 @@ template <> struct Vox<VOX_F32> {
   static constexpr int cx = OVR_F32_CX, mbx = OVR_F32_MBX, by = OVR_F32_BY, bz = OVR_F32_BZ; // cells per brick in x, bricks per macro block in x, log2 brick y/z
   static constexpr bool kScale = false, kClamp = false;
   static constexpr bool kTransposed = false;
+  static constexpr bool kQuad = false;
 };
 #ifndef OVR_U16_CX
 #define OVR_U16_CX 3
@@ -98,6 +99,7 @@ template <> struct Vox<VOX_U16> {
   static constexpr int cx = OVR_U16_CX, mbx = OVR_U16_MBX, by = OVR_U16_BY, bz = OVR_U16_BZ;
   static constexpr bool kScale = false, kClamp = false; // u16 is sampled as RAW float (array.cpp:335-338)
   static constexpr bool kTransposed = false;
+  static constexpr bool kQuad = false;
 };
 // Thin replicas (view-dependent layout choice, see VoxelType in ovr_hip_kernels.h): 1 cell + apron along the pair axis, 4 x 4
 // (f32) or 4 x 8 (u16) voxels across.  *_TT is stored with x and y exchanged, so its pair axis is the volume's y.
@@ -110,6 +112,7 @@ template <> struct Vox<VOX_F32_T> {
   static constexpr int cx = 1, mbx = 32, by = 2, bz = 2;
   static constexpr bool kScale = false, kClamp = false;
   static constexpr bool kTransposed = false;
+  static constexpr bool kQuad = false;
 };
 template <> struct Vox<VOX_F32_TT> : Vox<VOX_F32_T> { static constexpr bool kTransposed = true; };
 template <> struct Vox<VOX_U16_T> {
@@ -117,6 +120,7 @@ template <> struct Vox<VOX_U16_T> {
   static constexpr int cx = 1, mbx = 32, by = OVR_U16T_BY, bz = OVR_U16T_BZ;
   static constexpr bool kScale = false, kClamp = false;
   static constexpr bool kTransposed = false;
+  static constexpr bool kQuad = false;
 };
 template <> struct Vox<VOX_U16_TT> : Vox<VOX_U16_T> { static constexpr bool kTransposed = true; };
 template <> struct Vox<VOX_I16> {
@@ -124,18 +128,32 @@ template <> struct Vox<VOX_I16> {
   static constexpr int cx = 3, mbx = 10, by = 2, bz = 2;
   static constexpr bool kScale = false, kClamp = false;
   static constexpr bool kTransposed = false;
+  static constexpr bool kQuad = false;
 };
 template <> struct Vox<VOX_U8> {
   typedef unsigned char T; typedef u8x2_u P;
   static constexpr int cx = 7, mbx = 4, by = 2, bz = 2;
   static constexpr bool kScale = true, kClamp = false; // normalized read: v / 255 (array.cpp:304-306)
   static constexpr bool kTransposed = false;
+  static constexpr bool kQuad = false;
 };
 template <> struct Vox<VOX_I8> {
   typedef signed char T; typedef i8x2_u P;
   static constexpr int cx = 7, mbx = 4, by = 2, bz = 2;
   static constexpr bool kScale = true, kClamp = true; // max(v / 127, -1)
   static constexpr bool kTransposed = false;
+  static constexpr bool kQuad = false;
+};
+
+// Quad replica (VoxelType in ovr_hip_kernels.h): a cell stores its 2 x 2 (x, y) voxels as one float4; 2 x 2 x 2 cells per brick.
+// (cx / mbx / by / bz describe the brick to the code that is shared with the other layouts; the pair type is not used)
+typedef float f32x4_q __attribute__((ext_vector_type(4)));
+template <> struct Vox<VOX_F32_Q> {
+  typedef float T; typedef f32x2_u P;
+  static constexpr int cx = 2, mbx = 16, by = 1, bz = 1;
+  static constexpr bool kScale = false, kClamp = false;
+  static constexpr bool kTransposed = false;
+  static constexpr bool kQuad = true;
 };
 
 template <int VT> struct BrickMap {
@@ -163,6 +181,15 @@ template <int VT> struct BrickMap {
   {
     return ((z & ((1u << V::bz) - 1u)) << V::by) * SX + ((z >> V::bz) & ((32u >> V::bz) - 1u)) * sbz;
   }
+};
+
+// offsets in floats: cell (x, y, z) -> 4 floats at X(x) + Y(y) + Z(z); bricks x-fastest inside macro blocks of 16^3 bricks (32^3 cells)
+template <> struct BrickMap<VOX_F32_Q> {
+  static constexpr unsigned SX = 2, BV = 32, MV = 32u * 16u * 16u * 16u, MCX = 32;
+  static __host__ __device__ __forceinline__ unsigned div_cx(unsigned x) { return x >> 1; }
+  static __host__ __device__ __forceinline__ unsigned X(unsigned x) { return (x & 1u) * 4u + ((x >> 1) & 15u) * BV + (x >> 5) * MV; }
+  static __host__ __device__ __forceinline__ unsigned Y(unsigned y, unsigned macro_y_stride) { return (y & 1u) * 8u + ((y >> 1) & 15u) * (16u * BV) + (y >> 5) * macro_y_stride; }
+  static __host__ __device__ __forceinline__ unsigned Zlo(unsigned z) { return (z & 1u) * 16u + ((z >> 1) & 15u) * (256u * BV); }
 };
 
 struct VolConsts {
@@ -228,6 +255,39 @@ __device__ __forceinline__ void tap_loads(const VolConsts& vc, Tap& t)
   typedef BrickMap<VT> M;
   typedef typename Vox<VT>::T T;
   typedef typename Vox<VT>::P P;
+  if constexpr (Vox<VT>::kQuad) { // quad replica: the (x, y) footprint of a z slice is one 16-byte load
+    const int z1 = min(t.z0 + 1, vc.nz1);
+    f32x4_q q0, q1;
+    if (AM == 3) {
+      const unsigned o = M::X((unsigned)t.x0) + M::Y((unsigned)t.y0, vc.macro_y);
+      const float* base = static_cast<const float*>(vc.data);
+      const unsigned long long oz0 = (unsigned long long)M::Zlo((unsigned)t.z0) + (unsigned long long)((unsigned)t.z0 >> 5) * vc.macro_z;
+      const unsigned long long oz1 = (unsigned long long)M::Zlo((unsigned)z1) + (unsigned long long)((unsigned)z1 >> 5) * vc.macro_z;
+      q0 = *reinterpret_cast<const f32x4_q*>(base + (oz0 + o)); q1 = *reinterpret_cast<const f32x4_q*>(base + (oz1 + o));
+    }
+    else if (AM == 2) {
+      const unsigned o = vc.tab_x[t.x0] + vc.tab_y[t.y0];
+      const unsigned long long oz0 = vc.tab_z64[t.z0], oz1 = vc.tab_z64[t.z0 + 1];
+      const float* base = static_cast<const float*>(vc.data);
+      q0 = *reinterpret_cast<const f32x4_q*>(base + (oz0 + o)); q1 = *reinterpret_cast<const f32x4_q*>(base + (oz1 + o));
+    }
+    else {
+      const unsigned o = vc.tab_x[t.x0] + vc.tab_y[t.y0];
+      const unsigned oz0 = vc.tab_z[t.z0], oz1 = vc.tab_z[t.z0 + 1];
+      if (AM == 1) {
+        const float* base = static_cast<const float*>(vc.data);
+        q0 = *reinterpret_cast<const f32x4_q*>(base + (oz0 + o)); q1 = *reinterpret_cast<const f32x4_q*>(base + (oz1 + o));
+      }
+      else {
+        const char* cb = static_cast<const char*>(vc.data);
+        q0 = *reinterpret_cast<const f32x4_q*>(cb + (oz0 + o)); q1 = *reinterpret_cast<const f32x4_q*>(cb + (oz1 + o));
+      }
+    }
+    (void)z1;
+    t.c000 = q0.x; t.c100 = q0.y; t.c010 = q0.z; t.c110 = q0.w;
+    t.c001 = q1.x; t.c101 = q1.y; t.c011 = q1.z; t.c111 = q1.w;
+    return;
+  }
   // layout coordinates (a, b, c): a = the pair axis (the volume's x; its y in a transposed replica), b = the other of the two
   constexpr bool TR = Vox<VT>::kTransposed;
   const int a0 = TR ? t.y0 : t.x0, b0 = TR ? t.x0 : t.y0, z0 = t.z0;
@@ -271,6 +331,9 @@ __device__ __forceinline__ void tap_loads(const VolConsts& vc, Tap& t)
       p01 = *reinterpret_cast<const P*>(cb + (oz1 + o0)); p11 = *reinterpret_cast<const P*>(cb + (oz1 + o1));
     }
   }
+#ifdef OVR_EXP_HALF_LOADS /* timing experiment only (wrong pictures): what would half the gather instructions buy? */
+  p10 = p00; p11 = p01;
+#endif
   // p(b, c) = the pair along a at (b0 + b, z0 + c); the corners keep their volume-axis names, so the lerp order (x, then y,
   // then z) and with it every bit of the result is the same for every layout
   if (!TR) {
@@ -315,6 +378,57 @@ __device__ __forceinline__ float sample_volume(const VolConsts& vc, f3 p)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// packed FP32: two taps of ONE lane side by side in 64-bit register pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: each half
+// is the IEEE operation of the scalar instruction, so results are bit-identical to the scalar form).  Measured issue cost relative
+// to v_fma_f32 (tools/ubench_valu.hip): v_pk_fma_f32 1.3 for two fmas, v_pk_add / v_pk_mul 1.1 for two.  Only what is naturally
+// a pair is packed: the loaded voxel pairs are (x, x+1) of one brick row - their x-lerp needs hi - lo of ONE register pair, which a
+// packed instruction cannot do without moves (the compiler's own SLP packing of those lerps costs 3 v_mov per 2 lerps: the
+// library is built with -fno-slp-vectorize) - so the x-lerps stay scalar and write their results side by side for the packed y / z lerps.
+// ------------------------------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ f2 splat2(float a) { return mk2(a, a); }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 lerp2(f2 a, f2 b, f2 f) { return fma2(f, b - a, a); }
+
+// axis_tap for two taps.  The clamp of p to [0, 1] (sample_volume_object_space) is subsumed by the clamp of x to [0, n - 1]:
+// x = fma(p, cs, cb) is monotone in p (cs > 0), p = 0 maps to cb <= 0 and p = 1 to at least n - 1, so clamping x alone gives the
+// value clamping p first gives, for every p (NaN -> 0 either way: clamp01(NaN) = 0 -> cb -> 0, and med3(NaN, 0, n - 1) = 0)
+// a * sc.x + sc.y on both halves; sc = (scale, offset) lives in one register pair whose halves the instruction broadcasts (op_sel)
+__device__ __forceinline__ f2 fma2_sc(f2 a, f2 sc) { return fma2(a, __builtin_shufflevector(sc, sc, 0, 0), __builtin_shufflevector(sc, sc, 1, 1)); }
+__device__ __forceinline__ void axis_tap2(f2 po, f2 csb, float fn1, int& ia, int& ib, float& fa, float& fb)
+{
+  const f2 x = fma2_sc(po, csb);
+  const float xa = clampf(x.x, 0.f, fn1), xb = clampf(x.y, 0.f, fn1);
+  fa = __builtin_amdgcn_fractf(xa); ia = (int)xa;
+  fb = __builtin_amdgcn_fractf(xb); ib = (int)xb;
+}
+__device__ __forceinline__ void tap_coords2(const VolConsts& vc, f2 px, f2 py, f2 pz, f2 cx, f2 cy, f2 cz, Tap& a, Tap& b)
+{
+  axis_tap2(px, cx, vc.fx1, a.x0, b.x0, a.fx, b.fx);
+  axis_tap2(py, cy, vc.fy1, a.y0, b.y0, a.fy, b.fy);
+  axis_tap2(pz, cz, vc.fz1, a.z0, b.z0, a.fz, b.fz);
+}
+// tap_finish for two taps: 8 scalar x-lerps, then the y and z lerps of both taps packed (6 instructions instead of 12)
+template <int VT>
+__device__ __forceinline__ f2 tap_finish2(const VolConsts& vc, Tap a, Tap b)
+{
+  if (Vox<VT>::kClamp) {
+    a.c000 = fmaxf(a.c000, vc.vmin); a.c100 = fmaxf(a.c100, vc.vmin); a.c010 = fmaxf(a.c010, vc.vmin); a.c110 = fmaxf(a.c110, vc.vmin);
+    a.c001 = fmaxf(a.c001, vc.vmin); a.c101 = fmaxf(a.c101, vc.vmin); a.c011 = fmaxf(a.c011, vc.vmin); a.c111 = fmaxf(a.c111, vc.vmin);
+    b.c000 = fmaxf(b.c000, vc.vmin); b.c100 = fmaxf(b.c100, vc.vmin); b.c010 = fmaxf(b.c010, vc.vmin); b.c110 = fmaxf(b.c110, vc.vmin);
+    b.c001 = fmaxf(b.c001, vc.vmin); b.c101 = fmaxf(b.c101, vc.vmin); b.c011 = fmaxf(b.c011, vc.vmin); b.c111 = fmaxf(b.c111, vc.vmin);
+  }
+  const f2 c00 = mk2(lerpf(a.c000, a.c100, a.fx), lerpf(b.c000, b.c100, b.fx)), c10 = mk2(lerpf(a.c010, a.c110, a.fx), lerpf(b.c010, b.c110, b.fx));
+  const f2 c01 = mk2(lerpf(a.c001, a.c101, a.fx), lerpf(b.c001, b.c101, b.fx)), c11 = mk2(lerpf(a.c011, a.c111, a.fx), lerpf(b.c011, b.c111, b.fx));
+  const f2 fy = mk2(a.fy, b.fy), fz = mk2(a.fz, b.fz);
+  const f2 c0 = lerp2(c00, c10, fy), c1 = lerp2(c01, c11, fy);
+  f2 s = lerp2(c0, c1, fz);
+  if (Vox<VT>::kScale) s = s * splat2(vc.vscale);
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // transfer function in LDS (or global when it does not fit)
 // ------------------------------------------------------------------------------------------------------------------
 struct TfConsts {
@@ -329,19 +443,36 @@ __device__ __forceinline__ float tf_coord(const TfConsts& tf, float sample)
 {
   return clamp01((fminf(fmaxf(sample, tf.lower), tf.upper) - tf.lower) * tf.scale); // shaders_common.h:363, :316
 }
+// (both tables carry one more entry, a copy of their last one - stage_tf - so that (i0, i0 + 1) is the reference's clamp-to-edge pair
+// without min(i0 + 1, n - 1): i0 = n - 1 only for v = 1, where the fraction is 0 and lerp(a, a, 0) = a; the two alphas arrive with
+// one ds_read2_b32.  Three instructions fewer per lookup, i.e. per shadow sample.)
 __device__ __forceinline__ float tf_alpha(const TfConsts& tf, float v)
 {
   const float x = v * tf.fna1;                      // v in [0, 1]: x >= 0, see axis_tap
-  const int i0 = (int)x, i1 = min(i0 + 1, tf.na1);
-  return lerpf(tf.alpha[i0], tf.alpha[i1], __builtin_amdgcn_fractf(x));
+  const int i0 = (int)x;
+  return lerpf(tf.alpha[i0], tf.alpha[i0 + 1], __builtin_amdgcn_fractf(x));
 }
 __device__ __forceinline__ f3 tf_color(const TfConsts& tf, float v)
 {
   const float x = v * tf.fnc1;
-  const int i0 = (int)x, i1 = min(i0 + 1, tf.nc1);
+  const int i0 = (int)x;
   const float f = __builtin_amdgcn_fractf(x);
-  const float4 a = tf.color[i0], b = tf.color[i1];
+  const float4 a = tf.color[i0], b = tf.color[i0 + 1];
   return mk3(lerpf(a.x, b.x, f), lerpf(a.y, b.y, f), lerpf(a.z, b.z, f));
+}
+
+// opacity of two samples: tf_coord + tf_alpha packed.  Two of the scalar form's instructions per sample are dropped without changing a bit:
+//  * the clamp of the coordinate to [0, 1]: v = (clamp(s, lower, upper) - lower) * scale is never negative and exceeds 1 by at most a
+//    rounding step; such a v indexes the table's last entry with a small fraction, and the entry after the last is a copy of the
+//    last (stage_tf), so the lerp returns A[n - 1] exactly as v = 1 does (update_tfn_range keeps scale finite);
+//  * min(i0 + 1, n - 1): the same copy makes (i0, i0 + 1) clamp-to-edge, and the two entries arrive with one ds_read2_b32.
+__device__ __forceinline__ f2 tf_alpha2(const TfConsts& tf, f2 s)
+{
+  const f2 sc = mk2(fminf(fmaxf(s.x, tf.lower), tf.upper), fminf(fmaxf(s.y, tf.lower), tf.upper));
+  const f2 x = ((sc - splat2(tf.lower)) * splat2(tf.scale)) * splat2(tf.fna1);
+  const int ia = (int)x.x, ib = (int)x.y;
+  const float a0 = tf.alpha[ia], a1 = tf.alpha[ia + 1], b0 = tf.alpha[ib], b1 = tf.alpha[ib + 1];
+  return mk2(lerpf(a0, a1, __builtin_amdgcn_fractf(x.x)), lerpf(b0, b1, __builtin_amdgcn_fractf(x.y)));
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -499,6 +630,83 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
   return alpha;
 }
 
+// The same march with its taps in pairs (packed FP32, see f2 above): the all-shaded frames - most of the reference's shipped scenes, and
+// every frame at the scene files' sampling rate 4 - are bound by this loop's instruction stream (profiles/r03_notes.md: VALU ~100 % busy).
+// Per pair of steps: positions, object coordinates and cell coordinates as 9 v_pk_fma_f32 (18 v_fma_f32 in the scalar form), the y / z lerps,
+// the transfer-function coordinate and the opacity correction's multiplies packed; the redundant clamps dropped (axis_tap2, tf_alpha2).
+// Every value is computed by the same IEEE operations in the same order as in march_shadow: bit-identical results.
+#ifndef OVR_SHADOW_PACKED
+#define OVR_SHADOW_PACKED 0
+#endif
+#ifndef OVR_PACKED_LERP
+#define OVR_PACKED_LERP 0
+#endif
+template <int VT, int AM, int KS>
+__device__ __forceinline__ float march_shadow_packed(const VolConsts& vc, const TfConsts& tf, const MarchConsts& mc, f3 org, unsigned int& n_shadow)
+{
+  static_assert(KS % 2 == 0, "taps come in pairs");
+  constexpr int KP = KS / 2;
+  const f3 oo = to_object(mc, org);
+  const f3 od = mk3(mc.light.x * mc.inv_scale.x, mc.light.y * mc.inv_scale.y, mc.light.z * mc.inv_scale.z);
+  float t0 = 0.f, t1 = FLT_MAX;
+  float alpha = 0.f;
+  if (!intersect_unit_box(t0, t1, oo, od)) return alpha;
+  float tx = t0, ty = fminf(t1, t0 + mc.shadow_stride);
+  bool live = true;
+  const f2 lx = splat2(mc.light.x), ly = splat2(mc.light.y), lz = splat2(mc.light.z);
+  const f2 ox = splat2(org.x), oy = splat2(org.y), oz = splat2(org.z);
+  // (scale, offset) of the two affine maps per axis, each pair in ONE 64-bit scalar register: a packed fma may read one scalar operand
+  const f2 wx = mk2(mc.inv_scale.x, mc.wto_p.x), wy = mk2(mc.inv_scale.y, mc.wto_p.y), wz = mk2(mc.inv_scale.z, mc.wto_p.z);
+  const f2 cx = mk2(vc.cs.x, vc.cb.x), cy = mk2(vc.cs.y, vc.cb.y), cz = mk2(vc.cs.z, vc.cb.z);
+  while (live) {
+    Tap taps[KS];
+    f2 dts[KP];
+    bool valid[KS];
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+      const float txa = tx, tya = ty;
+      tx = ty; ty = fminf(tx + mc.shadow_stride, t1);
+      const float txb = tx, tyb = ty;
+      tx = ty; ty = fminf(tx + mc.shadow_stride, t1);
+      valid[2 * p] = tya > txa; valid[2 * p + 1] = tyb > txb;
+      const f2 vtx = mk2(txa, txb), vty = mk2(tya, tyb);
+      dts[p] = vty - vtx;
+      const f2 tm = (vtx + vty) * splat2(0.5f);
+      // pos = org + tm * light; to_object (its clamp to [0, 1] is subsumed, axis_tap2); cell coordinates
+      const f2 px = fma2(tm, lx, ox), py = fma2(tm, ly, oy), pz = fma2(tm, lz, oz);
+      const f2 qx = fma2_sc(px, wx), qy = fma2_sc(py, wy), qz = fma2_sc(pz, wz);
+      tap_coords2(vc, qx, qy, qz, cx, cy, cz, taps[2 * p], taps[2 * p + 1]);
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) tap_loads<VT, AM>(vc, taps[k]);
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+#if OVR_PACKED_LERP
+      const f2 s = tap_finish2<VT>(vc, taps[2 * p], taps[2 * p + 1]);
+#else
+      // the 7 lerps of a tap stay scalar: v_sub + v_fmac cost 1.4 v_fma_f32 issue slots, the packed pair 2.45 for two - and the pairs would
+      // have to be assembled with moves first (tools/ubench_valu.hip, profiles/r03_notes.md)
+      const f2 s = mk2(tap_finish<VT>(vc, taps[2 * p]), tap_finish<VT>(vc, taps[2 * p + 1]));
+#endif
+      const f2 a = tf_alpha2(tf, s);
+      // opacity correction (shaders_raymarching.cu:118-122), branch-free: both transcendentals always run (the shadow stride is never
+      // 1 / base in practice), the select keeps a exactly where the reference's branch does
+      const f2 adj = splat2(mc.base) * dts[p];
+      const f2 lg = mk2(__builtin_amdgcn_logf(1.f - a.x), __builtin_amdgcn_logf(1.f - a.y));
+      const f2 pl = adj * lg;
+      const float ca = clamp01(1.f - __builtin_amdgcn_exp2f(pl.x)), cb = clamp01(1.f - __builtin_amdgcn_exp2f(pl.y));
+      const float aa = (fabsf(adj.x - 1.f) < 1e-7f) ? a.x : ca, ab = (fabsf(adj.y - 1.f) < 1e-7f) ? a.y : cb;
+      live = live && valid[2 * p] && (alpha < 0.9999f);
+      alpha = live ? fmaf(1.f - alpha, aa, alpha) : alpha;
+      n_shadow += live ? 1u : 0u;
+      live = live && valid[2 * p + 1] && (alpha < 0.9999f);
+      alpha = live ? fmaf(1.f - alpha, ab, alpha) : alpha;
+      n_shadow += live ? 1u : 0u;
+    }
+  }
+  return alpha;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // the ray-march kernels
 //
@@ -619,12 +827,13 @@ __host__ inline size_t table_lds_bytes(const RayMarchParams& p, int am)
 __device__ __forceinline__ void stage_tf(const RayMarchParams& P, unsigned char* tf_base, bool with_color, TfConsts& tf)
 {
   float4* lc = reinterpret_cast<float4*>(tf_base);
-  float* la = reinterpret_cast<float*>(tf_base + (with_color ? (size_t)P.n_color * sizeof(float4) : 0));
+  float* la = reinterpret_cast<float*>(tf_base + (with_color ? (size_t)(P.n_color + 1) * sizeof(float4) : 0));
   if (with_color) {
     const float4* gc = reinterpret_cast<const float4*>(P.tf_color);
-    for (int i = threadIdx.x; i < P.n_color; i += kBlock) lc[i] = gc[i];
+    for (int i = threadIdx.x; i <= P.n_color; i += kBlock) lc[i] = gc[min(i, P.n_color - 1)]; // one more entry, a copy of the last (tf_color)
   }
   for (int i = threadIdx.x; i < P.n_alpha; i += kBlock) la[i] = P.tf_alpha[i];
+  if (threadIdx.x == 0) la[P.n_alpha] = P.tf_alpha[P.n_alpha - 1]; // one more entry, a copy of the last: (i, i + 1) is clamp-to-edge (tf_alpha)
   __syncthreads();
   tf.color = lc;
   tf.alpha = la;
@@ -687,7 +896,10 @@ __device__ __forceinline__ void shade_request(const RayMarchParams& P, const Vol
                          fmaf(n_w.x, m[2], fmaf(n_w.y, m[5], n_w.z * m[8]))));
   }
   float shadow = 0.f;
-  if (SHADE == 2) shadow = march_shadow<VT, AM, kShadowTaps, SKIP>(vc, tf, mc, pos, n_shadow, n_shadow_skipped);
+  if (SHADE == 2) {
+    if (OVR_SHADOW_PACKED && !SKIP) shadow = march_shadow_packed<VT, AM, kShadowTaps>(vc, tf, mc, pos, n_shadow);
+    else shadow = march_shadow<VT, AM, kShadowTaps, SKIP>(vc, tf, mc, pos, n_shadow, n_shadow_skipped);
+  }
   const float cosNL = fabsf(dot3(mc.light, n_w));
   const float shade = 0.5f + 0.5f * cosNL * 2.f * (1.f - shadow); // shaders_raymarching.cu:156-157
   const float tr = r.tr;

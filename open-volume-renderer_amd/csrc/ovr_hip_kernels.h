@@ -9,8 +9,10 @@ namespace ovrhip {
 
 // device-resident scalar types of the bricked volume (u32/i32/f64 inputs are converted at upload, see relayout)
 // VOX_*_T / VOX_*_TT are not further scalar types but further LAYOUTS of a resident f32 / u16 volume ("thin" replicas, below)
-enum VoxelType : int { VOX_U8 = 0, VOX_I8 = 1, VOX_U16 = 2, VOX_I16 = 3, VOX_F32 = 4, VOX_F32_T = 5, VOX_F32_TT = 6, VOX_U16_T = 7, VOX_U16_TT = 8 };
-enum VolumeLayout : int { LAYOUT_GENERAL = 0, LAYOUT_THIN = 1, LAYOUT_THIN_T = 2 };
+// VOX_F32_Q is the "quad" layout of a resident f32 volume (below)
+enum VoxelType : int { VOX_U8 = 0, VOX_I8 = 1, VOX_U16 = 2, VOX_I16 = 3, VOX_F32 = 4, VOX_F32_T = 5, VOX_F32_TT = 6, VOX_U16_T = 7, VOX_U16_TT = 8, VOX_F32_Q = 9 };
+enum VolumeLayout : int { LAYOUT_GENERAL = 0, LAYOUT_THIN = 1, LAYOUT_THIN_T = 2, LAYOUT_QUAD = 3 };
+constexpr int kLayouts = 4;
 
 // Volume layout in HBM ("x-apron bricks in macro blocks"):
 //   voxels are grouped into 128-byte bricks = one L1/L2 line.  A brick covers CX x 4 x (2|4) cells and stores CX+1 voxels
@@ -29,7 +31,15 @@ enum VolumeLayout : int { LAYOUT_GENERAL = 0, LAYOUT_THIN = 1, LAYOUT_THIN_T = 2
 //   across: thin across the rays, 4-8 steps deep along them.  VOX_*_T has the pair axis on x (for rays along y or z), VOX_*_TT
 //   is the same layout of the volume with x and y exchanged (pair axis = the volume's y; for rays along x).  The tap reads the
 //   same 8 voxels and lerps them in the same order from any layout, so frames are bit-identical; the host picks the replica
-//   per frame from the camera direction (ovr_hip_api.cpp: choose_layout).  Measured: profiles/r02_notes.md.
+//   per frame from the camera direction (ovr_hip_api.cpp: enqueue_frame).  Measured: profiles/r02_notes.md.
+//
+// Quad replica (round 3; f32): every cell (x, y, z) stores the four voxels (x, y), (x+1, y), (x, y+1), (x+1, y+1) of its z slice as
+//   16 contiguous bytes (clamp-to-edge baked in), 2 x 2 x 2 cells per 128-byte brick, 16^3 bricks per macro block - 4 x the memory.
+//   A trilinear tap is TWO 16-byte loads (cell z0 and cell z0 + 1) instead of four 8-byte pair loads.  The frames in which every
+//   sample is shaded - most of the reference's shipped scenes, and every frame at the scene files' sampling rate 4 - are bound by the
+//   texture addresser's instruction rate (16+ clocks per 64-lane gather whatever its width; TA / TD busy 84-97 %, VALU 80-100 %,
+//   profiles/r03_notes.md): half the gathers and three fewer address adds per tap are what moves them.  Same 8 voxels, same lerp
+//   order: frames are bit-identical.
 struct VolumeDesc {
   const void* data;
   int type;        // VoxelType (of this replica: the base type, or its _T / _TT variant)

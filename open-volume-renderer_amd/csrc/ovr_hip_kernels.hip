@@ -249,7 +249,8 @@ hipError_t launch_schedule(const RayMarchParams& p, const unsigned int* src, uns
 size_t raymarch_lds_bytes(int n_color, int n_alpha)
 {
   // the transfer function always lives in LDS; 0 = does not fit next to the request queues (caller reports an error)
-  const size_t need = (size_t)n_color * sizeof(float4) + (size_t)n_alpha * sizeof(float);
+  // (+ 32: both tables carry one more entry, a copy of their last one - stage_tf)
+  const size_t need = (size_t)n_color * sizeof(float4) + (size_t)n_alpha * sizeof(float) + 32;
   return need <= 96 * 1024 ? need : 0;
 }
 
@@ -281,6 +282,7 @@ extern template hipError_t launch_v<VOX_F32_T>(const RayMarchParams&, hipStream_
 extern template hipError_t launch_v<VOX_F32_TT>(const RayMarchParams&, hipStream_t, const hipEvent_t*);
 extern template hipError_t launch_v<VOX_U16_T>(const RayMarchParams&, hipStream_t, const hipEvent_t*);
 extern template hipError_t launch_v<VOX_U16_TT>(const RayMarchParams&, hipStream_t, const hipEvent_t*);
+extern template hipError_t launch_v<VOX_F32_Q>(const RayMarchParams&, hipStream_t, const hipEvent_t*);
 
 size_t pool_shade_blocks() { return kShadeBlocks; }
 
@@ -299,6 +301,7 @@ hipError_t launch_raymarch(const RayMarchParams& p, hipStream_t stream, const hi
   case VOX_F32_TT: e = launch_v<VOX_F32_TT>(p, stream, ev); break;
   case VOX_U16_T: e = launch_v<VOX_U16_T>(p, stream, ev); break;
   case VOX_U16_TT: e = launch_v<VOX_U16_TT>(p, stream, ev); break;
+  case VOX_F32_Q: e = launch_v<VOX_F32_Q>(p, stream, ev); break;
   default: e = hipErrorInvalidValue;
   }
   if (ev) (void)hipEventRecord(ev[3], stream);
@@ -330,7 +333,7 @@ size_t voxel_size(int vt)
 int replica_voxel_type(int base, int layout)
 {
   if (layout == LAYOUT_GENERAL) return base;
-  if (base == VOX_F32) return layout == LAYOUT_THIN ? VOX_F32_T : layout == LAYOUT_THIN_T ? VOX_F32_TT : -1;
+  if (base == VOX_F32) return layout == LAYOUT_THIN ? VOX_F32_T : layout == LAYOUT_THIN_T ? VOX_F32_TT : layout == LAYOUT_QUAD ? VOX_F32_Q : -1;
   if (base == VOX_U16) return layout == LAYOUT_THIN ? VOX_U16_T : layout == LAYOUT_THIN_T ? VOX_U16_TT : -1;
   return -1;
 }
@@ -363,6 +366,33 @@ __global__ __launch_bounds__(256) void relayout_kernel(const TI* __restrict__ sr
   const unsigned m = M::div_mbx(br), bm = br - m * Vox<VT>::mbx;
   const unsigned long long off = (unsigned long long)(ar + bm * M::BV + m * M::MV) + M::Y((unsigned)b, macro_y) + M::Zlo(z) + (unsigned long long)(z >> 5) * macro_z;
   dst[off] = Conv<TI, TO>::cv(v);
+}
+
+// quad replica: one thread per cell writes the cell's 2 x 2 (x, y) voxels of its z slice as one float4, neighbours beyond the
+// grid replaced by the last voxel (clamp-to-edge addressing)
+template <typename TI>
+__global__ __launch_bounds__(256) void relayout_quad_kernel(const TI* __restrict__ src, float* __restrict__ dst, int nx, int ny, unsigned int macro_y, unsigned long long macro_z,
+                                                           int z0, int nz_chunk)
+{
+  typedef BrickMap<VOX_F32_Q> M;
+  const int x = (int)(blockIdx.x * 256u + threadIdx.x), y = (int)blockIdx.y, zl = (int)blockIdx.z;
+  if (x >= nx || zl >= nz_chunk) return;
+  const int x1 = min(x + 1, nx - 1), y1 = min(y + 1, ny - 1);
+  const TI* sl = src + (size_t)nx * (size_t)ny * (size_t)zl;
+  float4 q;
+  q.x = Conv<TI, float>::cv(sl[x + (size_t)nx * y]); q.y = Conv<TI, float>::cv(sl[x1 + (size_t)nx * y]);
+  q.z = Conv<TI, float>::cv(sl[x + (size_t)nx * y1]); q.w = Conv<TI, float>::cv(sl[x1 + (size_t)nx * y1]);
+  const unsigned z = (unsigned)(z0 + zl);
+  const unsigned long long off = (unsigned long long)(M::X((unsigned)x) + M::Y((unsigned)y, macro_y)) + M::Zlo(z) + (unsigned long long)(z >> 5) * macro_z;
+  *reinterpret_cast<float4*>(dst + off) = q;
+}
+template <typename TI>
+static hipError_t relayout_quad_t(const void* src, void* dst, const VolumeDesc& vd, int z0, int nzc, hipStream_t stream)
+{
+  dim3 grid((unsigned)((vd.nx + 255) / 256), (unsigned)vd.ny, (unsigned)nzc);
+  hipLaunchKernelGGL(relayout_quad_kernel<TI>, grid, dim3(256), 0, stream, (const TI*)src, (float*)dst, vd.nx, vd.ny, vd.macro_elems * (unsigned)vd.macros_x,
+                     (unsigned long long)vd.macro_elems * (unsigned long long)vd.macros_x * (unsigned long long)vd.macros_y, z0, nzc);
+  return hipGetLastError();
 }
 
 template <typename TI, typename TO, int VT>
@@ -402,6 +432,7 @@ void volume_layout(int voxel_type, int nx, int ny, int nz, VolumeDesc& vd)
   case VOX_F32_TT: volume_layout_t<VOX_F32_TT>(nx, ny, nz, vd); break;
   case VOX_U16_T: volume_layout_t<VOX_U16_T>(nx, ny, nz, vd); break;
   case VOX_U16_TT: volume_layout_t<VOX_U16_TT>(nx, ny, nz, vd); break;
+  case VOX_F32_Q: volume_layout_t<VOX_F32_Q>(nx, ny, nz, vd); break;
   default: volume_layout_t<VOX_F32>(nx, ny, nz, vd); break;
   }
 }
@@ -413,6 +444,7 @@ static hipError_t relayout_f32(const void* src, void* dst, const VolumeDesc& vd,
   case VOX_F32: return relayout_t<TI, float, VOX_F32>(src, dst, vd, z0, nzc, stream);
   case VOX_F32_T: return relayout_t<TI, float, VOX_F32_T>(src, dst, vd, z0, nzc, stream);
   case VOX_F32_TT: return relayout_t<TI, float, VOX_F32_TT>(src, dst, vd, z0, nzc, stream);
+  case VOX_F32_Q: return relayout_quad_t<TI>(src, dst, vd, z0, nzc, stream);
   default: return hipErrorInvalidValue;
   }
 }
@@ -481,6 +513,7 @@ hipError_t launch_axis_tables(VolumeDesc& vd, void* d_tables, hipStream_t stream
   case VOX_F32_TT: return axis_tables_t<VOX_F32_TT>(vd, ab, tz, stream);
   case VOX_U16_T: return axis_tables_t<VOX_U16_T>(vd, ab, tz, stream);
   case VOX_U16_TT: return axis_tables_t<VOX_U16_TT>(vd, ab, tz, stream);
+  case VOX_F32_Q: return axis_tables_t<VOX_F32_Q>(vd, ab, tz, stream);
   default: return hipErrorInvalidValue;
   }
 }

@@ -217,7 +217,8 @@ class DeviceHIP:
         L.check(self._lib.ovr_hip_set_volume_layouts(self._h, int(mode)))
 
     def set_layout_choice(self, choice):
-        """-1 (default): the layout a frame reads follows the camera direction; 0 / 1 / 2: forced.  Frames are bit-identical."""
+        """-1 (default): automatic (camera direction; the quad replica for frames that shade every sample); 0 / 1 / 2 / 3: forced
+        (general, thin, thin transposed, quad).  Frames are bit-identical."""
         L.check(self._lib.ovr_hip_set_layout_choice(self._h, int(choice)))
 
     def set_grid_convention(self, convention):

@@ -51,21 +51,25 @@ for name in sorted(f for f in os.listdir(SCENES) if f.endswith('.json') and pick
     alphas = np.stack([np.linspace(0.0, 1.0, n, dtype=np.float32), d['tfn_opacity'].astype(np.float32)], axis=1).ravel()
     eye, at, up, fovy = d['camera']
     ren = ovr.create_renderer('hip')
-    ren.set_fbsize((1920, 1080)); ren.set_frame_accumulation(True); ren.set_sample_per_pixel(1); ren.set_volume_sampling_rate(1.0); ren.set_shading(2)
+    ren.set_fbsize((1920, 1080)); ren.set_frame_accumulation(True); ren.set_sample_per_pixel(1); ren.set_shading(2)
     ren.set_transfer_function(colors, alphas, d['value_range'])
     ren.set_shading_pipeline(int(os.environ.get('OVR_SCENE_PIPELINE', '0')))   # 0 automatic, 1 in place, 2 pooled
-    ren.init(ovr.Scene(volume=vol, grid_origin=d['grid_origin'], grid_spacing=d['grid_spacing'], transfer_function=None, volume_sampling_rate=1.0), ovr.Camera(eye, at, up))
+    ren.set_layout_choice(int(os.environ.get('OVR_SCENE_LAYOUT', '-1')))       # -1 automatic, 0 general, 1 thin, 2 thin transposed, 3 quad
+    rate = float(os.environ.get('OVR_SCENE_RATE', '1.0'))                       # renderbatch renders rate 1; the scene files say 4
+    ren.set_volume_sampling_rate(rate)
+    ren.init(ovr.Scene(volume=vol, grid_origin=d['grid_origin'], grid_spacing=d['grid_spacing'], transfer_function=None, volume_sampling_rate=rate), ovr.Camera(eye, at, up))
     ren.set_camera(eye, at, up)
     res = {}
-    for skip in (False, True):
+    for skip in ((False, True) if os.environ.get('OVR_SCENE_SKIP_LEG', '1') != '0' else (False, False)):
         ren.set_empty_space_skipping(skip); ren.commit()
-        for _ in range(3):
+        for _ in range(int(os.environ.get('OVR_SCENE_WARMUP', '3'))):
             ren.render()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10):
             ren.render()
         torch.cuda.synchronize()
         res[skip] = ((time.perf_counter() - t0) / 10 * 1e3, ren.stats())
+    res.setdefault(True, res[False])
     st0, st1 = res[False][1], res[True][1]
     tot = st1.samples + st1.skipped_samples
     print(f"{name:36s} {'x'.join(map(str, dims)):>16s} {str(dtype):>7s} {res[False][0]:9.3f} {res[True][0]:8.3f} {1e3 / res[True][0]:10.0f}  {st0.layout:6d} {st0.samples / 1e6:9.1f} {st0.shaded_samples / 1e6:7.1f} "

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(16)));
 
 template <int W>
 __global__ __launch_bounds__(256) void gather(const float* __restrict__ base, const unsigned* __restrict__ idx, float* out, int iters)
@@ -15,6 +16,7 @@ __global__ __launch_bounds__(256) void gather(const float* __restrict__ base, co
   float acc = 0.f;
   for (int i = 0; i < iters; ++i) {
     if (W == 1) acc += base[o];
+    else if (W == 4) { f4u v = *(const f4u*)(base + (o & ~3u)); acc += v.x + v.y + v.z + v.w; } // 16-byte aligned (round 3: the quad layout's loads)
     else { f2u v = *(const f2u*)(base + o); acc += v.x + v.y; }
     o = (o + 32u * 97u + (unsigned)(acc == 123.456f)) & 4095u; // move every lane by 97 lines inside a 16 KiB window: pattern preserved
   }
@@ -30,7 +32,7 @@ int main()
   float* out; CK(hipMalloc(&out, T * 4));
   std::vector<unsigned> h(T);
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-  printf("lines/instr  arrangement      dword clk/instr   dwordx2 clk/instr\n");
+  printf("lines/instr  arrangement      dword clk/instr   dwordx2 clk/instr   dwordx4 clk/instr\n");
   for (int consecutive = 1; consecutive >= 0; --consecutive)
     for (int nl : {1, 2, 4, 8, 16, 32, 64}) {
       // nl distinct lines per wave; lanes sharing a line are consecutive lanes (consecutive=1) or strided (lane % nl)
@@ -42,7 +44,10 @@ int main()
         h[t] = ((wave * 7u + line * 5u) % 128u) * 32u + (within % 30u);
       }
       CK(hipMemcpy(idx, h.data(), T * 4, hipMemcpyHostToDevice));
-      float ms1, ms2;
+      float ms1, ms2, ms4;
+      gather<4><<<blocks, 256>>>(d, idx, out, 8); CK(hipDeviceSynchronize());
+      CK(hipEventRecord(a)); gather<4><<<blocks, 256>>>(d, idx, out, iters); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+      CK(hipEventElapsedTime(&ms4, a, b));
       gather<1><<<blocks, 256>>>(d, idx, out, 8); CK(hipDeviceSynchronize());
       CK(hipEventRecord(a)); gather<1><<<blocks, 256>>>(d, idx, out, iters); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
       CK(hipEventElapsedTime(&ms1, a, b));
@@ -50,7 +55,8 @@ int main()
       CK(hipEventRecord(a)); gather<2><<<blocks, 256>>>(d, idx, out, iters); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
       CK(hipEventElapsedTime(&ms2, a, b));
       const double winstr = (double)T / 64 * iters / 256; // wave-instructions per CU
-      printf("%6d       %-14s  %8.1f          %8.1f\n", nl, consecutive ? "consecutive" : "interleaved", ms1 * 1e-3 * 2.4e9 / winstr, ms2 * 1e-3 * 2.4e9 / winstr);
+      printf("%6d       %-14s  %8.1f          %8.1f          %8.1f\n", nl, consecutive ? "consecutive" : "interleaved", ms1 * 1e-3 * 2.4e9 / winstr, ms2 * 1e-3 * 2.4e9 / winstr,
+             ms4 * 1e-3 * 2.4e9 / winstr);
     }
   return 0;
 }
