@@ -169,8 +169,10 @@ def launch_ranks(args):
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # (torch.distributed.run's own parser takes a bare `--n` for an abbreviation of its options, even behind the script's name)
+    fwd = ["--edge" if a == "--n" else a for a in sys.argv[1:]]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), os.path.abspath(__file__)] + fwd
     return subprocess.call(cmd, env=env)
 
 
@@ -184,7 +186,7 @@ def main():
     ap.add_argument("--tf", default=None, choices=["sparse", "dense", "bumps", "opaque"])
     ap.add_argument("--shading", type=int, default=None, choices=[0, 1, 2])
     ap.add_argument("--dtype", default=None, choices=sorted(VOXEL_BYTES), help="voxel type override (exploration: the named configurations fix it)")
-    ap.add_argument("--n", type=int, default=None, help="volume edge override (exploration)")
+    ap.add_argument("--n", "--edge", dest="n", type=int, default=None, help="volume edge override (exploration; --edge is the same option)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile", type=int, default=16, help="image-shard tile size in pixels (16: best balance over 8 ranks, tools/shard_balance.py)")
     ap.add_argument("--no-skip-leg", action="store_true", help="do not time the extra leg with empty-space skipping (N = 1 only)")
@@ -239,6 +241,11 @@ def worker(args, world):
         backend = os.environ.get("OVR_BENCH_BACKEND", "nccl")
         if os.environ.get("OVR_BENCH_ONE_GPU") == "1":
             local_rank = 0
+        n_dev = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+        if local_rank >= n_dev:
+            # a fresh process that has not touched the GPU: say what is wrong and leave - the launcher ends the other ranks
+            raise SystemExit(f"bench.py: rank {rank} has LOCAL_RANK {local_rank} but this node shows {n_dev} GPU(s) "
+                             f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')}, ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES')})")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -484,6 +491,31 @@ def worker(args, world):
         set_cam()
         ren.commit()
 
+    # the N > 1 line explains itself: per rank the kernel phases, the steps beside the rendering, the work and the elapsed time
+    rank_report = None
+    if dist is not None:
+        torch.cuda.synchronize()
+        gt = gatherer.collect_times() if gatherer is not None else {}
+        mine = torch.tensor([phase_ms[0] / args.steps, phase_ms[1] / args.steps, phase_ms[2] / args.steps, kernel_ms / args.steps,
+                             gt.get("pack", 0.0), gt.get("gather", 0.0), gt.get("gather_wait", 0.0), gt.get("unpack", 0.0),
+                             dt / args.steps * 1e3, tot["samples"] / args.steps, tot["shaded_samples"] / args.steps, tot["shadow_samples"] / args.steps,
+                             tot["active_pixels"] / args.steps, float(torch.cuda.device_count()), float(last_stats.layout), float(last_stats.pipeline)],
+                            dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(allr, mine)
+        if rank == 0:
+            cols = ["march_ms", "shade_ms", "composite_ms", "kernel_ms", "pack_ms", "gather_ms", "gather_wait_ms", "unpack_ms", "step_ms",
+                    "samples", "shaded_samples", "shadow_samples", "active_pixels", "device_count", "layout", "pipeline"]
+            tab = np.array([a.cpu().numpy() for a in allr])
+            rank_report = {c: {"min": float(tab[:, i].min()), "mean": float(tab[:, i].mean()), "max": float(tab[:, i].max())} for i, c in enumerate(cols[:9])}
+            rank_report["per_rank"] = {c: [float(v) for v in tab[:, i]] for i, c in enumerate(cols)}
+            work = tab[:, 9] + 3.0 * tab[:, 10] + tab[:, 11]   # taps: primary + 3 per shaded sample + shadow
+            rank_report["work_imbalance_max_over_mean"] = float(work.max() / max(work.mean(), 1e-30))
+            rank_report["kernel_imbalance_max_over_mean"] = float(tab[:, 3].max() / max(tab[:, 3].mean(), 1e-30))
+            rank_report["payload_bytes_per_rank"] = int(gatherer.payload_bytes) if gatherer is not None else 0
+            rank_report["gather_note"] = ("gather_ms = the collective as each rank's communication stream sees it (includes waiting for the slowest rank); "
+                                          "gather_wait_ms = what the render stream stalls on it (the gather of frame i overlaps the rendering of frame i+1); "
+                                          "unpack_ms is rank 0's scatter of all payloads")
     # max over ranks of the elapsed time, sum over ranks of the work
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -558,6 +590,8 @@ def worker(args, world):
         if multi:
             out["rccl_ranks"] = dist.get_world_size()
             out["backend"] = dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")
+            out["device_count"] = torch.cuda.device_count()
+            out["ranks"] = rank_report
         if views is not None:
             out["roofline"]["views"] = views
         if variants:

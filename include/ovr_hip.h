@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OVR_HIP_ABI_VERSION 6
+#define OVR_HIP_ABI_VERSION 7
 
 /* error codes */
 #define OVR_HIP_OK 0
@@ -74,7 +74,7 @@ typedef struct ovr_hip_stats {
   uint64_t pool_chunks;     /* pooled pipeline: 2 KiB request chunks used by the frame                         */
   uint64_t skipped_samples; /* empty-space skipping: primary iterations whose voxel fetch was skipped (not in `samples`) */
   uint64_t skipped_shadow_samples; /* same for shadow-march iterations (not in `shadow_samples`)                 */
-  int32_t layout;           /* which resident layout of the volume the frame read: 0 general, 1 thin, 2 thin transposed */
+  int32_t layout;           /* which resident layout of the volume the frame read: 0 general, 1 thin, 2 thin transposed, 3 quad */
   int32_t stale_tiles;      /* 1: this frame was rendered again (request-pool overflow) AFTER ovr_hip_pack_tiles had packed it - discard that payload */
   uint64_t lds_fallback_taps;   /* LDS-staged bricks: taps of live samples that fell outside the staged box (read from L1/L2 instead) */
   uint64_t lds_unstaged_rounds; /* LDS-staged bricks: workgroup rounds whose box exceeded the LDS budget (ordinary path)            */
@@ -82,7 +82,9 @@ typedef struct ovr_hip_stats {
   int32_t skipping_kernels;     /* 1: the frame ran the empty-space-skipping kernels; 0: the plain ones - skipping disabled, or enabled but
                                    suspended because the last probed frame skipped < 10 % of its sample steps (probed again after 32 ... 256
                                    frames and on every transfer-function / volume change; the frames are bit-identical either way)      */
-  int32_t reserved0;
+  int32_t tuning;               /* automatic layout / pipeline (ABI v7): 0 = the frame ran what the rules say (camera direction, share of
+                                   shaded samples), 1 = it was a probe (a shade-heavy configuration: the other pipeline and the general / quad
+                                   layouts are timed, two frames each), 2 = it ran the measured winner (kept until the configuration changes) */
 } ovr_hip_stats;
 
 const char* ovr_hip_last_error(void);
@@ -103,15 +105,26 @@ int ovr_hip_set_stream(ovr_hip_renderer* r, void* hip_stream);
 int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int value_type, const int32_t dims[3],
                        const float grid_origin[3], const float grid_spacing[3]);
 int ovr_hip_set_grid_convention(ovr_hip_renderer* r, int convention);
+/* diagnostic, pure host arithmetic (no device needed): the addressing mode the kernels would take for a volume of these dimensions and
+ * type in the given layout (0 general ... 3 quad) with a transfer function of n_colors / n_alphas entries: 0 = 32-bit byte offsets,
+ * 1 = 32-bit element offsets, 2 = 64-bit z table in LDS, 3 = computed 64-bit offsets (per-axis tables would not fit in the 160 KiB of LDS
+ * next to the transfer function and the request queues: a dimension of tens of thousands of voxels).  < 0: no such layout for the type. */
+int ovr_hip_query_addressing_mode(const int32_t dims[3], int value_type, int32_t layout, int32_t n_colors, int32_t n_alphas);
 /* extension (MI355X: 288 GB of HBM traded for bandwidth): which layouts of the volume ovr_hip_set_volume keeps resident.
  * Besides the general layout (128-byte 3-D bricks) two "thin" replicas serve views whose rays run along a volume axis - 12 of
  * the reference's 21 shipped scene cameras - where rays are sparser than voxels and a general brick is mostly wasted (C3 front
  * view: 2.18 -> 1.69 ms per frame).  Frames are bit-identical whatever layout is read.  mode 0 = general only, 1 (default) =
  * thin replicas for float / uint16 volumes when all replicas fit in 40 % of the free HBM (x 3 - 4 of the volume's size),
- * 2 = always.  Takes effect at the next ovr_hip_set_volume. */
+ * 2 = always.  Takes effect at the next ovr_hip_set_volume.
+ * Round 3: float volumes get a fourth layout under the same rule, the "quad" replica - every cell stores its 2 x 2 (x, y) voxels as 16
+ * contiguous bytes (4 x the volume's size), so a trilinear tap is two 16-byte loads instead of four 8-byte ones.  Frames that shade every
+ * sample (most shipped scenes; every frame at the scene files' sampling rate 4) are bound by the gather-instruction rate: -7 ... -16 % there. */
 int ovr_hip_set_volume_layouts(ovr_hip_renderer* r, int32_t mode);
-/* which resident layout a frame reads: -1 (default) = chosen per frame from the camera direction (thin within ~18 degrees of
- * an axis), 0 / 1 / 2 = forced (general if that replica is not resident).  Applied at commit; does not reset the accumulation. */
+/* which resident layout a frame reads: -1 (default) = automatic - from the camera direction (a thin replica within ~21 degrees of an
+ * axis, cos >= 0.93) and, for configurations whose shading taps outnumber their primary taps, MEASURED: the frames after the first try the
+ * other pipeline and the general / quad layouts, two frames each, and the fastest is kept until the configuration changes
+ * (ovr_hip_stats.tuning; OVR_HIP_TUNE=0 disables the measuring).  0 / 1 / 2 / 3 = forced: general, thin, thin transposed, quad (general
+ * if that replica is not resident).  Applied at commit; does not reset the accumulation - every layout gives the same frame bit for bit. */
 int ovr_hip_set_layout_choice(ovr_hip_renderer* r, int32_t choice);
 
 /* replaces MainRenderer::set_transfer_function -> StructuredRegularVolume::set_transfer_function

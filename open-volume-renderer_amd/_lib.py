@@ -19,7 +19,9 @@ SHADE_NONE, SHADE_GRADIENT, SHADE_FULL = 0, 1, 2
 GRID_CELL_CENTRED, GRID_VERTEX_CENTRED = 0, 1
 PIPELINE_AUTO, PIPELINE_IN_PLACE, PIPELINE_POOLED = 0, 1, 2
 JITTER_TEA, JITTER_BLUE_NOISE = 0, 1
-LAYOUT_AUTO, LAYOUT_GENERAL, LAYOUT_THIN, LAYOUT_THIN_T = -1, 0, 1, 2
+LAYOUT_AUTO, LAYOUT_GENERAL, LAYOUT_THIN, LAYOUT_THIN_T, LAYOUT_QUAD = -1, 0, 1, 2, 3
+# the ABI these ctypes structures describe: load() refuses a library of another version (ovr_hip_get_stats would write past them)
+EXPECTED_ABI = 7
 
 
 class Stats(C.Structure):
@@ -45,7 +47,7 @@ class Stats(C.Structure):
         ("lds_unstaged_rounds", C.c_uint64),
         ("lds_rounds", C.c_uint64),
         ("skipping_kernels", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("tuning", C.c_int32),
     ]
 
 
@@ -103,6 +105,7 @@ SYMBOLS = {
     "ovr_hip_tea_floats": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int64]),
     "ovr_hip_set_pixel_jitter": (C.c_int, [_H, C.c_int32]),
     "ovr_hip_set_lds_staging": (C.c_int, [_H, C.c_int32]),
+    "ovr_hip_query_addressing_mode": (C.c_int, [C.POINTER(C.c_int32), C.c_int, C.c_int32, C.c_int32, C.c_int32]),
     "ovr_hip_set_volume_layouts": (C.c_int, [_H, C.c_int32]),
     "ovr_hip_set_layout_choice": (C.c_int, [_H, C.c_int32]),
     "ovr_hip_get_volume_info": (C.c_int, [_H, C.POINTER(VolumeInfo)]),
@@ -136,6 +139,10 @@ def load():
             raise RuntimeError(f"libovr_hip.so does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    abi = lib.ovr_hip_abi_version()
+    if abi != EXPECTED_ABI:
+        raise RuntimeError(f"{LIB_PATH} implements ABI version {abi}, this Python package describes version {EXPECTED_ABI}: rebuild the "
+                           "library (make -C open-volume-renderer_amd/csrc) or update the package")
     _lib = lib
     return lib
 

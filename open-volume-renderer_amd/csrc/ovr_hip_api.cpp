@@ -792,6 +792,8 @@ int finish_frame(ovr_hip_renderer* r)
   }
   r->stats.frame_index = r->frame_index;
   r->stats.skipping_kernels = r->frame_used_skip ? 1 : 0;
+  r->stats.tuning = r->tune_frame >= 0 ? 1 : (r->tune_on && r->tune_state == 2 && (r->tune_layout >= 0 || r->tune_pipeline != 0)) ? 2 : 0;
+  if (r->tune_frame == 0 && r->tune_state == 0) r->stats.tuning = 0; // the first frame of a configuration runs the rules' choice
   if (r->tune_frame >= 0 && r->tune_state < 2) { // measured choice of layout and pipeline (see tune_state)
     static const bool trace = getenv("OVR_HIP_TUNE_TRACE") != nullptr;
     auto& c = r->tune_cand[r->tune_frame];
@@ -1135,6 +1137,18 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
   r->tune_state = 0;
   r->pool_roomy = false; // a pooled frame of THIS volume has to prove the pool (ovr_hip_pack_tiles packs early only then)
   return 0;
+}
+
+int ovr_hip_query_addressing_mode(const int32_t dims[3], int value_type, int32_t layout, int32_t n_colors, int32_t n_alphas)
+{
+  if (!dims || dims[0] < 1 || dims[1] < 1 || dims[2] < 1) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_query_addressing_mode: bad dims");
+  const int vt = device_voxel_type(value_type);
+  if (vt < 0) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_query_addressing_mode: unknown value type");
+  const int rt = replica_voxel_type(vt, layout);
+  if (layout < 0 || layout >= kLayouts || rt < 0) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_query_addressing_mode: the type has no such layout");
+  VolumeDesc vd{};
+  volume_layout(rt, dims[0], dims[1], dims[2], vd);
+  return volume_addressing_mode(vd, n_colors, n_alphas);
 }
 
 int ovr_hip_set_grid_convention(ovr_hip_renderer* r, int c)

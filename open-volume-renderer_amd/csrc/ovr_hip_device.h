@@ -816,6 +816,20 @@ __device__ __forceinline__ size_t stage_tables(const RayMarchParams& P, unsigned
   vc.tab_x = tx; vc.tab_y = tx + na; vc.tab_z = tz;
   return (size_t)(nab + P.vol.nz + 1) * sizeof(unsigned int);
 }
+// Addressing mode of a volume layout: 0 = 32-bit byte offsets (<= 4 GiB), 1 = 32-bit element offsets (< 2^32 stored voxels), 2 = 64-bit z
+// table, 3 = computed 64-bit offsets, no tables.  Modes 0-2 keep the per-axis tables in LDS next to the transfer function and the request
+// queues (32 KiB in the in-place march): a volume with one very long axis - small in bytes, tens of thousands of voxels long - whose
+// tables do not fit in the 160 KiB of a CU takes mode 3 whatever its size (before round 3 only mode 2 fell back, and such a volume was
+// accepted by ovr_hip_set_volume and failed at its first launch).
+__host__ inline int addressing_mode(const VolumeDesc& vd, int n_color, int n_alpha)
+{
+  int am = vd.bytes <= 0x100000000ull ? 0 : (vd.bytes / voxel_size(vd.type) < 0xffffffffull) ? 1 : 2;
+  const size_t tables = am == 2 ? (size_t)(vd.nz + 1) * sizeof(unsigned long long) + (size_t)(vd.nx + vd.ny + 1) * sizeof(unsigned int)
+                                : (size_t)(vd.nx + vd.ny + vd.nz + 2) * sizeof(unsigned int);
+  const size_t fixed = raymarch_lds_bytes(n_color, n_alpha) + (size_t)kWaves * 256 * 32 + 1024; // TF + the largest request queues + slack
+  if ((am == 2 && tables > 64 * 1024) || tables + 16 + fixed > 160 * 1024) am = 3;
+  return am;
+}
 __host__ inline size_t table_lds_bytes(const RayMarchParams& p, int am)
 {
   if (am == 3) return 0;
@@ -1864,9 +1878,8 @@ inline hipError_t launch_vs(const RayMarchParams& p, hipStream_t stream, const h
   // addressing mode: 0 = 32-bit byte offsets (volume <= 4 GiB; largest byte offset = bytes - sizeof(voxel)),
   //                  1 = 32-bit element offsets (< 2^32 stored voxels), 2 = 64-bit z table in LDS,
   //                  3 = 64-bit, computed (axis tables would not fit in LDS next to the queues: a dimension beyond ~8000)
-  int am = p.vol.bytes <= 0x100000000ull ? 0 : (p.vol.bytes / voxel_size(p.vol.type) < 0xffffffffull) ? 1 : 2;
+  int am = addressing_mode(p.vol, p.n_color, p.n_alpha);
   if (const char* f = getenv("OVR_HIP_ADDRESSING")) am = std::max(am, atoi(f)); // diagnostic: a more general mode than needed (tests)
-  if (am == 2 && table_lds_bytes(p, 2) > 64 * 1024) am = 3;
   if (am < 3 && (!p.vol.axis_ab || !p.vol.axis_z)) return hipErrorInvalidValue; // the layout's offset tables (launch_axis_tables)
   switch (am) {
   case 0: return launch_vsb<VT, SHADE, 0>(p, stream, ev);

@@ -25,7 +25,7 @@ constexpr int kLayouts = 4;
 //   layout touches 4 and loses all reuse as soon as rays do not run along x: measured 81 % L1 / 52 % L2 miss rate on the
 //   oblique bench camera), and a tap is 4 pair loads instead of 8 scalar loads.
 //
-// View-dependent replicas (288 GB of HBM buy bandwidth): when the rays of a frame run within ~18 degrees of a volume axis - 12 of
+// View-dependent replicas (288 GB of HBM buy bandwidth): when the rays of a frame run within ~21 degrees of a volume axis (cos >= 0.93) - 12 of
 //   the reference's 21 shipped scene cameras do - and are sparser than the voxels, a general brick is mostly wasted: a ray uses
 //   a 2 x 2 column of it.  A THIN replica stores 1 cell (+ apron) along the pair axis and 4 x 4 (f32) / 4 x 8 (u16) voxels
 //   across: thin across the rays, 4-8 steps deep along them.  VOX_*_T has the pair axis on x (for rays along y or z), VOX_*_TT
@@ -151,6 +151,8 @@ size_t pool_shade_blocks();
 
 // dynamic LDS bytes the ray-march kernel needs for this TF (0 when the TF stays in global memory)
 size_t raymarch_lds_bytes(int n_color, int n_alpha);
+// addressing mode the march / shade kernels take for a layout (0 / 1: 32-bit offsets, 2: 64-bit z table, 3: computed, no LDS tables)
+int volume_addressing_mode(const VolumeDesc& vd, int n_color, int n_alpha);
 // number of workgroups launch_raymarch will use (size of the block_counters workspace / 7)
 size_t raymarch_grid_blocks(const RayMarchParams& p);
 // sorts the n owned blocks of src (bx | by << 16, any order) by descending ray length into dst; uses p's camera and box

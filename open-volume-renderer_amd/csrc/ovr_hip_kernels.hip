@@ -254,6 +254,8 @@ size_t raymarch_lds_bytes(int n_color, int n_alpha)
   return need <= 96 * 1024 ? need : 0;
 }
 
+int volume_addressing_mode(const VolumeDesc& vd, int n_color, int n_alpha) { return addressing_mode(vd, n_color, n_alpha); }
+
 size_t raymarch_grid_blocks(const RayMarchParams& p)
 {
   if (p.sparse_xy) return ((size_t)p.width * p.height + kBlock / 4 - 1) / (kBlock / 4);

@@ -102,21 +102,54 @@ class TileGather:
             t.record_stream(self.comm_stream)   # allocated on one stream, used on both
         self.packed = [torch.cuda.Event() for _ in range(2)]
         self.gathered = [torch.cuda.Event() for _ in range(2)]
+        # timing of the steps beside the rendering (round 3: the first multi-GPU run has to explain itself): event pairs per buffer set,
+        # read back when the set is used again (two frames later - long finished, no host wait): pack, the collective as the
+        # communication stream sees it (it includes waiting for the slowest peer), the render stream's stall on it, the scatter on rank dst
+        ev = lambda: [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        self._t = {k: [ev(), ev()] for k in ("pack", "gather", "gather_wait", "unpack")}
+        self._t_used = {k: [False, False] for k in self._t}
+        self.times_ms = {k: 0.0 for k in self._t}   # sums over the frames whose events have been read
+        self.times_n = {k: 0 for k in self._t}
+        self.payload_bytes = self.payload[0].numel() * 4
         self.index = 0
         self.outstanding = None   # buffer whose gather was enqueued and whose tiles are not scattered yet
         self.render_stream.synchronize()
+
+    def _collect(self, key, b):
+        """elapsed time of the event pair (key, b) of its previous use - two frames ago, complete unless the caller never synchronised"""
+        if self._t_used[key][b]:
+            e0, e1 = self._t[key][b]
+            if e1.query():
+                self.times_ms[key] += e0.elapsed_time(e1)
+                self.times_n[key] += 1
+            self._t_used[key][b] = False
+
+    def collect_times(self):
+        """after a device synchronisation: fold every finished event pair into times_ms; returns per-frame means in ms"""
+        for key in self._t:
+            for b in (0, 1):
+                self._collect(key, b)
+        return {k: (self.times_ms[k] / self.times_n[k] if self.times_n[k] else 0.0) for k in self._t}
 
     def _scatter_outstanding(self):
         from . import _lib as L
         C, ren, b = self.C, self.ren, self.outstanding
         if b is None:
             return
+        self._collect("gather_wait", b)
+        self._t["gather_wait"][b][0].record(self.render_stream)
         self.render_stream.wait_event(self.gathered[b])   # also frees payload[b] for the next pack into it
+        self._t["gather_wait"][b][1].record(self.render_stream)
+        self._t_used["gather_wait"][b] = True
         if self.rank == self.dst:
             with self.torch.cuda.stream(self.render_stream):
                 recv = self.recv[b]
+                self._collect("unpack", b)
+                self._t["unpack"][b][0].record(self.render_stream)
                 L.check(ren._lib.ovr_hip_unpack_all_tiles(ren._h, C.c_void_p(recv.data_ptr()), recv[0].numel() * 4, recv.numel() * 4,
                                                            C.c_void_p(self.frame.data_ptr()), self.frame.numel() * 4))
+                self._t["unpack"][b][1].record(self.render_stream)
+                self._t_used["unpack"][b] = True
         self.outstanding = None
 
     def run(self):
@@ -125,13 +158,21 @@ class TileGather:
         from . import _lib as L
         C, ren, torch = self.C, self.ren, self.torch
         b = self.index & 1
+        self._collect("pack", b)
+        self._collect("gather", b)
         with torch.cuda.stream(self.render_stream):
+            self._t["pack"][b][0].record(self.render_stream)
             L.check(ren._lib.ovr_hip_pack_tiles(ren._h, C.c_void_p(self.payload[b].data_ptr()), self.payload[b].numel() * 4))
+            self._t["pack"][b][1].record(self.render_stream)
+            self._t_used["pack"][b] = True
             self.packed[b].record(self.render_stream)
         self._scatter_outstanding()
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(self.packed[b])
+            self._t["gather"][b][0].record(self.comm_stream)
             dist.gather(self.payload[b], gather_list=self.bufs[b], dst=self.dst)
+            self._t["gather"][b][1].record(self.comm_stream)
+            self._t_used["gather"][b] = True
             self.gathered[b].record(self.comm_stream)
         self.outstanding = b
         self.index += 1

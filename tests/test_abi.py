@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(ovr):
 
 
 def test_stats_struct_layout_matches_header(ovr):
-    # 5 x u64, 2 x f64, 2 x i32, 3 x f64, 3 x u64, 2 x i32, 3 x u64, 2 x i32 (ABI v6: skipping_kernels + reserved)
+    # 5 x u64, 2 x f64, 2 x i32, 3 x f64, 3 x u64, 2 x i32, 3 x u64, 2 x i32 (ABI v6: skipping_kernels; v7: tuning)
     assert C.sizeof(ovr._lib.Stats) == 5 * 8 + 2 * 8 + 2 * 4 + 3 * 8 + 3 * 8 + 2 * 4 + 3 * 8 + 2 * 4
     # the same fields, in the same order, as the header's struct
     import re
@@ -36,6 +36,54 @@ def test_stats_struct_layout_matches_header(ovr):
     body = hdr[hdr.index("typedef struct ovr_hip_stats {"):hdr.index("} ovr_hip_stats;")]
     names = re.findall(r"^\s*(?:uint64_t|int32_t|double)\s+(\w+);", body, flags=re.M)
     assert names == [f[0] for f in ovr._lib.Stats._fields_]
+
+
+def test_ctypes_structs_have_the_size_the_header_gives_them(ovr, tmp_path):
+    """sizeof(ovr_hip_stats) / sizeof(ovr_hip_volume_info) as a C compiler sees include/ovr_hip.h == the ctypes structures' sizes, and the
+    package refuses a library of another ABI version (ovr_hip_get_stats would write past a shorter ctypes buffer)"""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "probe.c"
+    src.write_text('#include <stdio.h>\n#include "ovr_hip.h"\nint main(void) { printf("%zu %zu %d\\n", sizeof(ovr_hip_stats), sizeof(ovr_hip_volume_info), OVR_HIP_ABI_VERSION); return 0; }\n')
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "probe")])
+    s_stats, s_info, abi = map(int, subprocess.check_output([str(tmp_path / "probe")], text=True).split())
+    assert C.sizeof(ovr._lib.Stats) == s_stats
+    assert C.sizeof(ovr._lib.VolumeInfo) == s_info
+    assert ovr._lib.EXPECTED_ABI == abi == ovr._lib.load().ovr_hip_abi_version()
+    # a library that reports another version is refused
+    real = ovr._lib._lib
+    try:
+        ovr._lib._lib = None
+        ovr._lib.EXPECTED_ABI = abi + 1
+        with pytest.raises(RuntimeError, match="ABI version"):
+            ovr._lib.load()
+    finally:
+        ovr._lib.EXPECTED_ABI = abi
+        ovr._lib._lib = real
+
+
+def test_addressing_mode_selection(ovr):
+    """which addressing mode the kernels take (host arithmetic only): by the layout's size - and mode 3 (no LDS tables) whenever the per-axis
+    tables would not fit in LDS next to the transfer function and the request queues, for EVERY base mode (a volume small in
+    bytes with one very long axis used to be accepted and then fail at its first launch)"""
+    lib = ovr._lib.load()
+
+    def mode(dims, vt=400, layout=0, nc=1024, na=1024):
+        return lib.ovr_hip_query_addressing_mode((C.c_int32 * 3)(*dims), vt, layout, nc, na)
+
+    assert mode((256, 256, 256), 100) == 0              # C1: 16 MiB
+    assert mode((1024, 1024, 1024)) == 1                # C3 general layout: 5.7 GB, < 2^32 stored voxels
+    assert mode((1024, 1024, 1024), layout=3) == 2      # its quad replica: 2^32 floats
+    assert mode((2048, 2048, 2048), 200) == 2           # C4: 11.4 G stored voxels
+    assert mode((512, 512, 304), layout=3) == 0         # scene_lung's quad replica: 1.3 GB
+    assert mode((40000, 8, 8)) == 3                     # 10 MB, but 160 KB of x table: computed offsets
+    assert mode((8, 8, 30000), 100) == 3
+    assert mode((20000, 8, 8)) == 0                     # 80 KB of tables still fit
+    assert mode((20000, 8, 8), nc=4096, na=4096) == 3   # ... not next to an 80 KiB transfer function
+    assert mode((64, 64, 64), 100, layout=1) < 0        # 8-bit volumes have no thin replicas
+    assert mode((64, 64, 64), 200, layout=3) < 0        # 16-bit volumes have no quad replica
 
 
 def test_no_cpu_fallback(ovr):

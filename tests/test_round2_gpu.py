@@ -234,10 +234,31 @@ def test_bench_launches_its_own_ranks(tmp_path):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"].startswith("gloo") and d["value"] > 0
     assert d["per_frame"]["rays"] == 256 * 256
+    # round 3: the N > 1 line carries what a first multi-GPU run needs to explain itself
+    rk = d["ranks"]
+    for c in ("march_ms", "shade_ms", "composite_ms", "pack_ms", "gather_ms", "gather_wait_ms", "step_ms"):
+        assert set(rk[c]) == {"min", "mean", "max"} and rk[c]["max"] >= rk[c]["min"] >= 0.0, c
+    assert len(rk["per_rank"]["samples"]) == 2 and sum(rk["per_rank"]["samples"]) == d["per_frame"]["samples"]
+    assert rk["work_imbalance_max_over_mean"] >= 1.0 and rk["payload_bytes_per_rank"] > 0 and d["device_count"] >= 1
     # a launcher / --gpus mismatch is an error, not a silent single-rank run
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "tiny"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
+
+
+@pytest.mark.parametrize("config,n", [("c4", 96), ("c5", 64)])
+def test_two_ranks_on_one_card_at_the_8_gpu_configurations_shapes(config, n):
+    """the N > 1 path of BASELINE's 8-GPU configurations (C4: u16, 1080p; C5: 4K, blue-noise jitter, accumulation) at a reduced volume
+    edge, two gloo ranks on one card: the frame's work is the sum of the ranks' and the line carries the per-rank report"""
+    env = dict(os.environ, OVR_BENCH_BACKEND="gloo", OVR_BENCH_ONE_GPU="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", config, "--n", str(n), "--steps", "3", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    w, h = (1920, 1080) if config == "c4" else (3840, 2160)
+    assert d["n_gpus"] == 2 and d["per_frame"]["rays"] == w * h and d["dtype"] == ("u16" if config == "c4" else "f32")
+    assert len(d["ranks"]["per_rank"]["kernel_ms"]) == 2 and d["ranks"]["work_imbalance_max_over_mean"] < 1.5
 
 
 # ---- view-dependent volume replicas (thin layouts) ----------------------------------------------------------------------------
@@ -376,7 +397,9 @@ def test_lds_staged_bricks_are_bit_identical(ovr, oracle, hip_renderer_factory, 
     """the unshaded march with its bricks staged through LDS gives the frame of the ordinary march bit for bit (taps outside the
     staged box and rounds that do not fit take the ordinary path), and that frame agrees with the oracle"""
     case = make_case(ovr, oracle, n=n, tf="bumps", cam=cam, size=size, shading=0, spp=spp)
-    ren = hip_setup(ovr, hip_renderer_factory(), case, accumulate=True)
+    ren = hip_renderer_factory()
+    ren.set_layout_choice(0)   # the staged variant exists for the general layout (an axis view would otherwise read a thin replica - and stage nothing)
+    hip_setup(ovr, ren, case, accumulate=True)
     ren.render(); ren.render()
     plain, plain_g = hip_frame(ovr, ren)
     st0 = ren.stats()
@@ -388,7 +411,10 @@ def test_lds_staged_bricks_are_bit_identical(ovr, oracle, hip_renderer_factory, 
     st1 = ren.stats()
     assert np.array_equal(plain, staged) and np.array_equal(plain_g, staged_g)
     assert (st0.samples, st0.shaded_samples, st0.rays) == (st1.samples, st1.shaded_samples, st1.rays)
-    assert st1.skipped_samples == 0 and st0.lds_fallback_taps == 0
+    assert st1.skipped_samples == 0 and st1.lds_fallback_taps == 0      # no tap of the STAGED run fell outside its box
+    assert st0.lds_rounds == 0 and st1.lds_rounds > 0                    # ... and the staged variant did run
+    if cam in ("front", "top"):                                          # rays along an axis: the box of a round fits, bricks ARE staged
+        assert st1.lds_rounds > st1.lds_unstaged_rounds, (st1.lds_rounds, st1.lds_unstaged_rounds)
     ref, _, cnt = oracle_scene(oracle, case).render(frames=2, accumulate=True)
     assert st1.samples == cnt.samples
     compare(oracle, staged, ref, name=f"lds staging {cam}")

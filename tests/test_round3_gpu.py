@@ -1,0 +1,157 @@
+"""Round-3 features through the C ABI against the CPU oracle: the measured choice of layout and pipeline (frames stay bit-identical while
+the renderer probes), the quad replica, the addressing-mode fallback for very long axes, the request-pool proof after an in-place frame,
+the degenerate transfer-function range, the asynchronous host mirror of mapframe."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from helpers import compare, hip_frame, hip_setup, make_case, oracle_scene
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _render_sequence(ovr, ren, n):
+    out = []
+    for _ in range(n):
+        ren.render()
+        st = ren.stats()
+        out.append((hip_frame(ovr, ren)[0], st.tuning, st.layout, st.pipeline, (st.samples, st.shaded_samples, st.shadow_samples)))
+    return out
+
+
+@pytest.mark.parametrize("rate", [1.0, 4.0])
+def test_measured_choice_keeps_the_frames(ovr, oracle, hip_renderer_factory, rate):
+    """A configuration whose shading taps outnumber its primary taps (dense transfer function) makes the renderer time the other pipeline
+    and the general / quad layouts, two frames each, and keep the fastest: every frame of the sequence - probe or not - is the frame a
+    renderer with OVR_HIP_TUNE=0 produces, bit for bit, and agrees with the oracle; a sparse transfer function stays on the rules."""
+    case = make_case(ovr, oracle, n=40, tf="dense", cam="oblique", size=(96, 64), shading=2, rate=rate)
+    os.environ["OVR_HIP_TUNE"] = "0"
+    try:
+        plain = hip_setup(ovr, hip_renderer_factory(), case)
+    finally:
+        del os.environ["OVR_HIP_TUNE"]
+    ref_seq = _render_sequence(ovr, plain, 3)
+    assert [t for _, t, *_ in ref_seq] == [0, 0, 0]
+    plain.close()
+    ren = hip_renderer_factory()
+    ren.set_volume_layouts(2)   # all replicas, whatever the free memory
+    hip_setup(ovr, ren, case)
+    seq = _render_sequence(ovr, ren, 14)
+    tun = [t for _, t, *_ in seq]
+    assert tun[0] == 0 and tun[1] == 1 and tun[-1] == 2, tun          # rules, probes, the measured winner
+    assert 1 in tun and tun.index(2) <= 12, tun                       # at most 1 + 2 * (2 pipelines + 2 more layouts) + 1 frames
+    assert {l for _, t, l, *_ in seq if t == 1} >= {0, 3}, seq        # the general and the quad layout were both tried
+    assert {p for _, t, _, p, _ in seq if t == 1} == {1, 2}           # ... and both pipelines
+    for f, _, _, _, cnt in seq:
+        assert np.array_equal(f, ref_seq[0][0]) and cnt == ref_seq[0][4]
+    o_rgba, _, cnt = oracle_scene(oracle, case).render()
+    assert seq[0][4][0] == cnt.samples and seq[0][4][1] == cnt.shaded_samples
+    compare(oracle, seq[-1][0], o_rgba, name=f"tuned rate {rate}")
+    # a change of the configuration starts over; the decision itself is not an accumulation reset
+    ren.set_camera(ovr.Camera(*ovr.synth.make_camera("front", 40), 60.0))
+    ren.commit()
+    ren.render()
+    assert ren.stats().tuning == 0
+    ren.close()
+    # not shade-heavy: the rules stay in charge
+    case2 = make_case(ovr, oracle, n=40, tf="sparse", cam="oblique", size=(96, 64), shading=1, rate=1.0)
+    ren = hip_setup(ovr, hip_renderer_factory(), case2)
+    assert [t for _, t, *_ in _render_sequence(ovr, ren, 4)] == [0, 0, 0, 0]
+    ren.close()
+
+
+def test_measured_choice_under_accumulation(ovr, oracle, hip_renderer_factory):
+    """probing must not disturb an accumulation: 12 accumulated frames with and without the measuring are the same frame"""
+    case = make_case(ovr, oracle, n=32, tf="dense", cam="front", size=(72, 48), shading=2, rate=2.0)
+    frames = []
+    for tune in ("0", "1"):
+        os.environ["OVR_HIP_TUNE"] = tune
+        try:
+            ren = hip_renderer_factory()
+        finally:
+            del os.environ["OVR_HIP_TUNE"]
+        ren.set_volume_layouts(2)
+        hip_setup(ovr, ren, case, accumulate=True)
+        for _ in range(12):
+            ren.render()
+        frames.append(hip_frame(ovr, ren))
+        assert ren.stats().frame_index == 12 and ren.stats().tuning == (2 if tune == "1" else 0)
+        ren.close()
+    assert np.array_equal(frames[0][0], frames[1][0]) and np.array_equal(frames[0][1], frames[1][1])
+
+
+def test_very_long_axis_takes_computed_addressing(ovr, oracle, hip_renderer_factory):
+    """a volume that is small in bytes but 24 000 voxels long, under a 4096-entry transfer function: the per-axis tables do not
+    fit in LDS next to it, the kernels take mode 3 (computed offsets) instead of failing at their first launch"""
+    dims = (24000, 6, 5)
+    lib = ovr._lib.load()
+    assert lib.ovr_hip_query_addressing_mode((C.c_int32 * 3)(*dims), 100, 0, 4096, 4096) == 3
+    case = make_case(ovr, oracle, dtype=np.uint8, dims=dims, tf="bumps", size=(80, 40), shading=2, tf_n=4096)
+    c = np.array(dims, dtype=np.float64) / 2.0
+    case["cam"] = (tuple(c + np.array((300.0, 40.0, 90.0))), tuple(c), (0.0, 1.0, 0.0))
+    ren = hip_setup(ovr, hip_renderer_factory(), case)
+    ren.render()
+    got, _ = hip_frame(ovr, ren)
+    st = ren.stats()
+    ref, _, cnt = oracle_scene(oracle, case).render()
+    assert (st.samples, st.shaded_samples) == (cnt.samples, cnt.shaded_samples) and cnt.samples > 300 and cnt.shaded_samples > 10
+    compare(oracle, got, ref, name="long axis")
+    ren.close()
+
+
+def test_an_in_place_frame_does_not_prove_the_pool(ovr, oracle, hip_renderer_factory):
+    """an in-place frame followed - with no commit in between - by a pooled frame whose pool is too small: ovr_hip_pack_tiles
+    must resolve the frame (it is rendered again with a larger pool) BEFORE packing; the payload is the final frame, stale_tiles stays 0"""
+    import torch
+    case = make_case(ovr, oracle, n=32, tf="dense", cam="oblique", size=(96, 64), shading=2)
+    ref_ren = hip_setup(ovr, hip_renderer_factory(), case)
+    ref_ren.render()
+    ref, _ = hip_frame(ovr, ref_ren)
+    ref_ren.close()
+    os.environ["OVR_HIP_POOL_CHUNKS"] = "8"
+    os.environ["OVR_HIP_TUNE"] = "0"
+    try:
+        ren = hip_renderer_factory()
+        ren.set_image_shard(0, 1, 16, 16)
+        hip_setup(ovr, ren, case, pipeline=1)
+        slots = ovr.tiles.max_owned_tiles(96, 64, 16, 16, 1)
+        payload = torch.zeros((slots, 16, 16, 4), dtype=torch.float32, device="cuda")
+        ren.render()                                   # in place: no pool involved
+        assert ren.stats().pipeline == 1
+        ren.set_shading_pipeline(2)                    # the same frame, pooled (no accumulation reset, pool never proven)
+        ren.commit()
+        ren.render_async()
+        ovr._lib.check(ren._lib.ovr_hip_pack_tiles(ren._h, C.c_void_p(payload.data_ptr()), payload.numel() * 4))
+        ren.sync()
+        st = ren.stats()
+        assert st.pipeline == 2 and st.pool_chunks > 8 and st.stale_tiles == 0
+    finally:
+        del os.environ["OVR_HIP_POOL_CHUNKS"]
+        del os.environ["OVR_HIP_TUNE"]
+    frame = np.zeros((64, 96, 4), np.float32)
+    ovr.tiles.unpack_tiles_host(payload.cpu().numpy(), frame, 16, 16, 0, 1)
+    assert np.array_equal(frame.reshape(ref.shape), ref)
+    ren.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint8])
+def test_constant_volume_under_the_data_range_fallback(ovr, oracle, hip_renderer_factory, dtype):
+    """a constant volume with the default (invalid) transfer-function range: the data range is one value, the reference's scale is 1 / 0 and its
+    coordinate clamp01(0 * inf) = 0 for every sample - the oracle's fminf / fmaxf give that 0, the device gets it from scale = 0"""
+    case = make_case(ovr, oracle, n=20, dtype=dtype, tf="dense", cam="oblique", size=(48, 32), shading=2)
+    case["vol"] = np.full_like(case["vol"], 7 if np.dtype(dtype) == np.uint8 else 0.25)
+    case["vr"] = (1.0, -1.0)
+    case["alphas"] = case["alphas"].copy()
+    case["alphas"][1] = 0.3          # alpha of entry 0: what every sample must get
+    ren = hip_setup(ovr, hip_renderer_factory(), case)
+    ren.render()
+    got, _ = hip_frame(ovr, ren)
+    st = ren.stats()
+    ref, _, cnt = oracle_scene(oracle, case).render()
+    assert not np.isnan(got).any() and got[..., 3].max() > 0.5
+    assert (st.samples, st.shaded_samples, st.shadow_samples) == (cnt.samples, cnt.shaded_samples, cnt.shadow_samples)
+    compare(oracle, got, ref, name=f"constant volume {np.dtype(dtype).name}")
+    ren.close()

@@ -53,7 +53,9 @@ def compare_visible(O, got, ref, name):
     invisible (its 8-bit alpha is 0).  So: alpha and the PREMULTIPLIED colour must meet the bar everywhere (<= 1 on 8 bits, 2e-4 in
     float), the un-premultiplied colour wherever the pixel is visible at all (8-bit alpha >= 1)."""
     assert not np.isnan(got).any(), f"{name}: NaN in HIP frame"
-    q = lambda x: np.floor(np.clip(x, 0.0, 1.0) * 255.0 + 0.5).astype(np.int32)   # imageio.cpp:146-181 per channel (pinned in tests/test_oracle_vs_ref.py)
+    # the reference's quantiser TRUNCATES, uint8_t(clamp(x, 0, 1) * 255) in float arithmetic (imageio.cpp:162-176; O.rgba8 is pinned to it bit for
+    # bit in tests/test_oracle_vs_ref.py)
+    q = lambda x: (np.clip(np.asarray(x, dtype=np.float32), np.float32(0.0), np.float32(1.0)) * np.float32(255.0)).astype(np.uint8).astype(np.int32)
     da = np.abs(got[..., 3] - ref[..., 3]).max()
     pg, pr = got[..., :3] * got[..., 3:4], ref[..., :3] * ref[..., 3:4]
     dp = np.abs(pg - pr).max()
