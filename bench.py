@@ -17,6 +17,7 @@ import hashlib
 import itertools
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -98,6 +99,44 @@ def kernels_hash():
     return h.hexdigest()[:16]
 
 
+def traffic_key(config, cam, tf, shading, world, rate, fovy, sparse):
+    return f"{config}|{cam}|{tf}|{shading}|{world}|{float(rate)}|{float(fovy)}|{int(bool(sparse))}"
+
+
+N_CU, N_SIMD = 256, 1024
+GATHER_CLK = 16.0      # texture-addresser clocks per 64-lane gather instruction whose quads each stay in one line (tools/ubench_lines.hip)
+VALU_CLK = 4.0         # issue clocks of a VALU instruction of one wave (MI355X_MICROARCH.md; tools/ubench_valu.hip)
+
+
+def kernel_bound(kms, abytes, ctr):
+    """Which resource bounds a kernel, from its PMC counters (profiles/*_traffic.json, mean per dispatch) and its measured duration.
+    Utilisations, each against the ceiling of its own unit: hbm = (FETCH_SIZE x 2 + WRITE_SIZE) / t / 8 TB/s (the L2's memory side, Infinity-
+    Cache hits included); ta = gather instructions x 16 clk / (256 CUs x clocks of the launch): the instruction rate of the texture
+    addressers; valu = vector instructions x 4 clk / (1024 SIMDs x clocks).  The bound is the busiest of the three.  `hbm` is only named
+    when the memory side really moves at least the algorithmic bytes; a kernel whose algorithmic bytes exceed its traffic is served by
+    the caches and its HBM fraction says nothing (no HBM fraction above 1)."""
+    if not ctr or kms <= 0 or "GRBM_GUI_ACTIVE" not in ctr:
+        return None
+    clocks = ctr["GRBM_GUI_ACTIVE"] / 8.0                        # per XCD, over the profiled launch
+    t_prof = ctr.get("mean_ms_rocprof", kms) * 1e-3
+    traffic = (2.0 * ctr.get("FETCH_SIZE", 0.0) + ctr.get("WRITE_SIZE", 0.0)) * 1024.0
+    u = {"hbm": traffic / t_prof / (HBM_PEAK_GBS * 1e9),
+         "ta": ctr.get("SQ_INSTS_VMEM_RD", 0.0) * GATHER_CLK / (N_CU * clocks),
+         "valu": min(ctr.get("SQ_INSTS_VALU", 0.0) * VALU_CLK / (N_SIMD * clocks), 1.0)}
+    bound = max(u, key=lambda k: u[k])
+    if bound == "hbm" and abytes > traffic * 1.02:
+        bound = max(("ta", "valu"), key=lambda k: u[k])
+    out = {"bound": bound, "utilisation": {k: round(v, 4) for k, v in u.items()}, "traffic": traffic, "clock_ghz": clocks / t_prof / 1e9,
+           "l1_fill_bytes": ctr.get("TCP_TCC_READ_REQ_sum", 0.0) * 128.0, "ta_busy": ctr.get("TA_TA_BUSY_sum", 0.0) / (N_CU * clocks)}
+    if bound == "ta":
+        out.update(achieved=ctr["SQ_INSTS_VMEM_RD"] / t_prof / 1e9, peak=N_CU * (clocks / t_prof) / GATHER_CLK / 1e9, unit="G gather instr/s")
+    elif bound == "valu":
+        out.update(achieved=ctr["SQ_INSTS_VALU"] / t_prof / 1e9, peak=N_SIMD * (clocks / t_prof) / VALU_CLK / 1e9, unit="G vector instr/s")
+    if bound != "hbm":
+        out["frac"] = out["achieved"] / out["peak"]
+    return out
+
+
 def load_traffic(key):
     """measured HBM traffic (rocprofv3 PMC: FETCH_SIZE x 2 + WRITE_SIZE, collected by tools/prof.sh + tools/traffic_json.py)
     of this configuration - only if the committed profile was taken from the kernels that are running now"""
@@ -114,8 +153,7 @@ def load_traffic(key):
                 continue
             ent = doc.get("entries", {}).get(key)
             if ent:
-                by_kernel = {k: (2 * kib + ent.get("write_size_kib", {}).get(k, 0)) * 1024 for k, kib in ent.get("fetch_size_kib", {}).items()}
-                return ent["traffic_bytes_per_launch"], by_kernel, f"profiles/{name} (rocprofv3 PMC of this configuration, kernels hash {doc['kernels_hash']})"
+                return ent["traffic_bytes_per_launch"], ent.get("kernels", {}), f"profiles/{name} (rocprofv3 PMC of this configuration, kernels hash {doc['kernels_hash']})"
             src = src or f"null: profiles/{name} has no entry for {key}"
     return None, {}, src or "null: no committed PMC profile"
 
@@ -326,6 +364,13 @@ def worker(args, world):
         """warmup untimed steps, then exactly `steps` steps between barrier + device-synchronise pairs"""
         for _ in range(warmup):
             step()
+        # a shade-heavy configuration makes the renderer time its alternatives (layout, pipeline: ovr_hip_stats.tuning == 1) for up to a
+        # dozen frames: they belong to the warm-up, not to the timed steps (untimed extra steps, counted in `extra_warmup`)
+        extra = 0
+        while not multi and extra < 16 and ren.stats().tuning == 1:
+            step()
+            extra += 1
+        timed_leg.extra_warmup = extra
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -370,8 +415,22 @@ def worker(args, world):
         kern = {}
         for kname, kb, kms in parts:
             if kms > 0:
-                kern[kname] = {"ms": kms, "algorithmic_bytes_per_launch": kb, "achieved": kb / (kms * 1e-3) / 1e9,
-                               "frac": kb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_by_kernel.get(kname)}
+                ctr = traffic_by_kernel.get(kname)
+                # the in-place kernel and the pooled march are both raymarch_kernel: a profile of the other pipeline does not describe this one
+                if ctr and kname == "raymarch_kernel":
+                    m = re.search(r"raymarch_kernel<\d+, \d+, \d+, (true|false)", ctr.get("instantiation", ""))
+                    if not m or (m.group(1) == "true") != bool(pooled):
+                        ctr = None
+                kb_ = kernel_bound(kms, kb, ctr)
+                kern[kname] = {"ms": kms, "algorithmic_bytes_per_launch": kb, "bound": "hbm", "achieved": kb / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": kb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}
+                if kb_:
+                    kern[kname].update(traffic=kb_["traffic"], utilisation=kb_["utilisation"], l1_fill_bytes=kb_["l1_fill_bytes"], ta_busy=kb_["ta_busy"],
+                                       clock_ghz=kb_["clock_ghz"], hbm_algorithmic_frac=kern[kname]["frac"])
+                    if kb_["bound"] != "hbm":
+                        kern[kname].update(bound=kb_["bound"], achieved=kb_["achieved"], peak=kb_["peak"], unit=kb_["unit"], frac=kb_["frac"])
+                else:
+                    kern[kname]["bound_note"] = "no PMC profile of this configuration for these kernels: HBM assumed"
         if "composite_kernel" in kern:
             # not algorithmic bytes but what this pipeline makes the kernel read besides the framebuffer: every request slot of the
             # frame's chunks (32 B each) - the reason its measured traffic is ~3 x its framebuffer bytes
@@ -380,6 +439,7 @@ def worker(args, world):
         return kern, dom, abytes
 
     main_leg = timed_leg(args.steps, args.warmup)
+    main_extra_warmup = timed_leg.extra_warmup
     dt, tot, kernel_ms, phase_ms, last_stats = main_leg["dt"], main_leg["tot"], main_leg["kernel_ms"], main_leg["phase_ms"], main_leg["last"]
     if multi and world == 1:
         # forced single-rank gather: the gathered frame must be the renderer's own frame
@@ -439,12 +499,15 @@ def worker(args, world):
             pl = {k: v / vsteps for k, v in leg["tot"].items()}
             ph = [p / vsteps for p in leg["phase_ms"]]
             vc = dict(cfg, cam=vcam, tf=vtf)
-            kern, dom, abytes = kernel_report(vc, pl, ph, leg["kernel_ms"] / vsteps, leg["last"].pipeline == 2, {}, leg["last"].pool_chunks)
+            _, v_ctr, _ = load_traffic(traffic_key(args.config, vcam, vtf, cfg["shading"], world, cfg["rate"], args.fovy, args.sparse_sampling))
+            kern, dom, abytes = kernel_report(vc, pl, ph, leg["kernel_ms"] / vsteps, leg["last"].pipeline == 2, v_ctr, leg["last"].pool_chunks)
             views[f"{vcam}/{vtf}"] = {
                 "ms_per_step": leg["dt"] / vsteps * 1e3, "fps": vsteps / leg["dt"], "gsamples_per_s": leg["tot"]["samples"] / leg["dt"] / 1e9,
                 "samples_per_frame": pl["samples"], "shaded_samples_per_frame": pl["shaded_samples"], "shadow_samples_per_frame": pl["shadow_samples"],
                 "phase_ms": {"march": ph[0], "shade": ph[1], "composite": ph[2]},
-                "kernel": dom, "frac": kern[dom]["frac"] if dom else None, "kernel_fracs": {k: v["frac"] for k, v in kern.items()},
+                "kernel": dom, "bound": kern[dom]["bound"] if dom else None, "frac": kern[dom]["frac"] if dom else None, "unit": kern[dom]["unit"] if dom else None,
+                "utilisation": kern[dom].get("utilisation") if dom else None, "traffic": kern[dom]["traffic"] if dom else None,
+                "kernel_fracs": {k: v["frac"] for k, v in kern.items()}, "kernel_bounds": {k: v["bound"] for k, v in kern.items()},
                 "pipeline_frac": abytes / (leg["kernel_ms"] / vsteps * 1e-3) / 1e9 / HBM_PEAK_GBS if leg["kernel_ms"] > 0 else None}
         ren.set_transfer_function(colors, alphas, vr)
         set_cam()
@@ -476,14 +539,17 @@ def worker(args, world):
             leg = timed_leg(vsteps, 3)
             pl = {k: v / vsteps for k, v in leg["tot"].items()}
             ph = [p / vsteps for p in leg["phase_ms"]]
-            kern, dom, abytes = kernel_report(vc, pl, ph, leg["kernel_ms"] / vsteps, leg["last"].pipeline == 2, {}, leg["last"].pool_chunks)
+            _, v_ctr, _ = load_traffic(traffic_key(args.config, cfg["cam"], cfg["tf"], vc["shading"], world, vc["rate"], vkw.get("fovy", 60.0), vkw.get("sparse", False)))
+            kern, dom, abytes = kernel_report(vc, pl, ph, leg["kernel_ms"] / vsteps, leg["last"].pipeline == 2, v_ctr, leg["last"].pool_chunks)
             variants[vname] = {
                 "ms_per_step": leg["dt"] / vsteps * 1e3, "fps": vsteps / leg["dt"], "gsamples_per_s": leg["tot"]["samples"] / leg["dt"] / 1e9,
                 "samples_per_frame": pl["samples"], "shaded_samples_per_frame": pl["shaded_samples"], "shadow_samples_per_frame": pl["shadow_samples"],
                 "rendered_pixels_per_frame": pl["active_pixels"],
                 "phase_ms": {"march": ph[0], "shade": ph[1], "composite": ph[2]},
-                "kernel": dom, "frac": kern[dom]["frac"] if dom else None,
-                "pipeline_frac": abytes / (leg["kernel_ms"] / vsteps * 1e-3) / 1e9 / HBM_PEAK_GBS if leg["kernel_ms"] > 0 else None}
+                "kernel": dom, "bound": kern[dom]["bound"] if dom else None, "frac": kern[dom]["frac"] if dom else None, "unit": kern[dom]["unit"] if dom else None,
+                "utilisation": kern[dom].get("utilisation") if dom else None, "traffic": kern[dom]["traffic"] if dom else None,
+                "layout": ["general", "thin", "thin transposed", "quad"][leg["last"].layout], "pipeline": "pooled" if leg["last"].pipeline == 2 else "in place",
+                "hbm_algorithmic_frac_frame": abytes / (leg["kernel_ms"] / vsteps * 1e-3) / 1e9 / HBM_PEAK_GBS if leg["kernel_ms"] > 0 else None}
             if vkw.get("sparse"):
                 ren.set_sparse_sampling(False)
         ren.set_shading(cfg["shading"])
@@ -541,7 +607,7 @@ def worker(args, world):
         pixels_per_launch = per_launch["active_pixels"]
         nbytes = nominal_bytes(cfg, per_launch, pixels_per_launch)
         traffic, traffic_by_kernel, traffic_source = (None, {}, "null: the empty-space skipping leg is not profiled") if args.skip_empty else \
-            load_traffic(f"{args.config}|{cfg['cam']}|{cfg['tf']}|{cfg['shading']}|{world}")
+            load_traffic(traffic_key(args.config, cfg["cam"], cfg["tf"], cfg["shading"], world, cfg["rate"], args.fovy, args.sparse_sampling))
         pooled = last_stats.pipeline == 2
         ph = [p / steps for p in phase_ms]
         kern, dom, abytes = kernel_report(cfg, per_launch, ph, k_ms, pooled, traffic_by_kernel, last_stats.pool_chunks)
@@ -558,6 +624,7 @@ def worker(args, world):
             "n_gpus": world,
             "steps": steps,
             "warmup": args.warmup,
+            "extra_warmup": main_extra_warmup,
             "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
@@ -568,11 +635,15 @@ def worker(args, world):
                        "transfer_function": cfg["tf"], "camera": cfg["cam"], "fovy": args.fovy, "sparse_sampling": bool(args.sparse_sampling), "sampling_rate": cfg["rate"],
                        "spp": cfg["spp"], "pixel_jitter": "blue-noise tile (synthetic 64x64x64), slice = frame % 64" if noise is not None else "RandomTEA iff spp > 1 (reference)",
                        "shading": ["none", "gradient", "gradient+shadow"][cfg["shading"]],
-                       "frame_accumulation": True, "empty_space_skipping": bool(args.skip_empty), "volume_layout_read": ["general", "thin", "thin transposed", "quad"][last_stats.layout], "parallelism": f"image tiles {args.tile}x{args.tile} over {world} rank(s)"},
+                       "frame_accumulation": True, "empty_space_skipping": bool(args.skip_empty), "tuning": ["rules", "probing", "measured choice"][last_stats.tuning], "volume_layout_read": ["general", "thin", "thin transposed", "quad"][last_stats.layout], "parallelism": f"image tiles {args.tile}x{args.tile} over {world} rank(s)"},
             "per_frame": {k: per_step[k] for k in sorted(per_step)},
             # the dominant kernel of the frame (longest mean launch); the whole pipeline and the other kernels beside it
-            "roofline": {"bound": "hbm", "achieved": kern[dom]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": kern[dom]["bound"], "achieved": kern[dom]["achieved"], "peak": kern[dom]["peak"], "unit": kern[dom]["unit"],
                          "frac": kern[dom]["frac"], "traffic": kern[dom]["traffic"], "traffic_source": traffic_source,
+                         "bound_note": "bound = the busiest of: HBM side of L2 (FETCH x 2 + WRITE vs 8 TB/s), gather-instruction rate of the texture addressers "
+                                       "(16 clk per instruction and CU), vector-instruction issue (4 clk per instruction and SIMD), from the PMC profile of this "
+                                       "configuration; achieved / peak / frac are in that resource's unit, utilisation lists all three",
+                         "utilisation": kern[dom].get("utilisation"), "hbm_algorithmic_frac": kern[dom].get("hbm_algorithmic_frac", kern[dom]["frac"]),
                          "kernel": dom + ("" if "pipeline" in dom else " (pooled pipeline: march -> shade -> composite)" if pooled else " (in-place pipeline)"),
                          "kernel_ms": kern[dom]["ms"], "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes_per_launch"],
                          "kernels": kern,

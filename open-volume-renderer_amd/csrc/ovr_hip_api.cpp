@@ -194,6 +194,7 @@ struct ovr_hip_renderer {
   unsigned int* d_block_counts = nullptr;
   unsigned long long* d_sparse_count = nullptr;
   size_t sparse_pixels = 0;
+  unsigned long long sparse_prev_pixels = 0; // pixels of the previous sparse frame (RayMarchParams::sparse_hint_pixels)
 
   // counters
   unsigned long long* d_counters = nullptr;
@@ -675,6 +676,7 @@ int enqueue_frame(ovr_hip_renderer* r)
   P.trace = r->d_trace;
   P.sparse_xy = nullptr;
   P.sparse_count = nullptr;
+  P.sparse_hint_pixels = 0;
   P.schedule = nullptr;
   P.n_schedule = 0;
   if (!sparse) {
@@ -695,6 +697,7 @@ int enqueue_frame(ovr_hip_renderer* r)
     HIP_TRY(launch_sparse_mask(mp, st));
     P.sparse_xy = r->d_sparse_xy;
     P.sparse_count = r->d_sparse_count;
+    P.sparse_hint_pixels = r->sparse_prev_pixels;
   }
   // ---- shading pipeline: pooled (march -> shade -> composite) when it applies, else in place
   const int pipe = r->pipeline.current;
@@ -791,6 +794,7 @@ int finish_frame(ovr_hip_renderer* r)
     r->stats.skipped_samples = r->stats.skipped_shadow_samples = r->stats.shadow_samples = 0;
   }
   r->stats.frame_index = r->frame_index;
+  r->sparse_prev_pixels = r->P.sparse_xy ? r->stats.active_pixels : 0;
   r->stats.skipping_kernels = r->frame_used_skip ? 1 : 0;
   r->stats.tuning = r->tune_frame >= 0 ? 1 : (r->tune_on && r->tune_state == 2 && (r->tune_layout >= 0 || r->tune_pipeline != 0)) ? 2 : 0;
   if (r->tune_frame == 0 && r->tune_state == 0) r->stats.tuning = 0; // the first frame of a configuration runs the rules' choice

@@ -124,6 +124,7 @@ struct RayMarchParams {
   // sparse sampling: compacted (x,y) list + device-side count (2 * pixels), null in dense mode
   const int32_t* sparse_xy;
   const unsigned long long* sparse_count;
+  unsigned long long sparse_hint_pixels; // pixels the previous sparse frame rendered (0 = unknown): picks the deep march for small lists
   // pixel jitter: 0 = RandomTEA iff spp > 1 (the reference), 1 = blue-noise tile for every sample (jitter_noise: the noise
   // tile stored [t][y][x], jitter_xy its edge; see jitter_slice in ovr_hip_kernels.hip)
   int jitter_mode, jitter_xy;

@@ -718,8 +718,8 @@ __device__ __forceinline__ void stage_noise_rows(const SparseMaskParams& p, floa
   __syncthreads();
 }
 
-// enumeration index -> pixel.  Row-major: i = x + y * W.  Tile-major (p.tile_major): 256 consecutive indices are one 16x16-pixel tile,
-// 16 consecutive indices one of its 4x4 sub-tiles (row-major inside both levels); pixels beyond the image edge are never kept
+// enumeration index -> pixel.  Row-major: i = x + y * W.  Tile-major (p.tile_major): 256 consecutive indices are one 16x16-pixel tile in
+// Morton order (16 consecutive indices are a 4x4 block, 64 an 8x8 block); pixels beyond the image edge are never kept
 __device__ __forceinline__ bool mask_pixel(const SparseMaskParams& p, unsigned int i, int& x, int& y)
 {
   if (!p.tile_major) {
@@ -728,9 +728,25 @@ __device__ __forceinline__ bool mask_pixel(const SparseMaskParams& p, unsigned i
     return i < (unsigned int)p.width * (unsigned int)p.height;
   }
   const unsigned int tiles_x = ((unsigned int)p.width + 15u) / 16u;
-  const unsigned int tile = i >> 8, in = i & 255u, st = in >> 4, px = in & 15u;
-  x = (int)((tile % tiles_x) * 16u + (st & 3u) * 4u + (px & 3u));
-  y = (int)((tile / tiles_x) * 16u + (st >> 2) * 4u + (px >> 2));
+  const unsigned int tile = i >> 8, in = i & 255u;
+#ifndef OVR_MASK_MORTON
+#define OVR_MASK_MORTON 1
+#endif
+  unsigned int lx, ly;
+  if (OVR_MASK_MORTON) {
+    // Morton (Z) order inside the tile: wherever the mask keeps only part of the pixels, 16 consecutive KEPT pixels - a wave's rays - are
+    // still a compact patch (a 4x4 block where everything is kept, ~7x7 pixels at 30 %) instead of a 4-pixel-high strip of sub-tiles;
+    // rays that are neighbours share bricks, and the sparse frame is bound by the lines its rays do not share (profiles/r03_notes.md)
+    lx = (in & 1u) | ((in >> 1) & 2u) | ((in >> 2) & 4u) | ((in >> 3) & 8u);
+    ly = ((in >> 1) & 1u) | ((in >> 2) & 2u) | ((in >> 3) & 4u) | ((in >> 4) & 8u);
+  }
+  else {
+    const unsigned int st = in >> 4, px = in & 15u;
+    lx = (st & 3u) * 4u + (px & 3u);
+    ly = (st >> 2) * 4u + (px >> 2);
+  }
+  x = (int)((tile % tiles_x) * 16u + lx);
+  y = (int)((tile / tiles_x) * 16u + ly);
   return x < p.width && y < p.height;
 }
 

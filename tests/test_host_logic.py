@@ -104,12 +104,25 @@ def test_bench_refuses_a_launcher_mismatch_and_keys_traffic_by_the_kernel_hash(t
     assert len(h) == 16 and h == bench.kernels_hash()
     prof = tmp_path / "profiles"
     prof.mkdir()
-    entry = {"fetch_size_kib": {"raymarch_kernel": 1000}, "write_size_kib": {"raymarch_kernel": 10}, "traffic_bytes_per_launch": 2058240}
-    (prof / "r09_traffic.json").write_text(json.dumps({"kernels_hash": h, "entries": {"c3|oblique|sparse|2|1": entry}}))
-    (prof / "r08_traffic.json").write_text(json.dumps({"kernels_hash": "0" * 16, "entries": {"c2|oblique|sparse|0|1": entry}}))
+    k3 = bench.traffic_key("c3", "oblique", "sparse", 2, 1, 1.0, 60.0, False)
+    k2 = bench.traffic_key("c2", "oblique", "sparse", 0, 1, 1.0, 60.0, False)
+    assert k3 == "c3|oblique|sparse|2|1|1.0|60.0|0"
+    ctr = {"instantiation": "void ovrhip::raymarch_kernel<4, 2, 1, true, false, false, false>", "FETCH_SIZE": 1000.0, "WRITE_SIZE": 10.0, "GRBM_GUI_ACTIVE": 8 * 2.4e6,
+           "SQ_INSTS_VMEM_RD": 2.0e7, "SQ_INSTS_VALU": 1.0e8, "TCP_TCC_READ_REQ_sum": 1.0e6, "TA_TA_BUSY_sum": 1.0e8, "mean_ms_rocprof": 1.0}
+    entry = {"fetch_size_kib": {"raymarch_kernel": 1000}, "write_size_kib": {"raymarch_kernel": 10}, "traffic_bytes_per_launch": 2058240, "kernels": {"raymarch_kernel": ctr}}
+    (prof / "r09_traffic.json").write_text(json.dumps({"kernels_hash": h, "entries": {k3: entry}}))
+    (prof / "r08_traffic.json").write_text(json.dumps({"kernels_hash": "0" * 16, "entries": {k2: entry}}))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     monkeypatch.setattr(bench, "kernels_hash", lambda: h)
-    t, by_kernel, src = bench.load_traffic("c3|oblique|sparse|2|1")
-    assert t == 2058240 and by_kernel["raymarch_kernel"] == (2 * 1000 + 10) * 1024 and "r09_traffic.json" in src
-    t, by_kernel, src = bench.load_traffic("c2|oblique|sparse|0|1")       # only measured for other kernels
+    t, by_kernel, src = bench.load_traffic(k3)
+    assert t == 2058240 and by_kernel["raymarch_kernel"]["FETCH_SIZE"] == 1000.0 and "r09_traffic.json" in src
+    t, by_kernel, src = bench.load_traffic(k2)       # only measured for other kernels
     assert t is None and by_kernel == {} and src.startswith("null:")
+    # the bound of a kernel from its counters: 2e7 gathers x 16 clk on 256 CUs over 2.4e6 clocks = 0.52 of the texture addressers, 1e8 vector
+    # instructions x 4 clk on 1024 SIMDs = 0.16, 2 MB of traffic = nothing: bound by the gather rate - and never an HBM fraction above 1
+    b = bench.kernel_bound(1.0, 5.0e9, ctr)
+    assert b["bound"] == "ta" and abs(b["utilisation"]["ta"] - 2.0e7 * 16 / (256 * 2.4e6)) < 1e-3 and abs(b["frac"] - b["utilisation"]["ta"]) < 1e-3
+    ctr_hbm = dict(ctr, FETCH_SIZE=3.0e6, SQ_INSTS_VMEM_RD=1.0e6)    # 6.3 GB of traffic in 1 ms for 5 GB of algorithmic bytes: the memory side
+    assert bench.kernel_bound(1.0, 5.0e9, ctr_hbm)["bound"] == "hbm"
+    assert bench.kernel_bound(1.0, 9.0e9, ctr_hbm)["bound"] != "hbm"   # more algorithmic bytes than traffic: the caches serve it, HBM is not the bound
+    assert bench.kernel_bound(1.0, 5.0e9, None) is None
