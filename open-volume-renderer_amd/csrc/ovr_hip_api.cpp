@@ -174,6 +174,9 @@ struct ovr_hip_renderer {
   float* d_grad[2] = { nullptr, nullptr };
   float* h_rgba[2] = { nullptr, nullptr };
   float* h_grad[2] = { nullptr, nullptr };
+  // the pixel rectangle each host mirror was last refreshed in ({x0, y0, x1, y1}, empty at first): mapframe(HOST) copies only the
+  // rectangle the volume's box projects into - every pixel outside it is exactly 0 on the device and stays 0 in the mirror
+  int h_rgba_rect[2][4] = {}, h_grad_rect[2][4] = {};
   float* d_accum = nullptr;
   uint32_t* d_rgba8 = nullptr; // mapframe_rgba8: device and pinned host copy of the 8-bit frame
   uint32_t* h_rgba8 = nullptr;
@@ -454,6 +457,56 @@ SparseMaskParams make_mask_params(ovr_hip_renderer* r, int frame_index, int32_t*
 }
 
 int launch_frame(ovr_hip_renderer* r);
+
+// Screen-space bounding rectangle (pixels, aligned outwards to 8, two pixels of margin for the sub-pixel jitter) of the volume's box
+// under the committed camera: a ray outside it misses the box and its pixel is exactly 0 in every layer (background 0, alpha 0,
+// shaders_raymarching.cu:260-321) - in any mode: accumulation adds 0, sparse sampling and image shards leave it cleared.  The whole
+// frame when a corner of the box lies at or behind the camera plane.
+void nonzero_rect(const ovr_hip_renderer* r, int rect[4])
+{
+  const int W = r->fbsize.current.w, H = r->fbsize.current.h;
+  rect[0] = 0; rect[1] = 0; rect[2] = W; rect[3] = H;
+  if (!r->have_volume || W <= 0 || H <= 0) return;
+  const RayMarchParams& P = r->P;
+  const double d[3] = { P.cam_dir.x, P.cam_dir.y, P.cam_dir.z }, h[3] = { P.cam_hor.x, P.cam_hor.y, P.cam_hor.z }, v[3] = { P.cam_ver.x, P.cam_ver.y, P.cam_ver.z };
+  const double hh = h[0] * h[0] + h[1] * h[1] + h[2] * h[2], vv = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+  if (!(hh > 0.0) || !(vv > 0.0)) return;
+  const double inv[3] = { P.inv_scale.x, P.inv_scale.y, P.inv_scale.z }, wp[3] = { P.wto_p.x, P.wto_p.y, P.wto_p.z }, from[3] = { P.cam_pos.x, P.cam_pos.y, P.cam_pos.z };
+  double sx0 = 1e30, sx1 = -1e30, sy0 = 1e30, sy1 = -1e30;
+  for (int c = 0; c < 8; ++c) {
+    double p[3];
+    for (int k = 0; k < 3; ++k) p[k] = (((c >> k) & 1 ? 1.0 : 0.0) - wp[k]) / inv[k] - from[k]; // object corner -> world, relative to the eye
+    const double a = p[0] * d[0] + p[1] * d[1] + p[2] * d[2];
+    if (!(a > 1e-6 * (std::fabs(p[0]) + std::fabs(p[1]) + std::fabs(p[2]) + 1e-30))) return; // at or behind the camera plane: whole frame
+    const double sx = 0.5 + (p[0] * h[0] + p[1] * h[1] + p[2] * h[2]) / (hh * a), sy = 0.5 + (p[0] * v[0] + p[1] * v[1] + p[2] * v[2]) / (vv * a);
+    sx0 = std::min(sx0, sx); sx1 = std::max(sx1, sx); sy0 = std::min(sy0, sy); sy1 = std::max(sy1, sy);
+  }
+  auto lo = [](double s, int n) { const double q = std::floor(s * n) - 2.0; return (int)std::min<double>(std::max<double>(q, 0.0), n) & ~7; };
+  auto hi = [](double s, int n) { const double q = std::ceil(s * n) + 2.0; return std::min(((int)std::min<double>(std::max<double>(q, 0.0), n) + 7) & ~7, n); };
+  rect[0] = lo(sx0, W); rect[2] = hi(sx1, W); rect[1] = lo(sy0, H); rect[3] = hi(sy1, H);
+  if (rect[2] <= rect[0] || rect[3] <= rect[1]) { rect[0] = rect[1] = rect[2] = rect[3] = 0; } // the box is off screen: nothing to refresh
+}
+
+// device layer -> pinned host mirror, only where a pixel can differ from 0 now or could when the mirror was last refreshed
+int refresh_mirror(ovr_hip_renderer* r, float* host, const float* dev, int channels, int last[4], hipStream_t st)
+{
+  const int W = r->fbsize.current.w;
+  int now[4];
+  nonzero_rect(r, now);
+  static const bool whole = getenv("OVR_HIP_MAP_WHOLE_FRAME") != nullptr; // measurements: the uncropped copy
+  if (whole) { now[0] = 0; now[1] = 0; now[2] = W; now[3] = r->fbsize.current.h; }
+  int u[4] = { now[0], now[1], now[2], now[3] };
+  if (last[2] > last[0] && last[3] > last[1]) {
+    if (u[2] <= u[0] || u[3] <= u[1]) { u[0] = last[0]; u[1] = last[1]; u[2] = last[2]; u[3] = last[3]; }
+    else { u[0] = std::min(u[0], last[0]); u[1] = std::min(u[1], last[1]); u[2] = std::max(u[2], last[2]); u[3] = std::max(u[3], last[3]); }
+  }
+  if (u[2] > u[0] && u[3] > u[1]) {
+    const size_t pitch = (size_t)W * channels * sizeof(float), off = ((size_t)u[1] * W + u[0]) * channels;
+    HIP_TRY(hipMemcpy2DAsync(host + off, pitch, dev + off, pitch, (size_t)(u[2] - u[0]) * channels * sizeof(float), (size_t)(u[3] - u[1]), hipMemcpyDeviceToHost, st));
+  }
+  for (int k = 0; k < 4; ++k) last[k] = now[k];
+  return 0;
+}
 
 // the macrocell value ranges (sp.compute_value_range at load, volume.cpp:234-237): once per volume
 int update_macrocell_ranges(ovr_hip_renderer* r, hipStream_t st)
@@ -1367,11 +1420,21 @@ int ovr_hip_mapframe(ovr_hip_renderer* r, int mem_kind, const float** rgba, size
   if (mem_kind != OVR_HIP_MEM_HOST) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_mapframe: bad mem_kind");
   if (n == 0) { *rgba = nullptr; *rgba_bytes = 0; if (grad) *grad = nullptr; if (grad_bytes) *grad_bytes = 0; return 0; }
   hipStream_t st = r->stream();
-  if (!r->h_rgba[c]) HIP_TRY(hipHostMalloc((void**)&r->h_rgba[c], n * 4 * sizeof(float), hipHostMallocDefault));
-  HIP_TRY(hipMemcpyAsync(r->h_rgba[c], r->d_rgba[c], n * 4 * sizeof(float), hipMemcpyDeviceToHost, st));
+  // the mirrors start as zeros and only the rectangle the box projects into is ever copied (refresh_mirror): C3's oblique view moves 22 of
+  // the frame's 58 MB, 0.4 instead of 1.04 ms per mapped frame (profiles/r03_notes.md)
+  if (!r->h_rgba[c]) {
+    HIP_TRY(hipHostMalloc((void**)&r->h_rgba[c], n * 4 * sizeof(float), hipHostMallocDefault));
+    std::memset(r->h_rgba[c], 0, n * 4 * sizeof(float));
+    for (int k = 0; k < 4; ++k) r->h_rgba_rect[c][k] = 0;
+  }
+  if (int e = refresh_mirror(r, r->h_rgba[c], r->d_rgba[c], 4, r->h_rgba_rect[c], st)) return e;
   if (grad) {
-    if (!r->h_grad[c]) HIP_TRY(hipHostMalloc((void**)&r->h_grad[c], n * 3 * sizeof(float), hipHostMallocDefault));
-    HIP_TRY(hipMemcpyAsync(r->h_grad[c], r->d_grad[c], n * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (!r->h_grad[c]) {
+      HIP_TRY(hipHostMalloc((void**)&r->h_grad[c], n * 3 * sizeof(float), hipHostMallocDefault));
+      std::memset(r->h_grad[c], 0, n * 3 * sizeof(float));
+      for (int k = 0; k < 4; ++k) r->h_grad_rect[c][k] = 0;
+    }
+    if (int e = refresh_mirror(r, r->h_grad[c], r->d_grad[c], 3, r->h_grad_rect[c], st)) return e;
   }
   HIP_TRY(hipStreamSynchronize(st));
   *rgba = r->h_rgba[c];

@@ -999,7 +999,21 @@ __device__ __forceinline__ float quad_bcast(float x) // value of lane B of this 
 {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), B * 0x55, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float sel4(float a0, float a1, float a2, float a3, int sub) { return sub == 0 ? a0 : sub == 1 ? a1 : sub == 2 ? a2 : a3; }
+// a_sub for the lane's sub = lane & 3.  As nested conditionals the compiler builds this from compares and exec-mask branches (5 vector + 7
+// scalar instructions per select, 8 selects per round of the march); with the two lane masks m1 = -(sub & 1), m2 = -((sub >> 1) & 1) kept in
+// registers it is three v_bfi_b32 (bit-field insert: (m & b) | (~m & a)) - the same bits
+#ifndef OVR_SEL4_BFI
+#define OVR_SEL4_BFI 1
+#endif
+struct SubMask { unsigned int m1, m2; int sub; };
+__device__ __forceinline__ SubMask make_submask(int sub) { SubMask m; m.m1 = 0u - (unsigned int)(sub & 1); m.m2 = 0u - (unsigned int)((sub >> 1) & 1); m.sub = sub; return m; }
+__device__ __forceinline__ unsigned int bfi(unsigned int m, unsigned int b, unsigned int a) { return (m & b) | (~m & a); }
+__device__ __forceinline__ float sel4(float a0, float a1, float a2, float a3, const SubMask& m)
+{
+  if (!OVR_SEL4_BFI) return m.sub == 0 ? a0 : m.sub == 1 ? a1 : m.sub == 2 ? a2 : a3;
+  const unsigned int lo = bfi(m.m1, __float_as_uint(a1), __float_as_uint(a0)), hi = bfi(m.m1, __float_as_uint(a3), __float_as_uint(a2));
+  return __uint_as_float(bfi(m.m2, hi, lo));
+}
 
 // Blue-noise pixel jitter (P.jitter_mode == 1; BASELINE C5, north_star): sample k of frame f takes slice
 // t = ((f - 1) * spp + k) % 64 of the noise tile (lookup as blue_noise.h:95-99; the tile is stored transposed, [t][y][x]):
@@ -1111,6 +1125,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
   const int sub = lane & 3;               // this lane's step inside each group of 4 consecutive steps
   const int qbase = lane & ~3;            // first lane of the quad
   const bool owner = sub == 0;            // the quad's lane that keeps the pixel's colour / request list
+  const SubMask subm = make_submask(sub);
   const unsigned long long t_start = P.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   int ix, iy;
@@ -1368,8 +1383,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
           tx = ty;
           ty = fminf(tx + mc.step, t1);
         }
-        const float mtx = sel4(txq[0], txq[1], txq[2], txq[3], sub);
-        const float mty = sel4(tyq[0], tyq[1], tyq[2], tyq[3], sub);
+        const float mtx = sel4(txq[0], txq[1], txq[2], txq[3], subm);
+        const float mty = sel4(tyq[0], tyq[1], tyq[2], tyq[3], subm);
         dts[k] = mty - mtx;
         tms[k] = 0.5f * (mtx + mty);
       }
@@ -1562,7 +1577,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
         OVR_STEP(0) OVR_STEP(1) OVR_STEP(2) OVR_STEP(3)
 #undef OVR_STEP
         mlive[k] = sub == 0 ? lv[0] : sub == 1 ? lv[1] : sub == 2 ? lv[2] : lv[3];
-        mtr[k] = 1.f - sel4(al[0], al[1], al[2], al[3], sub);
+        mtr[k] = 1.f - sel4(al[0], al[1], al[2], al[3], subm);
         // a sample whose corrected opacity is exactly 0 adds exactly 0 to colour, gradient and alpha: nothing is shaded
         mpush[k] = mlive[k] && (aa[k] > 0.f);
       }

@@ -139,13 +139,17 @@ public:
   // Impl::mapframe (device_impl.cpp:271-281).  The reference hands out device pointers (DEVICE_CUDA), which only exist
   // in its CUDA build; an app built without OVR_BUILD_CUDA_DEVICES knows DEVICE_CPU only, so the frame is mapped to host
   // memory owned by the backend - what the caller's to_cpu() (cross_device_buffer.h:130-159) would do next anyway.
+  // Only the rectangle the volume's box projects into crosses PCIe (ovr_hip_mapframe).  OVR_HIP_MAP_GRAD=0 leaves the gradient layer unset
+  // like the reference's OSPRay device does (ospray/device_impl.cpp:814-818) - 43 % of a mapped frame's bytes, read only by renderapp's
+  // "gradient" view.
   void mapframe(FrameBufferData* fb) override
   {
+    static const bool want_grad = !(std::getenv("OVR_HIP_MAP_GRAD") && std::getenv("OVR_HIP_MAP_GRAD")[0] == '0');
     const float *rgba = nullptr, *grad = nullptr;
     size_t nb_rgba = 0, nb_grad = 0;
-    check(ovr_hip_mapframe(h, OVR_HIP_MEM_HOST, &rgba, &nb_rgba, &grad, &nb_grad));
+    check(ovr_hip_mapframe(h, OVR_HIP_MEM_HOST, &rgba, &nb_rgba, want_grad ? &grad : nullptr, want_grad ? &nb_grad : nullptr));
     fb->rgba->set_data((void*)rgba, nb_rgba, ovr::CrossDeviceBuffer::DEVICE_CPU);
-    fb->grad->set_data((void*)grad, nb_grad, ovr::CrossDeviceBuffer::DEVICE_CPU);
+    if (want_grad) fb->grad->set_data((void*)grad, nb_grad, ovr::CrossDeviceBuffer::DEVICE_CPU);
   }
 
 private:

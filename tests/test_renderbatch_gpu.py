@@ -121,9 +121,13 @@ def test_c3_through_the_unmodified_reference_app():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "renderbatch_c3.py"), "1024", "1920,1080", "float32"], capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    fps = [float(m) for m in re.findall(r"fps = ([0-9.]+)", out.stdout)]
+    fps = [float(m) for m in re.findall(r"own line: fps = ([0-9.]+)", out.stdout)]
     assert len(fps) == 2 and min(fps) > 50.0, out.stdout[-2000:]
     assert "byte-identical" in out.stdout and "NOT identical" not in out.stdout
+    # round 3: the same plugin in renderapp's order (commit -> mapframe -> swap -> render, plugin_probe --loop): every frame is mapped to the host
+    loop = [float(m) for m in re.findall(r"loop fps = ([0-9.]+)", out.stdout)]
+    assert len(loop) == 3 and min(loop) > 50.0, out.stdout[-2000:]
+    assert len(set(re.findall(r"centre alpha sum ([0-9.]+)", out.stdout))) == 1     # the three copies hand the same frames to the caller
 
 
 @pytest.mark.parametrize("name", ["scene_engine.json", "scene_teapot.json", "scene_vorts_t83.json", "scene_bonsai.json", "scene_skull.json"])

@@ -155,3 +155,42 @@ def test_constant_volume_under_the_data_range_fallback(ovr, oracle, hip_renderer
     assert (st.samples, st.shaded_samples, st.shadow_samples) == (cnt.samples, cnt.shaded_samples, cnt.shadow_samples)
     compare(oracle, got, ref, name=f"constant volume {np.dtype(dtype).name}")
     ren.close()
+
+
+def test_mapframe_copies_only_the_box_rectangle(ovr, oracle, hip_renderer_factory):
+    """mapframe(HOST) moves only the pixel rectangle the volume's box projects into; the mirror equals the device frame bit for bit - also
+    after the camera moved the rectangle (stale pixels of the old rectangle are refreshed), after a swap, with sparse sampling, and when a
+    corner of the box lies behind the camera (whole frame)"""
+    import torch
+    case = make_case(ovr, oracle, n=32, tf="dense", cam="oblique", size=(200, 120), shading=2)
+    ren = hip_setup(ovr, hip_renderer_factory(), case, accumulate=True)
+
+    def check(tag):
+        fb_h, fb_d = ovr.FrameBufferData(), ovr.FrameBufferData()
+        ren.mapframe(fb_h)
+        ren.mapframe(fb_d, device=True)
+        for lay in ("rgba", "grad"):
+            h = np.array(getattr(fb_h, lay).data(), copy=True)
+            d = getattr(fb_d, lay).data().cpu().numpy()
+            assert np.array_equal(h.view(np.uint32), d.reshape(h.shape).view(np.uint32)), (tag, lay)
+        return np.array(fb_h.rgba.data(), copy=True)
+
+    ren.render(); ren.render()
+    a = check("first")
+    assert a[..., 3].max() > 0.5 and (a[:, :8] == 0).all() and (a[:, -8:] == 0).all()      # the box does not fill the frame
+    eye, at, up = case["cam"]
+    far = tuple(np.array(at) + 3.0 * (np.array(eye) - np.array(at)))                           # a smaller rectangle: the old one's border goes back to 0
+    ren.set_camera(ovr.Camera(far, at, up, 60.0)); ren.commit(); ren.render()
+    b = check("far")
+    assert (b[..., 3] > 0).sum() < (a[..., 3] > 0).sum()
+    ren.set_camera(ovr.Camera(tuple(np.array(eye) + np.array((40.0, 25.0, 0.0))), tuple(np.array(at) + np.array((40.0, 25.0, 0.0))), up, 60.0)); ren.commit(); ren.render()
+    check("shifted")
+    ren.swap(); ren.render()
+    check("other set")
+    ren.set_camera(ovr.Camera(tuple(np.array(at) + 0.2 * (np.array(eye) - np.array(at))), at, up, 60.0)); ren.commit(); ren.render()   # eye inside the box
+    c = check("inside")
+    assert (c[..., 3] > 0).mean() > 0.9
+    ren.set_noise_tile(ovr.synth.make_noise_tile(64)); ren.set_focus((0.5, 0.5), 0.2, 0.1); ren.set_sparse_sampling(True)
+    ren.set_camera(ovr.Camera(eye, at, up, 60.0)); ren.commit(); ren.render()
+    check("sparse")
+    ren.close()

@@ -49,6 +49,17 @@ try:
         fps = [l for l in out.stdout.splitlines() if l.startswith("fps =")]
         print(f"[renderbatch_c3] {n}^3 {dtype} at {fbsize}, empty-space skipping {'on (plugin default)' if skip == '1' else 'off'}: the reference app's own line: "
               f"{fps[-1] if fps else 'no fps line'}  (whole run incl. volume load {time.perf_counter() - t1:.1f} s)", flush=True)
+    # renderapp's render-thread order (commit -> mapframe -> swap -> render: every frame crosses PCIe) through the same plugin
+    probe = os.path.join(ROOT, "oracle", "_ref", "plugin_probe")
+    w_, h_ = fbsize.split(",")
+    if os.path.exists(probe):
+        env["OVR_HIP_SKIP_EMPTY"] = "0"
+        for label, extra in (("RGBA + gradient layer, cropped to the box's screen rectangle (default)", {}),
+                             ("RGBA only (OVR_HIP_MAP_GRAD=0), cropped", {"OVR_HIP_MAP_GRAD": "0"}),
+                             ("RGBA + gradient layer, whole frame (round 2's copy)", {"OVR_HIP_MAP_WHOLE_FRAME": "1"})):
+            out = subprocess.run([probe, "--loop", "100", scene, w_, h_], env=dict(env, **extra), cwd=d, capture_output=True, text=True, timeout=900)
+            line = [l for l in out.stdout.splitlines() if l.startswith("loop fps")]
+            print(f"[renderbatch_c3] mapped every frame, {label}: {line[-1] if line else out.stderr[-500:]}", flush=True)
     a = open(os.path.join(d, "out0000000.png"), "rb").read() if os.path.exists(os.path.join(d, "out0000000.png")) else None
     b = open(os.path.join(d, "out1000000.png"), "rb").read() if os.path.exists(os.path.join(d, "out1000000.png")) else None
     print(f"[renderbatch_c3] the two PNGs are {'byte-identical' if a is not None and a == b else 'NOT identical / missing'}")
