@@ -525,8 +525,38 @@ __device__ __forceinline__ f3 to_object(const MarchConsts& mc, f3 p)
 // (4^3 macrocells = 64 voxels per entry), FINE = true: one entry per macrocell (16 voxels); both are dilated by one macrocell.
 // Sample coordinates: x = p * cs + cb (tap_coords), macrocell = (floor(x) + 1) >> 4 (tap_cell), i.e. the regular 16-voxel
 // grid in w = x + 1.
-template <bool FINE>
-__device__ __forceinline__ void skip_walk(const VolConsts& vc, f3 oo, f3 od, float ta, float tb, float& first, float& last)
+// Round 3 - any number of occupied intervals per ray: besides the hull [first, last] the fine walk of a primary ray marks, in a 64-bit mask,
+// which of 64 equal segments of the span [seg0, seg0 + 64 / seg_scale] it walked (the coarse hull) meet a set entry (one segment of
+// margin on either side).  A round of the march whose t range touches no marked segment lies in empty macrocells although it is inside the
+// hull - interior voids take the 45-instruction bulk path too (accel/dda.h walks such gaps cell by cell for the reference's path tracer).
+struct SkipSpan {
+  float first, last;            // hull: every sample outside it lies in a macrocell with majorant 0
+  float seg0, seg_scale;        // segment i covers t in [seg0 + i / seg_scale, seg0 + (i + 1) / seg_scale)
+  unsigned int mask_lo, mask_hi; // segments that can hold a sample with majorant > 0 (all set: no refinement)
+};
+__device__ __forceinline__ SkipSpan skipspan_all() { SkipSpan s; s.first = -FLT_MAX; s.last = FLT_MAX; s.seg0 = 0.f; s.seg_scale = 0.f; s.mask_lo = s.mask_hi = ~0u; return s; }
+__device__ __forceinline__ SkipSpan skipspan_none() { SkipSpan s; s.first = FLT_MAX; s.last = -FLT_MAX; s.seg0 = 0.f; s.seg_scale = 0.f; s.mask_lo = s.mask_hi = 0u; return s; }
+__device__ __forceinline__ int skipspan_seg(const SkipSpan& s, float t) { return min(max((int)((t - s.seg0) * s.seg_scale), 0), 63); }
+// can a sample at t lie in a macrocell with majorant > 0?
+__device__ __forceinline__ bool skipspan_inside(const SkipSpan& s, float t)
+{
+  const int g = skipspan_seg(s, t);
+  const unsigned int w = g < 32 ? s.mask_lo : s.mask_hi;
+  return t >= s.first && t <= s.last && ((w >> (g & 31)) & 1u) != 0u;
+}
+// may the t range [ta, tb] (ta <= tb) hold such a sample?
+__device__ __forceinline__ bool skipspan_touches(const SkipSpan& s, float ta, float tb)
+{
+  if (tb < s.first || ta > s.last) return false;
+  const int lo = skipspan_seg(s, ta), hi = skipspan_seg(s, tb);
+  const unsigned long long m = ((unsigned long long)s.mask_hi << 32) | s.mask_lo;
+  const unsigned long long range = (hi >= 63 ? ~0ull : ((2ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+  return (m & range) != 0ull;
+}
+
+template <bool FINE, bool MARK = false>
+__device__ __forceinline__ void skip_walk(const VolConsts& vc, f3 oo, f3 od, float ta, float tb, float& first, float& last, float seg0 = 0.f, float seg_scale = 0.f,
+                                          unsigned long long* mask = nullptr)
 {
   const float w0[3] = { fmaf(oo.x, vc.cs.x, vc.cb.x + 1.f), fmaf(oo.y, vc.cs.y, vc.cb.y + 1.f), fmaf(oo.z, vc.cs.z, vc.cb.z + 1.f) };
   const float dw[3] = { od.x * vc.cs.x, od.y * vc.cs.y, od.z * vc.cs.z };
@@ -550,7 +580,13 @@ __device__ __forceinline__ void skip_walk(const VolConsts& vc, f3 oo, f3 od, flo
     const bool occ = grid[(size_t)ci[0] + (size_t)(m1[0] + 1) * ((size_t)ci[1] + (size_t)(m1[1] + 1) * (size_t)ci[2])] != 0;
     const int ax = (tmax[0] <= tmax[1]) ? (tmax[0] <= tmax[2] ? 0 : 2) : (tmax[1] <= tmax[2] ? 1 : 2);
     const float tn = ax == 0 ? tmax[0] : ax == 1 ? tmax[1] : tmax[2];
-    if (occ) { first = fminf(first, t); last = fmaxf(last, fminf(tn, tb)); }
+    if (occ) {
+      first = fminf(first, t); last = fmaxf(last, fminf(tn, tb));
+      if (MARK) {
+        const int lo = max((int)((t - seg0) * seg_scale) - 1, 0), hi = min((int)((fminf(tn, tb) - seg0) * seg_scale) + 1, 63);
+        if (hi >= lo) *mask |= (hi >= 63 ? ~0ull : ((2ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+      }
+    }
     t = fmaxf(t, tn);
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -560,7 +596,7 @@ __device__ __forceinline__ void skip_walk(const VolConsts& vc, f3 oo, f3 od, flo
         else { ci[k] = nxt; tmax[k] += tdel[k]; }
       }
   }
-  if (t < tb) { first = fminf(first, t); last = tb; } // safety limit hit (never expected): treat the rest as occupied
+  if (t < tb) { first = fminf(first, t); last = tb; if (MARK) *mask = ~0ull; } // safety limit hit (never expected): treat the rest as occupied
 }
 
 // raymarching_shadow, shaders_raymarching.cu:44-85 (+ :205-229): alpha-only march toward the light.
@@ -619,7 +655,10 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
       // serialise the taps again (seen in the ISA); dead lanes just compute a value that is not used
       const float s = tap_finish<VT>(vc, taps[k]);
       float a = tf_alpha(tf, tf_coord(tf, s));
-      a = opacity_correction<SKIP>(a, mc.base * dts[k]);
+#ifndef OVR_SHADOW_BF
+#define OVR_SHADOW_BF 0 /* branch-free opacity correction in the plain shadow march too (measurement switch) */
+#endif
+      a = opacity_correction<SKIP || OVR_SHADOW_BF>(a, mc.base * dts[k]);
       if (SKIP) a = mj[k] > 0.f ? a : 0.f; // a macrocell whose majorant is 0 holds no sample with opacity > 0
       live = live && valid[k] && (alpha < 0.9999f);
       alpha = live ? fmaf(1.f - alpha, a, alpha) : alpha;
@@ -1073,13 +1112,45 @@ __device__ __forceinline__ void skip_interval_level(const VolConsts& vc, f3 oo, 
   t_first = fminf(fminf(quad_bcast<0>(first), quad_bcast<1>(first)), fminf(quad_bcast<2>(first), quad_bcast<3>(first)));
   t_last = fmaxf(fmaxf(quad_bcast<0>(last), quad_bcast<1>(last)), fmaxf(quad_bcast<2>(last), quad_bcast<3>(last)));
 }
-__device__ __forceinline__ void skip_interval(const VolConsts& vc, f3 oo, f3 od, float t0, float t1, int sub, bool live, float& t_first, float& t_last)
+// Measured (profiles/r03_notes.md, r03_ab_segments.txt): bit-identical frames, the march with skipping 2-4 % SLOWER on every bench
+// configuration and on the shipped scenes' shapes (C3 0.452 -> 0.467 ms, C2 0.334 -> 0.348, C5 1.70 -> 1.72) - their occupied macrocells are
+// one blob per ray, the hull already is the interval, and the mask costs registers and a 64-bit test per round.  Data with real interior
+// voids (the datasets do not ship) is where it would pay; off by default, -DOVR_SKIP_SEGMENTS=1 builds it.
+#ifndef OVR_SKIP_SEGMENTS
+#define OVR_SKIP_SEGMENTS 0
+#endif
+__device__ __forceinline__ SkipSpan skip_interval(const VolConsts& vc, f3 oo, f3 od, float t0, float t1, int sub, bool live)
 {
-  skip_interval_level<false>(vc, oo, od, t0, t1, sub, live, t_first, t_last);
+  SkipSpan sp = skipspan_none();
+  sp.mask_lo = sp.mask_hi = ~0u;
+  skip_interval_level<false>(vc, oo, od, t0, t1, sub, live, sp.first, sp.last);
   if (OVR_SKIP_FINE) {
-    const float c0 = t_first, c1 = t_last; // quad-uniform
-    if (__ballot(live && c0 <= c1) != 0ull) skip_interval_level<true>(vc, oo, od, c0, c1, sub, live && c0 <= c1, t_first, t_last);
+    const float c0 = sp.first, c1 = sp.last; // quad-uniform
+    if (__ballot(live && c0 <= c1) != 0ull) {
+      const bool walk = live && c0 <= c1;
+      if (!OVR_SKIP_SEGMENTS) skip_interval_level<true>(vc, oo, od, c0, c1, sub, walk, sp.first, sp.last);
+      else {
+        // the fine walk over the coarse hull [c0, c1], a quarter per lane: hull and segment mask in one pass
+        float first = FLT_MAX, last = -FLT_MAX;
+        unsigned long long m = 0ull;
+        const float len = c1 - c0;
+        const float scale = len > 0.f ? 64.f / len : 0.f;
+        if (walk) {
+          const float ta = fmaf((float)sub * 0.25f, len, c0), tb = sub == 3 ? c1 : fmaf((float)(sub + 1) * 0.25f, len, c0);
+          skip_walk<true, true>(vc, oo, od, ta, tb, first, last, c0, scale, &m);
+          if (!(len > 0.f)) m = ~0ull;
+        }
+        sp.first = fminf(fminf(quad_bcast<0>(first), quad_bcast<1>(first)), fminf(quad_bcast<2>(first), quad_bcast<3>(first)));
+        sp.last = fmaxf(fmaxf(quad_bcast<0>(last), quad_bcast<1>(last)), fmaxf(quad_bcast<2>(last), quad_bcast<3>(last)));
+        const float lo = __uint_as_float((unsigned int)m), hi = __uint_as_float((unsigned int)(m >> 32));
+        sp.mask_lo = __float_as_uint(quad_bcast<0>(lo)) | __float_as_uint(quad_bcast<1>(lo)) | __float_as_uint(quad_bcast<2>(lo)) | __float_as_uint(quad_bcast<3>(lo));
+        sp.mask_hi = __float_as_uint(quad_bcast<0>(hi)) | __float_as_uint(quad_bcast<1>(hi)) | __float_as_uint(quad_bcast<2>(hi)) | __float_as_uint(quad_bcast<3>(hi));
+        sp.seg0 = c0;
+        sp.seg_scale = scale;
+      }
+    }
   }
+  return sp;
 }
 
 template <int SHADE, bool POOLED> struct QCfg {
@@ -1140,7 +1211,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
   // empty-space skipping, neither does one whose rays only cross empty macrocells.
   ShadeReq* const queue = reinterpret_cast<ShadeReq*>(lds_raw) + (size_t)wave * (QCAP > 0 ? QCAP : 1);
   TfConsts tf;
-  float pro_first = FLT_MAX, pro_last = -FLT_MAX; // skipping, spp == 1: the ray's skip interval, found here once
+  SkipSpan pro_span = skipspan_none(); // skipping, spp == 1: the ray's skip hull and segment mask, found here once
   const float rsx = 1.f / (float)P.width, rsy = 1.f / (float)P.height;
   const float scx = ((float)ix + .5f) * rsx, scy = ((float)iy + .5f) * rsy;
   // pooled: one launch per sample-per-pixel generation (P.spp_index), in place: all here.  min(P.spp, 1) is 1, but as a
@@ -1189,8 +1260,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
       const f3 oo0 = to_object(mc, ld3(P.cam_pos)), od0 = mk3(d0.x * mc.inv_scale.x, d0.y * mc.inv_scale.y, d0.z * mc.inv_scale.z);
       need = intersect_unit_box(a0, b0, oo0, od0);
       if (SKIP && need) { // skipping: a ray that meets no occupied macrocell never fetches a voxel or a TF entry either
-        skip_interval(vc, oo0, od0, a0, b0, sub, true, pro_first, pro_last);
-        need = pro_first <= pro_last;
+        pro_span = skip_interval(vc, oo0, od0, a0, b0, sub, true);
+        need = pro_span.first <= pro_span.last;
       }
     }
     staged = __syncthreads_or(need ? 1 : 0) != 0;
@@ -1300,14 +1371,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
     gradient = mk3(0, 0, 0);
     bool live = active && intersect_unit_box(t0, t1, oo, od);
     if (active && owner) ++n_rays;
-    float skip_first = -FLT_MAX, skip_last = FLT_MAX; // samples outside [skip_first, skip_last] are in empty macrocells
+    SkipSpan span = skipspan_all(); // samples outside the hull, or in an unmarked segment of it, are in empty macrocells
     if (SKIP) {
-      if (P.spp == 1) { skip_first = pro_first; skip_last = pro_last; } // same ray, same [t0, t1] as in the prologue
-      else skip_interval(vc, oo, od, t0, t1, sub, live, skip_first, skip_last);
+      if (P.spp == 1) span = pro_span; // same ray, same [t0, t1] as in the prologue
+      else span = skip_interval(vc, oo, od, t0, t1, sub, live);
     }
     // `staged` guards the prologue's decision (it tests the same ray with the same expressions): without the tables and the TF
     // in LDS no sample may be fetched - a skipping ray then only counts its (all empty) steps, any other ray is dead
-    if (SKIP) { if (!staged) { skip_first = FLT_MAX; skip_last = -FLT_MAX; } }
+    if (SKIP) { if (!staged) span = skipspan_none(); }
     else live = live && staged;
     float tx = t0, ty = fminf(t1, t0 + mc.step);
     pend = 0;
@@ -1358,7 +1429,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
           nty = fminf(ntx + mc.step, t1);
         }
         const bool all_valid = ntx > ptx;                       // the round's last step: ty_last (= ntx) > tx_last (= ptx)
-        const bool outside = (ntx < skip_first) || (tx > skip_last);
+        const bool outside = !skipspan_touches(span, tx, ntx);
         const bool go = live && (alpha < 0.9999f);
         if (__ballot(live && !(outside && all_valid)) == 0ull) {
           n_skipped += go ? (unsigned int)K : 0u;               // this lane's K steps of the round
@@ -1404,7 +1475,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
         // (a) by the ray's skip interval: no coordinates, no majorant lookups
         bool inside = false;
 #pragma unroll
-        for (int k = 0; k < K; ++k) inside = inside || (tms[k] >= skip_first && tms[k] <= skip_last);
+        for (int k = 0; k < K; ++k) inside = inside || skipspan_inside(span, tms[k]);
         if (__ballot(inside && live) == 0ull) { skip_round(); continue; }
       }
 #pragma unroll
