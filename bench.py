@@ -185,7 +185,15 @@ def cpu_baseline(cfg, vol_host, colors, alphas, vr, cam, noise=None, budget_s=10
         if time.perf_counter() - t0 > budget_s or frames >= 4096:
             break
     dt = time.perf_counter() - t0
-    out = {"value": cnt.samples * frames / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port", "work": "same as GPU",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            models = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")]
+        if models:
+            cpu_model = f"{models[0]} ({len(models)} hardware threads)"
+    except OSError:
+        pass
+    out = {"value": cnt.samples * frames / dt / 1e6, "unit": "Msamples/s", "cores": cores, "cpu_model": cpu_model, "kind": "port", "work": "same as GPU",
            "fps_equivalent_full_frame": frames / dt / 16.0,
            "sample": f"{frames} frame(s) of the same scene at {w}x{h} (1/16 of the {cfg['width']}x{cfg['height']} rays), "
                      f"{cores} host threads, {dt:.1f} s"}
@@ -431,6 +439,10 @@ def worker(args, world):
                         kern[kname].update(bound=kb_["bound"], achieved=kb_["achieved"], peak=kb_["peak"], unit=kb_["unit"], frac=kb_["frac"])
                 else:
                     kern[kname]["bound_note"] = "no PMC profile of this configuration for these kernels: HBM assumed"
+                    if kern[kname]["frac"] > 1.0:
+                        # more algorithmic bytes than HBM can deliver: the caches serve them and HBM is not the bound - which unit is, only
+                        # the counters can say (tools/prof.sh); no fraction is printed rather than an HBM fraction above 1
+                        kern[kname].update(bound="cache-served (no counter profile)", hbm_algorithmic_frac=kern[kname]["frac"], frac=None, achieved=None, peak=None, unit=None)
         if "composite_kernel" in kern:
             # not algorithmic bytes but what this pipeline makes the kernel read besides the framebuffer: every request slot of the
             # frame's chunks (32 B each) - the reason its measured traffic is ~3 x its framebuffer bytes

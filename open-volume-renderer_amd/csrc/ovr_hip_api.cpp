@@ -136,6 +136,10 @@ struct ovr_hip_renderer {
   int tune_layout = -1, tune_pipeline = 0; // decided (-1 / 0 = leave it to the rules)
   int tune_frame = -1;         // candidate index of the frame in flight, -1 = not a tuned frame
   bool tune_on = true;
+  // A camera that moves on every frame (the interactive app) never sits still long enough to be measured: when only the camera changed, a
+  // measured decision is kept (the regime - transfer function, sampling rate, volume - is what decides, not the view), dropped as soon as a
+  // frame is no longer shade-heavy, and measured again once the configuration has been static for tune_recheck frames.
+  int tune_recheck = 0;
   int value_type = 0;
   float origin[3] = { 0, 0, 0 }, spacing[3] = { 1, 1, 1 };
   bool have_volume = false;
@@ -908,11 +912,21 @@ int finish_frame(ovr_hip_renderer* r)
       }
     }
   }
+  if (r->tune_on && r->tune_frame < 0 && r->tune_state == 2 && r->tune_recheck > 0) { // a decision kept across camera moves
+    const double shade_taps = 3.0 * (double)r->stats.shaded_samples + (double)r->stats.shadow_samples;
+    const bool heavy = r->P.shading != 0 && r->stats.samples > 0 && shade_taps >= 3.0 * (double)r->stats.samples;
+    if (!heavy) { r->tune_layout = -1; r->tune_pipeline = 0; r->tune_recheck = 0; }   // not that regime any more: back to the rules
+    else if (--r->tune_recheck == 0) r->tune_state = 0;                              // static for a while: measure again
+  }
   { // automatic shading pipeline of the next frame (see auto_inplace)
     const double steps = (double)r->stats.samples + (double)r->stats.skipped_samples, shaded = (double)r->stats.shaded_samples;
     if (steps > 0.0) {
-      if (shaded >= 0.50 * steps) r->auto_inplace = true;
-      else if (shaded < 0.35 * steps) r->auto_inplace = false;
+      // (round 3) ... unless the shadow marches are long - more than 60 iterations per shaded sample, i.e. sampling rates above ~2 (the
+      // stride is 10 / rate^2 voxels): then tiles differ again by what their shadow rays cross, and pooling wins by 30-50 % (C3 front /
+      // dense at rate 4: 22.7 ms in place, 13.4 pooled; profiles/r03_notes.md section 5)
+      const bool long_shadows = (double)r->stats.shadow_samples > 60.0 * std::max(shaded, 1.0);
+      if (shaded >= 0.50 * steps && !long_shadows) r->auto_inplace = true;
+      else if (shaded < 0.35 * steps || long_shadows) r->auto_inplace = false;
     }
   }
   if (r->frame_used_skip && r->skip_adaptive) { // did skipping pay?  (see skip_active)
@@ -1325,7 +1339,7 @@ int ovr_hip_commit(ovr_hip_renderer* r)
   std::lock_guard<std::mutex> lk(r->mtx);
   const bool reset_pending = r->fb_reset; // (without accumulation the flag is never consumed)
   r->fb_reset = false;
-  bool fb_size_updated = false;
+  bool fb_size_updated = false, camera_changed = false;
   if (r->fbsize.update()) { // device_impl.cpp:116-122
     if (int e = resize_framebuffers(r, r->fbsize.current.w, r->fbsize.current.h)) return e;
     fb_size_updated = true;
@@ -1338,7 +1352,10 @@ int ovr_hip_commit(ovr_hip_renderer* r)
     }
     r->sched_dirty = true;
     r->fb_reset = true;
+    camera_changed = !fb_size_updated;
   }
+  const bool only_camera_so_far = camera_changed;
+  if (camera_changed) r->fb_reset = false; // (restored below: the flag doubles as "something besides the camera changed")
   if (r->tfn.update()) { // :146-153
     if (int e = upload_tfn(r)) return e;
     update_tfn_range(r);
@@ -1365,11 +1382,14 @@ int ovr_hip_commit(ovr_hip_renderer* r)
     r->sched_list_dirty = true;
     r->fb_reset = true;
   }
-  if (r->fb_reset) {
+  const bool other_changed = r->fb_reset;
+  if (other_changed || only_camera_so_far) {
     r->pool_roomy = false; // something changed: the next frame's request count is unknown
-    r->tune_state = 0;     // ... and so are the fastest layout and pipeline
+    const bool keep = r->tune_on && !other_changed && r->tune_state == 2 && (r->tune_layout >= 0 || r->tune_pipeline != 0);
+    if (keep) r->tune_recheck = 12; // only the camera moved: the measured layout / pipeline stay (see tune_recheck)
+    else { r->tune_state = 0; r->tune_recheck = 0; } // ... and so are the fastest layout and pipeline
   }
-  r->fb_reset = r->fb_reset || reset_pending;
+  r->fb_reset = other_changed || only_camera_so_far || reset_pending;
   return 0;
 }
 

@@ -50,8 +50,21 @@ def test_measured_choice_keeps_the_frames(ovr, oracle, hip_renderer_factory, rat
     o_rgba, _, cnt = oracle_scene(oracle, case).render()
     assert seq[0][4][0] == cnt.samples and seq[0][4][1] == cnt.shaded_samples
     compare(oracle, seq[-1][0], o_rgba, name=f"tuned rate {rate}")
-    # a change of the configuration starts over; the decision itself is not an accumulation reset
+    # a camera that moves keeps the measured decision (an interactive session never rests long enough to be measured again) ...
+    won = (seq[-1][2], seq[-1][3])
     ren.set_camera(ovr.Camera(*ovr.synth.make_camera("front", 40), 60.0))
+    ren.commit()
+    ren.render()
+    st = ren.stats()
+    assert st.tuning == 2 and (st.layout, st.pipeline) == won
+    later = []
+    for _ in range(16):     # ... and measures again once the configuration has rested for a dozen frames
+        ren.render()
+        later.append(ren.stats().tuning)
+    assert later[:10] == [2] * 10 and 1 in later[11:], later
+    # any other change starts over with the rules
+    colors, alphas, vr = ovr.synth.make_tfn("bumps", 1024, np.float32)
+    ren.set_transfer_function(colors, alphas, vr)
     ren.commit()
     ren.render()
     assert ren.stats().tuning == 0

@@ -1,20 +1,28 @@
-"""ms per blocking render() of C3 with a static camera and with a camera that moves on every frame (every commit of a new camera
-rebuilds the launch order of the march: schedule kernels; accumulation restarts like in the reference).  usage: python tools/camera_path_time.py [n]"""
+"""ms per blocking render() of C3 with a static camera and with a camera that moves on every frame (every commit of a new camera rebuilds the
+launch order of the march: schedule kernels; accumulation restarts like in the reference).  Round 3: also the regime the interactive app runs
+the shipped scenes in - the scene files' sampling rate 4 with a dense transfer function - where a moving camera never sits still long enough
+for the renderer to measure layout and pipeline: the decision measured while the camera rested is kept while it moves.
+usage: python tools/camera_path_time.py [n] [rate] [tf]"""
 import sys, time
 sys.path[:0] = ['/root/repo', '/root/repo/tests']
 import numpy as np, torch, ovr_amd as ovr
 from test_full_size_gpu import _setup
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+rate = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+tf = sys.argv[3] if len(sys.argv) > 3 else 'sparse'
 vol = ovr.synth.make_volume_torch(n, torch.device('cuda', 0), 'float32')
 ren = _setup(ovr, ovr.create_renderer('hip'), vol, n, (1920, 1080), 2, accumulate=True)
+ren.set_volume_sampling_rate(rate)
+ren.set_transfer_function(*ovr.synth.make_tfn(tf, 1024, np.float32))
+ren.commit()
 eye, at, up = ovr.synth.make_camera('oblique', n)
 for moving in (False, True, False, True):
-    for _ in range(5):
+    for _ in range(14):
         ren.render()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    km = 0.0
+    km, seen = 0.0, set()
     for i in range(25):
         if moving:
             a = 0.002 * (i + 1)
@@ -22,8 +30,10 @@ for moving in (False, True, False, True):
             ren.set_camera(e, at, up)
             ren.commit()
         ren.render()
-        km += ren.stats().kernel_ms
+        st = ren.stats()
+        km += st.kernel_ms
+        seen.add((st.layout, st.pipeline, st.tuning))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 25 * 1e3
-    print(f"{'moving' if moving else 'static'} camera: {dt:.3f} ms per frame (march + shade + composite kernels {km / 25:.3f} ms)")
+    print(f"rate {rate} {tf}: {'moving' if moving else 'static'} camera: {dt:.3f} ms per frame (kernels {km / 25:.3f} ms), (layout, pipeline, tuning) seen: {sorted(seen)}")
 ren.close()
