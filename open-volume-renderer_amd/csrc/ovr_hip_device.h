@@ -145,13 +145,32 @@ template <> struct Vox<VOX_I8> {
   static constexpr bool kQuad = false;
 };
 
-// Quad replica (VoxelType in ovr_hip_kernels.h): a cell stores its 2 x 2 (x, y) voxels as one float4; 2 x 2 x 2 cells per brick.
-// (cx / mbx / by / bz describe the brick to the code that is shared with the other layouts; the pair type is not used)
+// Quad replicas (VoxelType in ovr_hip_kernels.h): a cell stores its 2 x 2 (x, y) voxels as one 4-vector Q; a 128-byte brick holds
+// 2^lx x 2^ly x 2^lz cells.  (cx / mbx / by / bz describe the brick to the code that is shared with the other layouts; P is not used)
 typedef float f32x4_q __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4_q __attribute__((ext_vector_type(4)));
+typedef unsigned char u8x4_q __attribute__((ext_vector_type(4)));
 template <> struct Vox<VOX_F32_Q> {
-  typedef float T; typedef f32x2_u P;
+  typedef float T; typedef f32x2_u P; typedef f32x4_q Q;
+  static constexpr int lx = 1, ly = 1, lz = 1;
   static constexpr int cx = 2, mbx = 16, by = 1, bz = 1;
   static constexpr bool kScale = false, kClamp = false;
+  static constexpr bool kTransposed = false;
+  static constexpr bool kQuad = true;
+};
+template <> struct Vox<VOX_U16_Q> {
+  typedef unsigned short T; typedef u16x2_u P; typedef u16x4_q Q;
+  static constexpr int lx = 2, ly = 1, lz = 1;
+  static constexpr int cx = 4, mbx = 8, by = 1, bz = 1;
+  static constexpr bool kScale = false, kClamp = false;
+  static constexpr bool kTransposed = false;
+  static constexpr bool kQuad = true;
+};
+template <> struct Vox<VOX_U8_Q> {
+  typedef unsigned char T; typedef u8x2_u P; typedef u8x4_q Q;
+  static constexpr int lx = 2, ly = 2, lz = 1;
+  static constexpr int cx = 4, mbx = 8, by = 2, bz = 1;
+  static constexpr bool kScale = true, kClamp = false; // normalized read like VOX_U8
   static constexpr bool kTransposed = false;
   static constexpr bool kQuad = true;
 };
@@ -183,14 +202,28 @@ template <int VT> struct BrickMap {
   }
 };
 
-// offsets in floats: cell (x, y, z) -> 4 floats at X(x) + Y(y) + Z(z); bricks x-fastest inside macro blocks of 16^3 bricks (32^3 cells)
-template <> struct BrickMap<VOX_F32_Q> {
-  static constexpr unsigned SX = 2, BV = 32, MV = 32u * 16u * 16u * 16u, MCX = 32;
-  static __host__ __device__ __forceinline__ unsigned div_cx(unsigned x) { return x >> 1; }
-  static __host__ __device__ __forceinline__ unsigned X(unsigned x) { return (x & 1u) * 4u + ((x >> 1) & 15u) * BV + (x >> 5) * MV; }
-  static __host__ __device__ __forceinline__ unsigned Y(unsigned y, unsigned macro_y_stride) { return (y & 1u) * 8u + ((y >> 1) & 15u) * (16u * BV) + (y >> 5) * macro_y_stride; }
-  static __host__ __device__ __forceinline__ unsigned Zlo(unsigned z) { return (z & 1u) * 16u + ((z >> 1) & 15u) * (256u * BV); }
+// quad replicas: offsets in voxels (elements of T); cell (x, y, z) -> 4 elements at X(x) + Y(y) + Z(z); cells x-fastest inside a brick, bricks
+// x-fastest inside macro blocks of 32^3 cells, macro blocks x-fastest
+template <int VT> struct QuadMap {
+  typedef Vox<VT> V;
+  static constexpr unsigned SX = 2, BV = 128u / (unsigned)sizeof(typename V::T);   // elements per brick
+  static constexpr unsigned MV = 32u * 32u * 32u * 4u, MCX = 32;                     // elements per macro block; cells per macro block along x
+  static constexpr unsigned bx_ = 32u >> V::lx, by_ = 32u >> V::ly;                  // bricks per macro block along x / y
+  static_assert((4u << (V::lx + V::ly + V::lz)) == BV, "a brick is exactly one 128-byte L1/L2 line");
+  static __host__ __device__ __forceinline__ unsigned div_cx(unsigned x) { return x >> V::lx; }
+  static __host__ __device__ __forceinline__ unsigned X(unsigned x) { return (x & ((1u << V::lx) - 1u)) * 4u + ((x >> V::lx) & (bx_ - 1u)) * BV + (x >> 5) * MV; }
+  static __host__ __device__ __forceinline__ unsigned Y(unsigned y, unsigned macro_y_stride)
+  {
+    return (y & ((1u << V::ly) - 1u)) * (4u << V::lx) + ((y >> V::ly) & (by_ - 1u)) * (bx_ * BV) + (y >> 5) * macro_y_stride;
+  }
+  static __host__ __device__ __forceinline__ unsigned Zlo(unsigned z)
+  {
+    return (z & ((1u << V::lz) - 1u)) * (4u << (V::lx + V::ly)) + ((z >> V::lz) & ((32u >> V::lz) - 1u)) * (bx_ * by_ * BV);
+  }
 };
+template <> struct BrickMap<VOX_F32_Q> : QuadMap<VOX_F32_Q> {};
+template <> struct BrickMap<VOX_U16_Q> : QuadMap<VOX_U16_Q> {};
+template <> struct BrickMap<VOX_U8_Q> : QuadMap<VOX_U8_Q> {};
 
 struct VolConsts {
   const void* data;
@@ -255,37 +288,38 @@ __device__ __forceinline__ void tap_loads(const VolConsts& vc, Tap& t)
   typedef BrickMap<VT> M;
   typedef typename Vox<VT>::T T;
   typedef typename Vox<VT>::P P;
-  if constexpr (Vox<VT>::kQuad) { // quad replica: the (x, y) footprint of a z slice is one 16-byte load
+  if constexpr (Vox<VT>::kQuad) { // quad replica: the (x, y) footprint of a z slice is ONE load (16 / 8 / 4 bytes)
+    typedef typename Vox<VT>::Q Q;
     const int z1 = min(t.z0 + 1, vc.nz1);
-    f32x4_q q0, q1;
+    Q q0, q1;
     if (AM == 3) {
       const unsigned o = M::X((unsigned)t.x0) + M::Y((unsigned)t.y0, vc.macro_y);
-      const float* base = static_cast<const float*>(vc.data);
+      const T* base = static_cast<const T*>(vc.data);
       const unsigned long long oz0 = (unsigned long long)M::Zlo((unsigned)t.z0) + (unsigned long long)((unsigned)t.z0 >> 5) * vc.macro_z;
       const unsigned long long oz1 = (unsigned long long)M::Zlo((unsigned)z1) + (unsigned long long)((unsigned)z1 >> 5) * vc.macro_z;
-      q0 = *reinterpret_cast<const f32x4_q*>(base + (oz0 + o)); q1 = *reinterpret_cast<const f32x4_q*>(base + (oz1 + o));
+      q0 = *reinterpret_cast<const Q*>(base + (oz0 + o)); q1 = *reinterpret_cast<const Q*>(base + (oz1 + o));
     }
     else if (AM == 2) {
       const unsigned o = vc.tab_x[t.x0] + vc.tab_y[t.y0];
       const unsigned long long oz0 = vc.tab_z64[t.z0], oz1 = vc.tab_z64[t.z0 + 1];
-      const float* base = static_cast<const float*>(vc.data);
-      q0 = *reinterpret_cast<const f32x4_q*>(base + (oz0 + o)); q1 = *reinterpret_cast<const f32x4_q*>(base + (oz1 + o));
+      const T* base = static_cast<const T*>(vc.data);
+      q0 = *reinterpret_cast<const Q*>(base + (oz0 + o)); q1 = *reinterpret_cast<const Q*>(base + (oz1 + o));
     }
     else {
       const unsigned o = vc.tab_x[t.x0] + vc.tab_y[t.y0];
       const unsigned oz0 = vc.tab_z[t.z0], oz1 = vc.tab_z[t.z0 + 1];
       if (AM == 1) {
-        const float* base = static_cast<const float*>(vc.data);
-        q0 = *reinterpret_cast<const f32x4_q*>(base + (oz0 + o)); q1 = *reinterpret_cast<const f32x4_q*>(base + (oz1 + o));
+        const T* base = static_cast<const T*>(vc.data);
+        q0 = *reinterpret_cast<const Q*>(base + (oz0 + o)); q1 = *reinterpret_cast<const Q*>(base + (oz1 + o));
       }
       else {
         const char* cb = static_cast<const char*>(vc.data);
-        q0 = *reinterpret_cast<const f32x4_q*>(cb + (oz0 + o)); q1 = *reinterpret_cast<const f32x4_q*>(cb + (oz1 + o));
+        q0 = *reinterpret_cast<const Q*>(cb + (oz0 + o)); q1 = *reinterpret_cast<const Q*>(cb + (oz1 + o));
       }
     }
     (void)z1;
-    t.c000 = q0.x; t.c100 = q0.y; t.c010 = q0.z; t.c110 = q0.w;
-    t.c001 = q1.x; t.c101 = q1.y; t.c011 = q1.z; t.c111 = q1.w;
+    t.c000 = (float)q0.x; t.c100 = (float)q0.y; t.c010 = (float)q0.z; t.c110 = (float)q0.w;
+    t.c001 = (float)q1.x; t.c101 = (float)q1.y; t.c011 = (float)q1.z; t.c111 = (float)q1.w;
     return;
   }
   // layout coordinates (a, b, c): a = the pair axis (the volume's x; its y in a transposed replica), b = the other of the two

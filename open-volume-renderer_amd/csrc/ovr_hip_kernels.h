@@ -9,8 +9,9 @@ namespace ovrhip {
 
 // device-resident scalar types of the bricked volume (u32/i32/f64 inputs are converted at upload, see relayout)
 // VOX_*_T / VOX_*_TT are not further scalar types but further LAYOUTS of a resident f32 / u16 volume ("thin" replicas, below)
-// VOX_F32_Q is the "quad" layout of a resident f32 volume (below)
-enum VoxelType : int { VOX_U8 = 0, VOX_I8 = 1, VOX_U16 = 2, VOX_I16 = 3, VOX_F32 = 4, VOX_F32_T = 5, VOX_F32_TT = 6, VOX_U16_T = 7, VOX_U16_TT = 8, VOX_F32_Q = 9 };
+// VOX_*_Q are the "quad" layouts of a resident f32 / u16 / u8 volume (below)
+enum VoxelType : int { VOX_U8 = 0, VOX_I8 = 1, VOX_U16 = 2, VOX_I16 = 3, VOX_F32 = 4, VOX_F32_T = 5, VOX_F32_TT = 6, VOX_U16_T = 7, VOX_U16_TT = 8, VOX_F32_Q = 9,
+                       VOX_U16_Q = 10, VOX_U8_Q = 11 };
 enum VolumeLayout : int { LAYOUT_GENERAL = 0, LAYOUT_THIN = 1, LAYOUT_THIN_T = 2, LAYOUT_QUAD = 3 };
 constexpr int kLayouts = 4;
 
@@ -33,9 +34,9 @@ constexpr int kLayouts = 4;
 //   same 8 voxels and lerps them in the same order from any layout, so frames are bit-identical; the host picks the replica
 //   per frame from the camera direction (ovr_hip_api.cpp: enqueue_frame).  Measured: profiles/r02_notes.md.
 //
-// Quad replica (round 3; f32): every cell (x, y, z) stores the four voxels (x, y), (x+1, y), (x, y+1), (x+1, y+1) of its z slice as
-//   16 contiguous bytes (clamp-to-edge baked in), 2 x 2 x 2 cells per 128-byte brick, 16^3 bricks per macro block - 4 x the memory.
-//   A trilinear tap is TWO 16-byte loads (cell z0 and cell z0 + 1) instead of four 8-byte pair loads.  The frames in which every
+// Quad replica (round 3; f32, u16, u8): every cell (x, y, z) stores the four voxels (x, y), (x+1, y), (x, y+1), (x+1, y+1) of its z slice
+//   contiguously (16 / 8 / 4 bytes, clamp-to-edge baked in), 2x2x2 / 4x2x2 / 4x4x2 cells per 128-byte brick, 32^3 cells per macro block -
+//   4 x the memory.  A trilinear tap is TWO loads (cell z0 and cell z0 + 1) instead of four pair loads.  The frames in which every
 //   sample is shaded - most of the reference's shipped scenes, and every frame at the scene files' sampling rate 4 - are bound by the
 //   texture addresser's instruction rate (16+ clocks per 64-lane gather whatever its width; TA / TD busy 84-97 %, VALU 80-100 %,
 //   profiles/r03_notes.md): half the gathers and three fewer address adds per tap are what moves them.  Same 8 voxels, same lerp

@@ -285,6 +285,8 @@ extern template hipError_t launch_v<VOX_F32_TT>(const RayMarchParams&, hipStream
 extern template hipError_t launch_v<VOX_U16_T>(const RayMarchParams&, hipStream_t, const hipEvent_t*);
 extern template hipError_t launch_v<VOX_U16_TT>(const RayMarchParams&, hipStream_t, const hipEvent_t*);
 extern template hipError_t launch_v<VOX_F32_Q>(const RayMarchParams&, hipStream_t, const hipEvent_t*);
+extern template hipError_t launch_v<VOX_U16_Q>(const RayMarchParams&, hipStream_t, const hipEvent_t*);
+extern template hipError_t launch_v<VOX_U8_Q>(const RayMarchParams&, hipStream_t, const hipEvent_t*);
 
 size_t pool_shade_blocks() { return kShadeBlocks; }
 
@@ -304,6 +306,8 @@ hipError_t launch_raymarch(const RayMarchParams& p, hipStream_t stream, const hi
   case VOX_U16_T: e = launch_v<VOX_U16_T>(p, stream, ev); break;
   case VOX_U16_TT: e = launch_v<VOX_U16_TT>(p, stream, ev); break;
   case VOX_F32_Q: e = launch_v<VOX_F32_Q>(p, stream, ev); break;
+  case VOX_U16_Q: e = launch_v<VOX_U16_Q>(p, stream, ev); break;
+  case VOX_U8_Q: e = launch_v<VOX_U8_Q>(p, stream, ev); break;
   default: e = hipErrorInvalidValue;
   }
   if (ev) (void)hipEventRecord(ev[3], stream);
@@ -327,8 +331,8 @@ int device_voxel_type(int t)
 size_t voxel_size(int vt)
 {
   switch (vt) {
-  case VOX_U8: case VOX_I8: return 1;
-  case VOX_U16: case VOX_I16: case VOX_U16_T: case VOX_U16_TT: return 2;
+  case VOX_U8: case VOX_I8: case VOX_U8_Q: return 1;
+  case VOX_U16: case VOX_I16: case VOX_U16_T: case VOX_U16_TT: case VOX_U16_Q: return 2;
   default: return 4;
   }
 }
@@ -336,7 +340,8 @@ int replica_voxel_type(int base, int layout)
 {
   if (layout == LAYOUT_GENERAL) return base;
   if (base == VOX_F32) return layout == LAYOUT_THIN ? VOX_F32_T : layout == LAYOUT_THIN_T ? VOX_F32_TT : layout == LAYOUT_QUAD ? VOX_F32_Q : -1;
-  if (base == VOX_U16) return layout == LAYOUT_THIN ? VOX_U16_T : layout == LAYOUT_THIN_T ? VOX_U16_TT : -1;
+  if (base == VOX_U16) return layout == LAYOUT_THIN ? VOX_U16_T : layout == LAYOUT_THIN_T ? VOX_U16_TT : layout == LAYOUT_QUAD ? VOX_U16_Q : -1;
+  if (base == VOX_U8) return layout == LAYOUT_QUAD ? VOX_U8_Q : -1;
   return -1;
 }
 
@@ -370,29 +375,31 @@ __global__ __launch_bounds__(256) void relayout_kernel(const TI* __restrict__ sr
   dst[off] = Conv<TI, TO>::cv(v);
 }
 
-// quad replica: one thread per cell writes the cell's 2 x 2 (x, y) voxels of its z slice as one float4, neighbours beyond the
+// quad replicas: one thread per cell writes the cell's 2 x 2 (x, y) voxels of its z slice as one 4-vector, neighbours beyond the
 // grid replaced by the last voxel (clamp-to-edge addressing)
-template <typename TI>
-__global__ __launch_bounds__(256) void relayout_quad_kernel(const TI* __restrict__ src, float* __restrict__ dst, int nx, int ny, unsigned int macro_y, unsigned long long macro_z,
-                                                           int z0, int nz_chunk)
+template <typename TI, int VT>
+__global__ __launch_bounds__(256) void relayout_quad_kernel(const TI* __restrict__ src, typename Vox<VT>::T* __restrict__ dst, int nx, int ny, unsigned int macro_y,
+                                                           unsigned long long macro_z, int z0, int nz_chunk)
 {
-  typedef BrickMap<VOX_F32_Q> M;
+  typedef BrickMap<VT> M;
+  typedef typename Vox<VT>::T TO;
+  typedef typename Vox<VT>::Q Q;
   const int x = (int)(blockIdx.x * 256u + threadIdx.x), y = (int)blockIdx.y, zl = (int)blockIdx.z;
   if (x >= nx || zl >= nz_chunk) return;
   const int x1 = min(x + 1, nx - 1), y1 = min(y + 1, ny - 1);
   const TI* sl = src + (size_t)nx * (size_t)ny * (size_t)zl;
-  float4 q;
-  q.x = Conv<TI, float>::cv(sl[x + (size_t)nx * y]); q.y = Conv<TI, float>::cv(sl[x1 + (size_t)nx * y]);
-  q.z = Conv<TI, float>::cv(sl[x + (size_t)nx * y1]); q.w = Conv<TI, float>::cv(sl[x1 + (size_t)nx * y1]);
+  Q q;
+  q.x = Conv<TI, TO>::cv(sl[x + (size_t)nx * y]); q.y = Conv<TI, TO>::cv(sl[x1 + (size_t)nx * y]);
+  q.z = Conv<TI, TO>::cv(sl[x + (size_t)nx * y1]); q.w = Conv<TI, TO>::cv(sl[x1 + (size_t)nx * y1]);
   const unsigned z = (unsigned)(z0 + zl);
   const unsigned long long off = (unsigned long long)(M::X((unsigned)x) + M::Y((unsigned)y, macro_y)) + M::Zlo(z) + (unsigned long long)(z >> 5) * macro_z;
-  *reinterpret_cast<float4*>(dst + off) = q;
+  *reinterpret_cast<Q*>(dst + off) = q;
 }
-template <typename TI>
+template <typename TI, int VT>
 static hipError_t relayout_quad_t(const void* src, void* dst, const VolumeDesc& vd, int z0, int nzc, hipStream_t stream)
 {
   dim3 grid((unsigned)((vd.nx + 255) / 256), (unsigned)vd.ny, (unsigned)nzc);
-  hipLaunchKernelGGL(relayout_quad_kernel<TI>, grid, dim3(256), 0, stream, (const TI*)src, (float*)dst, vd.nx, vd.ny, vd.macro_elems * (unsigned)vd.macros_x,
+  hipLaunchKernelGGL((relayout_quad_kernel<TI, VT>), grid, dim3(256), 0, stream, (const TI*)src, (typename Vox<VT>::T*)dst, vd.nx, vd.ny, vd.macro_elems * (unsigned)vd.macros_x,
                      (unsigned long long)vd.macro_elems * (unsigned long long)vd.macros_x * (unsigned long long)vd.macros_y, z0, nzc);
   return hipGetLastError();
 }
@@ -435,6 +442,8 @@ void volume_layout(int voxel_type, int nx, int ny, int nz, VolumeDesc& vd)
   case VOX_U16_T: volume_layout_t<VOX_U16_T>(nx, ny, nz, vd); break;
   case VOX_U16_TT: volume_layout_t<VOX_U16_TT>(nx, ny, nz, vd); break;
   case VOX_F32_Q: volume_layout_t<VOX_F32_Q>(nx, ny, nz, vd); break;
+  case VOX_U16_Q: volume_layout_t<VOX_U16_Q>(nx, ny, nz, vd); break;
+  case VOX_U8_Q: volume_layout_t<VOX_U8_Q>(nx, ny, nz, vd); break;
   default: volume_layout_t<VOX_F32>(nx, ny, nz, vd); break;
   }
 }
@@ -446,7 +455,7 @@ static hipError_t relayout_f32(const void* src, void* dst, const VolumeDesc& vd,
   case VOX_F32: return relayout_t<TI, float, VOX_F32>(src, dst, vd, z0, nzc, stream);
   case VOX_F32_T: return relayout_t<TI, float, VOX_F32_T>(src, dst, vd, z0, nzc, stream);
   case VOX_F32_TT: return relayout_t<TI, float, VOX_F32_TT>(src, dst, vd, z0, nzc, stream);
-  case VOX_F32_Q: return relayout_quad_t<TI>(src, dst, vd, z0, nzc, stream);
+  case VOX_F32_Q: return relayout_quad_t<TI, VOX_F32_Q>(src, dst, vd, z0, nzc, stream);
   default: return hipErrorInvalidValue;
   }
 }
@@ -454,13 +463,16 @@ static hipError_t relayout_f32(const void* src, void* dst, const VolumeDesc& vd,
 hipError_t launch_relayout(const void* src, int vt, void* dst, const VolumeDesc& vd, int z0, int nzc, hipStream_t stream)
 {
   switch (vt) {
-  case 100: return relayout_t<unsigned char, unsigned char, VOX_U8>(src, dst, vd, z0, nzc, stream);
+  case 100:
+    if (vd.type == VOX_U8_Q) return relayout_quad_t<unsigned char, VOX_U8_Q>(src, dst, vd, z0, nzc, stream);
+    return relayout_t<unsigned char, unsigned char, VOX_U8>(src, dst, vd, z0, nzc, stream);
   case 101: return relayout_t<signed char, signed char, VOX_I8>(src, dst, vd, z0, nzc, stream);
   case 200:
     switch (vd.type) {
     case VOX_U16: return relayout_t<unsigned short, unsigned short, VOX_U16>(src, dst, vd, z0, nzc, stream);
     case VOX_U16_T: return relayout_t<unsigned short, unsigned short, VOX_U16_T>(src, dst, vd, z0, nzc, stream);
     case VOX_U16_TT: return relayout_t<unsigned short, unsigned short, VOX_U16_TT>(src, dst, vd, z0, nzc, stream);
+    case VOX_U16_Q: return relayout_quad_t<unsigned short, VOX_U16_Q>(src, dst, vd, z0, nzc, stream);
     default: return hipErrorInvalidValue;
     }
   case 201: return relayout_t<short, short, VOX_I16>(src, dst, vd, z0, nzc, stream);
@@ -516,6 +528,8 @@ hipError_t launch_axis_tables(VolumeDesc& vd, void* d_tables, hipStream_t stream
   case VOX_U16_T: return axis_tables_t<VOX_U16_T>(vd, ab, tz, stream);
   case VOX_U16_TT: return axis_tables_t<VOX_U16_TT>(vd, ab, tz, stream);
   case VOX_F32_Q: return axis_tables_t<VOX_F32_Q>(vd, ab, tz, stream);
+  case VOX_U16_Q: return axis_tables_t<VOX_U16_Q>(vd, ab, tz, stream);
+  case VOX_U8_Q: return axis_tables_t<VOX_U8_Q>(vd, ab, tz, stream);
   default: return hipErrorInvalidValue;
   }
 }

@@ -82,8 +82,10 @@ def test_addressing_mode_selection(ovr):
     assert mode((8, 8, 30000), 100) == 3
     assert mode((20000, 8, 8)) == 0                     # 80 KB of tables still fit
     assert mode((20000, 8, 8), nc=4096, na=4096) == 3   # ... not next to an 80 KiB transfer function
-    assert mode((64, 64, 64), 100, layout=1) < 0        # 8-bit volumes have no thin replicas
-    assert mode((64, 64, 64), 200, layout=3) < 0        # 16-bit volumes have no quad replica
+    assert mode((64, 64, 64), 100, layout=1) < 0        # 8-bit volumes have no thin replicas ...
+    assert mode((64, 64, 64), 100, layout=3) == 0       # ... but a quad replica, like 16-bit and float volumes
+    assert mode((2048, 2048, 2048), 200, layout=3) == 2 # C4's would be 64 GiB
+    assert mode((64, 64, 64), 201, layout=3) < 0        # signed types: general layout only
 
 
 def test_no_cpu_fallback(ovr):

@@ -275,11 +275,11 @@ def _layout_case(ovr, oracle, dtype, dims, cam, shading=2, size=(88, 56)):
     return case
 
 
-@pytest.mark.parametrize("dtype", [np.float32, np.uint16, np.float64])
+@pytest.mark.parametrize("dtype", [np.float32, np.uint16, np.float64, np.uint8])
 @pytest.mark.parametrize("cam", ["x", "y", "z", "oblique"])
 def test_layouts_are_bit_identical(ovr, oracle, hip_renderer_factory, dtype, cam):
-    """the general layout, the two thin replicas (pair axis x / pair axis y) and - for float volumes - the quad replica (round 3: a tap is
-    two 16-byte loads) of a non-cubic volume give the same frame bit for bit - with and without empty-space skipping, both pipelines -
+    """the general layout, the two thin replicas (pair axis x / pair axis y; float and 16-bit volumes) and the quad replica (round 3: a tap is
+    two loads; float, 16-bit and 8-bit volumes) of a non-cubic volume give the same frame bit for bit - with and without empty-space skipping, both pipelines -
     and that frame agrees with the oracle"""
     dims = (45, 70, 33)   # nx != ny != nz: an exchanged axis cannot go unnoticed
     case = _layout_case(ovr, oracle, dtype, dims, cam)
@@ -287,7 +287,7 @@ def test_layouts_are_bit_identical(ovr, oracle, hip_renderer_factory, dtype, cam
     ren.set_volume_layouts(2)
     hip_setup(ovr, ren, case)
     frames = {}
-    for choice in (0, 1, 2, 3) if np.dtype(dtype) != np.uint16 else (0, 1, 2):
+    for choice in (0, 1, 2, 3) if np.dtype(dtype) != np.uint8 else (0, 3):
         for skip, pipeline in ((False, 0), (True, 0), (False, 1)):
             ren.set_layout_choice(choice)
             ren.set_empty_space_skipping(skip)
@@ -305,9 +305,8 @@ def test_layouts_are_bit_identical(ovr, oracle, hip_renderer_factory, dtype, cam
     assert ref_cnt[0] == cnt.samples and ref_cnt[1] == cnt.shaded_samples and cnt.shaded_samples > 100
     compare(oracle, ref_rgba, o_rgba, name=f"layouts {np.dtype(dtype).name} {cam}")
     info = ren.volume_info()
-    assert info.resident_bytes > 3 * case["vol"].size * min(case["vol"].itemsize, 4)   # general (x 4/3) + two thin (x 2 each) [+ quad x 4]
-    if np.dtype(dtype) != np.uint16:
-        assert info.resident_bytes > 9 * case["vol"].size * 4
+    # general (x 4/3) + two thin (x 2 each, not for 8-bit) + quad (x 4)
+    assert info.resident_bytes > (5 if np.dtype(dtype) == np.uint8 else 9) * case["vol"].size * min(case["vol"].itemsize, 4)
     ren.close()
 
 
@@ -341,10 +340,11 @@ def test_layout_follows_the_camera(ovr, oracle, hip_renderer_factory):
     ren.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.uint16, np.uint8])
 @pytest.mark.parametrize("mode", [1, 2, 3])
-def test_quad_layout_in_every_addressing_mode(ovr, oracle, hip_renderer_factory, mode):
+def test_quad_layout_in_every_addressing_mode(ovr, oracle, hip_renderer_factory, mode, dtype):
     """the quad replica under the 32-bit element, 64-bit z-table and computed addressing modes; in place and pooled, with skipping"""
-    case = _layout_case(ovr, oracle, np.float32, (37, 29, 50), "oblique", shading=2, size=(64, 40))
+    case = _layout_case(ovr, oracle, dtype, (37, 29, 50), "oblique", shading=2, size=(64, 40))
     ren = hip_renderer_factory()
     ren.set_volume_layouts(2)
     hip_setup(ovr, ren, case)
