@@ -88,12 +88,13 @@ def layout_bytes(dtype, n, layout):
 
 
 def kernels_hash():
-    """hash of the device + host sources of libovr_hip.so: a committed PMC traffic measurement is only quoted for the
-    kernels it was taken from"""
+    """hash of the DEVICE sources of libovr_hip.so (kernels, their launch code and parameter structures; round 3: not the host state
+    machine ovr_hip_api.cpp any more - a fix to mapframe must not disown every counter profile): a committed PMC measurement is only
+    quoted for the kernels it was taken from"""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "open-volume-renderer_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h", ".cpp")):
+        if name.endswith((".hip", ".h")):
             with open(os.path.join(d, name), "rb") as f:
                 h.update(f.read())
     return h.hexdigest()[:16]
@@ -124,7 +125,9 @@ def kernel_bound(kms, abytes, ctr):
          "ta": ctr.get("SQ_INSTS_VMEM_RD", 0.0) * GATHER_CLK / (N_CU * clocks),
          "valu": min(ctr.get("SQ_INSTS_VALU", 0.0) * VALU_CLK / (N_SIMD * clocks), 1.0)}
     bound = max(u, key=lambda k: u[k])
-    if bound == "hbm" and abytes > traffic * 1.02:
+    # (15 % tolerance: the headline's march moves 7.1 GB for 7.6 GB of algorithmic bytes - the caches serve 7 % of them and the memory side
+    # is still what it waits for; at 4K or at sampling rate 4 the algorithmic bytes are 2.5 ... 10 x the traffic)
+    if bound == "hbm" and abytes > traffic * 1.15:
         bound = max(("ta", "valu"), key=lambda k: u[k])
     out = {"bound": bound, "utilisation": {k: round(v, 4) for k, v in u.items()}, "traffic": traffic, "clock_ghz": clocks / t_prof / 1e9,
            "l1_fill_bytes": ctr.get("TCP_TCC_READ_REQ_sum", 0.0) * 128.0, "ta_busy": ctr.get("TA_TA_BUSY_sum", 0.0) / (N_CU * clocks)}
@@ -133,7 +136,9 @@ def kernel_bound(kms, abytes, ctr):
     elif bound == "valu":
         out.update(achieved=ctr["SQ_INSTS_VALU"] / t_prof / 1e9, peak=N_SIMD * (clocks / t_prof) / VALU_CLK / 1e9, unit="G vector instr/s")
     if bound != "hbm":
-        out["frac"] = out["achieved"] / out["peak"]
+        # (the 4-clock price is v_fma_f32's; v_add / v_mul / v_mov issue in 2.4-2.8 clocks, tools/ubench_valu.hip: a kernel full of them can
+        # exceed the nominal peak - the fraction is capped, the utilisation says "saturated")
+        out["frac"] = min(out["achieved"] / out["peak"], 1.0)
     return out
 
 
@@ -256,6 +261,11 @@ def main():
 
 
 def worker(args, world):
+    # stdout carries exactly ONE line, the JSON: libraries that print banners there (RCCL's version block at the first collective, gloo's
+    # connection messages) are routed to stderr for the lifetime of the worker
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import ovr_amd as ovr
@@ -683,7 +693,8 @@ def worker(args, world):
             out["with_empty_space_skipping"] = skip_leg
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(cfg, vol_host, colors, alphas, vr, cam, noise)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

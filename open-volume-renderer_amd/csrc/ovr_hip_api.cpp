@@ -181,6 +181,7 @@ struct ovr_hip_renderer {
   // the pixel rectangle each host mirror was last refreshed in ({x0, y0, x1, y1}, empty at first): mapframe(HOST) copies only the
   // rectangle the volume's box projects into - every pixel outside it is exactly 0 on the device and stays 0 in the mirror
   int h_rgba_rect[2][4] = {}, h_grad_rect[2][4] = {};
+  int d_rect[2][4] = {}; // per framebuffer set: the rectangle of the camera its last frame was rendered with (empty: never rendered, all zeros)
   float* d_accum = nullptr;
   uint32_t* d_rgba8 = nullptr; // mapframe_rgba8: device and pinned host copy of the 8-bit frame
   uint32_t* h_rgba8 = nullptr;
@@ -305,6 +306,8 @@ int resize_framebuffers(ovr_hip_renderer* r, int w, int h)
     }
   }
   r->fb_pixels = n;
+  for (int i = 0; i < 2; ++i)
+    for (int k = 0; k < 4; ++k) r->d_rect[i][k] = r->h_rgba_rect[i][k] = r->h_grad_rect[i][k] = 0;
   return 0;
 }
 
@@ -492,11 +495,12 @@ void nonzero_rect(const ovr_hip_renderer* r, int rect[4])
 }
 
 // device layer -> pinned host mirror, only where a pixel can differ from 0 now or could when the mirror was last refreshed
-int refresh_mirror(ovr_hip_renderer* r, float* host, const float* dev, int channels, int last[4], hipStream_t st)
+int refresh_mirror(ovr_hip_renderer* r, float* host, const float* dev, int channels, const int dev_rect[4], int last[4], hipStream_t st)
 {
   const int W = r->fbsize.current.w;
-  int now[4];
-  nonzero_rect(r, now);
+  // what the DEVICE set holds is the frame of the camera it was last rendered with - renderapp commits the next camera before it maps
+  // the previous frame (main_app.cpp:244-263) - so the rectangle is the one recorded at render time, not the committed camera's
+  int now[4] = { dev_rect[0], dev_rect[1], dev_rect[2], dev_rect[3] };
   static const bool whole = getenv("OVR_HIP_MAP_WHOLE_FRAME") != nullptr; // measurements: the uncropped copy
   if (whole) { now[0] = 0; now[1] = 0; now[2] = W; now[3] = r->fbsize.current.h; }
   int u[4] = { now[0], now[1], now[2], now[3] };
@@ -634,6 +638,7 @@ int enqueue_frame(ovr_hip_renderer* r)
   r->frame_index++;
 
   P.rgba = r->d_rgba[r->cur];
+  nonzero_rect(r, r->d_rect[r->cur]); // what mapframe(HOST) will have to copy of this set (the committed camera is the one this frame renders)
   P.grad = r->d_grad[r->cur];
   P.accum = r->d_accum;
   P.width = W;
@@ -1447,14 +1452,14 @@ int ovr_hip_mapframe(ovr_hip_renderer* r, int mem_kind, const float** rgba, size
     std::memset(r->h_rgba[c], 0, n * 4 * sizeof(float));
     for (int k = 0; k < 4; ++k) r->h_rgba_rect[c][k] = 0;
   }
-  if (int e = refresh_mirror(r, r->h_rgba[c], r->d_rgba[c], 4, r->h_rgba_rect[c], st)) return e;
+  if (int e = refresh_mirror(r, r->h_rgba[c], r->d_rgba[c], 4, r->d_rect[c], r->h_rgba_rect[c], st)) return e;
   if (grad) {
     if (!r->h_grad[c]) {
       HIP_TRY(hipHostMalloc((void**)&r->h_grad[c], n * 3 * sizeof(float), hipHostMallocDefault));
       std::memset(r->h_grad[c], 0, n * 3 * sizeof(float));
       for (int k = 0; k < 4; ++k) r->h_grad_rect[c][k] = 0;
     }
-    if (int e = refresh_mirror(r, r->h_grad[c], r->d_grad[c], 3, r->h_grad_rect[c], st)) return e;
+    if (int e = refresh_mirror(r, r->h_grad[c], r->d_grad[c], 3, r->d_rect[c], r->h_grad_rect[c], st)) return e;
   }
   HIP_TRY(hipStreamSynchronize(st));
   *rgba = r->h_rgba[c];

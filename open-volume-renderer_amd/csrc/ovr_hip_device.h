@@ -480,10 +480,15 @@ __device__ __forceinline__ float tf_coord(const TfConsts& tf, float sample)
 // (both tables carry one more entry, a copy of their last one - stage_tf - so that (i0, i0 + 1) is the reference's clamp-to-edge pair
 // without min(i0 + 1, n - 1): i0 = n - 1 only for v = 1, where the fraction is 0 and lerp(a, a, 0) = a; the two alphas arrive with
 // one ds_read2_b32.  Three instructions fewer per lookup, i.e. per shadow sample.)
+// PAD = false keeps the two separate reads with min(i0 + 1, n - 1): the POOLED march of the headline (bound by L1 fills, not by instructions)
+// is 4 % slower with the paired read - 1.512 -> 1.577 ms on C3, same box, four alternating runs (profiles/r03_ab/r03_ab_regress2.txt) - while every
+// instruction-bound kernel gains 1-4 % from it (shadow march at rate 4, the in-place kernels of the shipped scenes, C2, C5)
+template <bool PAD = true>
 __device__ __forceinline__ float tf_alpha(const TfConsts& tf, float v)
 {
   const float x = v * tf.fna1;                      // v in [0, 1]: x >= 0, see axis_tap
   const int i0 = (int)x;
+  if (!PAD) return lerpf(tf.alpha[i0], tf.alpha[min(i0 + 1, tf.na1)], __builtin_amdgcn_fractf(x));
   return lerpf(tf.alpha[i0], tf.alpha[i0 + 1], __builtin_amdgcn_fractf(x));
 }
 __device__ __forceinline__ f3 tf_color(const TfConsts& tf, float v)
@@ -1625,7 +1630,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
       for (int k = 0; k < K; ++k) {
         sa[k] = tap_finish<VT>(vc, taps[k]);
         va[k] = tf_coord(tf, sa[k]);
-        aa[k] = opacity_correction<false>(tf_alpha(tf, va[k]), mc.base * dts[k]);
+#ifndef OVR_MARCH_TF_PAD
+#define OVR_MARCH_TF_PAD 0 /* 1: the pooled march takes the paired read too (measurements) */
+#endif
+        aa[k] = opacity_correction<false>(tf_alpha<!POOLED || OVR_MARCH_TF_PAD>(tf, va[k]), mc.base * dts[k]);
         if (SKIP) aa[k] = mj[k] > 0.f ? aa[k] : 0.f; // a macrocell whose majorant is 0 holds no sample with opacity > 0
         if (SHADE == 0) {
           const f3 rgb = tf_color(tf, va[k]);

@@ -200,6 +200,14 @@ def test_mapframe_copies_only_the_box_rectangle(ovr, oracle, hip_renderer_factor
     check("shifted")
     ren.swap(); ren.render()
     check("other set")
+    # renderapp's order (main_app.cpp:244-263): the NEXT camera is committed before the previous frame is mapped - the mirror must show the frame
+    # that is on the device (rendered with the old camera), not the rectangle of the camera just committed
+    before = check("before")
+    ren.set_camera(ovr.Camera(tuple(np.array(at) + 1.5 * (np.array(eye) - np.array(at)) + np.array((60.0, -30.0, 10.0))), at, up, 60.0)); ren.commit()
+    after = check("committed, not rendered")
+    assert np.array_equal(before, after)
+    ren.render()
+    check("rendered")
     ren.set_camera(ovr.Camera(tuple(np.array(at) + 0.2 * (np.array(eye) - np.array(at))), at, up, 60.0)); ren.commit(); ren.render()   # eye inside the box
     c = check("inside")
     assert (c[..., 3] > 0).mean() > 0.9
