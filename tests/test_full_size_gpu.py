@@ -2,6 +2,7 @@
 pipelines and options that must not change a single bit, conservation of the sample counters, sharded == unsharded, and the
 oracle itself on a 1/64 subset of the pixels of the full-size frame."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -61,6 +62,49 @@ def test_c3_invariants(ovr, oracle, hip_renderer_factory, c3_volume):
             assert st.shaded_samples == stats_ref.shaded_samples
             assert st.shadow_samples + st.skipped_shadow_samples == stats_ref.shadow_samples
         ren.close()
+
+
+def test_c3_shade_heavy_regime_at_full_size(ovr, oracle, hip_renderer_factory, c3_volume):
+    """C3's volume under a dense transfer function at the scene files' sampling rate 4 (round 3: every sample shaded, long shadow
+    marches): general layout in place == quad replica pooled == whatever the renderer's measuring settles on, bit for bit, with the same
+    counters; the measured choice is not slower than the rules' (it timed them); and the oracle agrees on 1/64 of the tiles"""
+    n, size, tile = 1024, (1920, 1080), 64
+    frames = {}
+    for tag, layout, pipeline, tune in (("general in place", 0, 1, "0"), ("quad pooled", 3, 2, "0"), ("measured", -1, 0, "1")):
+        os.environ["OVR_HIP_TUNE"] = tune
+        try:
+            ren = hip_renderer_factory()
+        finally:
+            del os.environ["OVR_HIP_TUNE"]
+        ren.set_layout_choice(layout)
+        ren.set_volume_sampling_rate(4.0)
+        _setup(ovr, ren, c3_volume, n, size, 2, tf="dense", cam="front", pipeline=pipeline)
+        ren.set_volume_sampling_rate(4.0)
+        ren.commit()
+        ms = []
+        for _ in range(12 if tag == "measured" else 2):
+            ren.render()
+            ms.append(ren.stats().kernel_ms)
+        st = ren.stats()
+        frames[tag] = (_frame(ovr, ren), (st.samples, st.shaded_samples, st.shadow_samples), ms[-1], (st.layout, st.pipeline, st.tuning))
+        ren.close()
+    ref, cnt, ms_rules, _ = frames["general in place"]
+    assert np.isfinite(ref).all() and cnt[1] == cnt[0] and cnt[2] > 50 * cnt[0]          # all shaded, > 50 shadow iterations per sample
+    for tag, (f, c, _, _) in frames.items():
+        assert np.array_equal(f, ref) and c == cnt, tag
+    assert frames["quad pooled"][3][:2] == (3, 2) and frames["measured"][3][2] == 2
+    assert frames["measured"][2] <= 1.05 * min(ms_rules, frames["quad pooled"][2]), {k: v[2:] for k, v in frames.items()}
+    vol_host = c3_volume.cpu().numpy()
+    colors, alphas, vr = ovr.synth.make_tfn("dense", 1024)
+    sc = oracle.OracleScene(vol_host, colors, alphas, vr, ovr.synth.make_camera("front", n), size[0], size[1], rate=4.0, shading=oracle.SHADE_FULL,
+                            shard=(23, 64, tile, tile), skip_zero_opacity=True)
+    o_rgba, _, ocnt = sc.render()
+    mask = np.zeros((size[1], size[0]), bool)
+    for tx, ty in ovr.tiles.owned_tiles(size[0], size[1], tile, tile, 23, 64):
+        mask[ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile] = True
+    assert ocnt.samples > 1e5
+    d8 = np.abs(oracle.rgba8(ref, flip=False).astype(int) - oracle.rgba8(o_rgba, flip=False).astype(int))[mask]
+    assert d8.max() <= 1 and np.abs(ref - o_rgba)[mask].max() <= 2e-4
 
 
 def test_c3_shards_and_oracle_subset(ovr, oracle, hip_renderer_factory, c3_volume):
