@@ -749,6 +749,8 @@ int enqueue_frame(ovr_hip_renderer* r)
       r->sched_dirty = false;
     }
     P.schedule = r->d_sched;
+    static const bool unsorted = getenv("OVR_HIP_SCHED_SORT") && atoi(getenv("OVR_HIP_SCHED_SORT")) == 0; // experiment: image (supertile) order
+    if (unsorted) P.schedule = r->d_sched_src;
     P.n_schedule = r->n_sched;
   }
   if (sparse) { // createSparseSamples, device_impl.cpp:304-342
