@@ -1635,10 +1635,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
 #endif
         aa[k] = opacity_correction<false>(tf_alpha<!POOLED || OVR_MARCH_TF_PAD>(tf, va[k]), mc.base * dts[k]);
         if (SKIP) aa[k] = mj[k] > 0.f ? aa[k] : 0.f; // a macrocell whose majorant is 0 holds no sample with opacity > 0
-        if (SHADE == 0) {
-          const f3 rgb = tf_color(tf, va[k]);
-          ca[k] = mk3(clamp01(rgb.x), clamp01(rgb.y), clamp01(rgb.z));
-        }
       }
       // ---- (3b) transparent round (wave-uniform; ~9 of 10 rounds with a sparse transfer function): no live sample of any
       //      ray of the wave has opacity > 0, so every step adds exactly 0 to alpha and colour (fma(tr, 0, x) == x) and
@@ -1661,6 +1657,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
           }
           live = go && ((vmask >> (4 * K - 1)) & 1u) != 0u;
           continue;
+        }
+      }
+      // (round 3) the colours of an unshaded march are only needed from here on: ~9 of 10 rounds leave through the transparent-round exit
+      // above and never look them up (15 vector instructions and two 12-byte LDS reads per sample; C2 is bound by vector issue)
+      if (SHADE == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const f3 rgb = tf_color(tf, va[k]);
+          ca[k] = mk3(clamp01(rgb.x), clamp01(rgb.y), clamp01(rgb.z));
         }
       }
       // ---- (4) the ray's alpha recurrence over the 4K steps, in order; every lane of the quad computes all of it
