@@ -158,7 +158,9 @@ def load_traffic(key):
                 continue
             ent = doc.get("entries", {}).get(key)
             if ent:
-                return ent["traffic_bytes_per_launch"], ent.get("kernels", {}), f"profiles/{name} (rocprofv3 PMC of this configuration, kernels hash {doc['kernels_hash']})"
+                w = key.split("|")[4]
+                what = "this configuration" if w == "1" else f"rank 0's image shard of {w} ranks, profiled on one GPU without the gather: bench.py --shard-of {w}"
+                return ent["traffic_bytes_per_launch"], ent.get("kernels", {}), f"profiles/{name} (rocprofv3 PMC of {what}; kernels hash {doc['kernels_hash']})"
             src = src or f"null: profiles/{name} has no entry for {key}"
     return None, {}, src or "null: no committed PMC profile"
 
@@ -248,6 +250,8 @@ def main():
     ap.add_argument("--skip-empty", action="store_true", help="enable macrocell empty-space skipping (not the headline: fewer samples are fetched)")
     ap.add_argument("--rate", type=float, default=None, help="volume sampling rate override (the scene files say 4: serializer_vidi3d.cpp:402; renderbatch's default is 1)")
     ap.add_argument("--fovy", type=float, default=60.0, help="vertical field of view (renderbatch renders 60: renderer.h:149-152; the scene files say 45)")
+    ap.add_argument("--shard-of", type=int, default=0, help="ONE process renders rank --shard-rank's image shard of this many ranks, without a gather: a profilable stand-in for one rank of the N-GPU run (its counters are filed under world = N)")
+    ap.add_argument("--shard-rank", type=int, default=0)
     ap.add_argument("--sparse-sampling", action="store_true", help="the foveated mode with the interactive app's default focus (apps/main_app.cpp:123-124)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -334,6 +338,9 @@ def worker(args, world):
         ren.set_pixel_jitter(ovr.JITTER_BLUE_NOISE)
     if multi:
         ren.set_image_shard(rank, world, args.tile, args.tile)
+    elif args.shard_of > 1:
+        ren.set_image_shard(args.shard_rank, args.shard_of, args.tile, args.tile)
+    key_world = args.shard_of if (args.shard_of > 1 and not multi) else world   # the world the counters of profiles/*_traffic.json are filed under
     ren.set_layout_choice(args.layout)
     ren.set_shading_pipeline(args.pipeline)
     ren.set_lds_staging(args.lds_staging)
@@ -521,7 +528,7 @@ def worker(args, world):
             pl = {k: v / vsteps for k, v in leg["tot"].items()}
             ph = [p / vsteps for p in leg["phase_ms"]]
             vc = dict(cfg, cam=vcam, tf=vtf)
-            _, v_ctr, _ = load_traffic(traffic_key(args.config, vcam, vtf, cfg["shading"], world, cfg["rate"], args.fovy, args.sparse_sampling))
+            _, v_ctr, _ = load_traffic(traffic_key(args.config, vcam, vtf, cfg["shading"], key_world, cfg["rate"], args.fovy, args.sparse_sampling))
             kern, dom, abytes = kernel_report(vc, pl, ph, leg["kernel_ms"] / vsteps, leg["last"].pipeline == 2, v_ctr, leg["last"].pool_chunks)
             views[f"{vcam}/{vtf}"] = {
                 "ms_per_step": leg["dt"] / vsteps * 1e3, "fps": vsteps / leg["dt"], "gsamples_per_s": leg["tot"]["samples"] / leg["dt"] / 1e9,
@@ -561,7 +568,7 @@ def worker(args, world):
             leg = timed_leg(vsteps, 3)
             pl = {k: v / vsteps for k, v in leg["tot"].items()}
             ph = [p / vsteps for p in leg["phase_ms"]]
-            _, v_ctr, _ = load_traffic(traffic_key(args.config, cfg["cam"], cfg["tf"], vc["shading"], world, vc["rate"], vkw.get("fovy", 60.0), vkw.get("sparse", False)))
+            _, v_ctr, _ = load_traffic(traffic_key(args.config, cfg["cam"], cfg["tf"], vc["shading"], key_world, vc["rate"], vkw.get("fovy", 60.0), vkw.get("sparse", False)))
             kern, dom, abytes = kernel_report(vc, pl, ph, leg["kernel_ms"] / vsteps, leg["last"].pipeline == 2, v_ctr, leg["last"].pool_chunks)
             variants[vname] = {
                 "ms_per_step": leg["dt"] / vsteps * 1e3, "fps": vsteps / leg["dt"], "gsamples_per_s": leg["tot"]["samples"] / leg["dt"] / 1e9,
@@ -629,7 +636,7 @@ def worker(args, world):
         pixels_per_launch = per_launch["active_pixels"]
         nbytes = nominal_bytes(cfg, per_launch, pixels_per_launch)
         traffic, traffic_by_kernel, traffic_source = (None, {}, "null: the empty-space skipping leg is not profiled") if args.skip_empty else \
-            load_traffic(traffic_key(args.config, cfg["cam"], cfg["tf"], cfg["shading"], world, cfg["rate"], args.fovy, args.sparse_sampling))
+            load_traffic(traffic_key(args.config, cfg["cam"], cfg["tf"], cfg["shading"], key_world, cfg["rate"], args.fovy, args.sparse_sampling))
         pooled = last_stats.pipeline == 2
         ph = [p / steps for p in phase_ms]
         kern, dom, abytes = kernel_report(cfg, per_launch, ph, k_ms, pooled, traffic_by_kernel, last_stats.pool_chunks)
@@ -657,7 +664,7 @@ def worker(args, world):
                        "transfer_function": cfg["tf"], "camera": cfg["cam"], "fovy": args.fovy, "sparse_sampling": bool(args.sparse_sampling), "sampling_rate": cfg["rate"],
                        "spp": cfg["spp"], "pixel_jitter": "blue-noise tile (synthetic 64x64x64), slice = frame % 64" if noise is not None else "RandomTEA iff spp > 1 (reference)",
                        "shading": ["none", "gradient", "gradient+shadow"][cfg["shading"]],
-                       "frame_accumulation": True, "empty_space_skipping": bool(args.skip_empty), "tuning": ["rules", "probing", "measured choice"][last_stats.tuning], "volume_layout_read": ["general", "thin", "thin transposed", "quad"][last_stats.layout], "parallelism": f"image tiles {args.tile}x{args.tile} over {world} rank(s)"},
+                       "frame_accumulation": True, "empty_space_skipping": bool(args.skip_empty), "tuning": ["rules", "probing", "measured choice"][last_stats.tuning], "volume_layout_read": ["general", "thin", "thin transposed", "quad"][last_stats.layout], "parallelism": (f"image tiles {args.tile}x{args.tile} over {world} rank(s)" if key_world == world else f"stand-in: rank {args.shard_rank}'s shard of {key_world} ranks on one GPU, no gather")},
             "per_frame": {k: per_step[k] for k in sorted(per_step)},
             # the dominant kernel of the frame (longest mean launch); the whole pipeline and the other kernels beside it
             "roofline": {"bound": kern[dom]["bound"], "achieved": kern[dom]["achieved"], "peak": kern[dom]["peak"], "unit": kern[dom]["unit"],

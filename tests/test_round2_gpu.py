@@ -246,6 +246,25 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
 
 
+def test_one_rank_of_n_as_a_profilable_stand_in():
+    """`bench.py --shard-of N`: one process renders rank 0's image shard of N ranks without a gather - what tools/r03_prof_all.sh profiles so
+    that the N-GPU line of the driver's run can quote counters (filed under world = N in profiles/*_traffic.json)"""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    res = {}
+    for extra in ([], ["--shard-of", "2"], ["--shard-of", "2", "--shard-rank", "1"]):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                              "--no-views", "--no-skip-leg"] + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[tuple(extra)] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    whole, r0, r1 = res[()], res[("--shard-of", "2")], res[("--shard-of", "2", "--shard-rank", "1")]
+    assert "stand-in" in r0["config"]["parallelism"] and "stand-in" not in whole["config"]["parallelism"] and r0["n_gpus"] == 1
+    assert r0["per_frame"]["samples"] + r1["per_frame"]["samples"] == whole["per_frame"]["samples"]
+    assert r0["per_frame"]["rays"] + r1["per_frame"]["rays"] == whole["per_frame"]["rays"]
+    src = r0["roofline"]["traffic_source"]
+    assert "|2|2|" in src or "shard of 2" in src, src   # looked up under world = 2, never under the whole frame's key
+
+
 @pytest.mark.parametrize("config,n", [("c4", 96), ("c5", 64)])
 def test_two_ranks_on_one_card_at_the_8_gpu_configurations_shapes(config, n):
     """the N > 1 path of BASELINE's 8-GPU configurations (C4: u16, 1080p; C5: 4K, blue-noise jitter, accumulation) at a reduced volume

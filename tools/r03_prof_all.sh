@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # round-3 profile collection ON the GPU box (run last: the traffic file is keyed by the kernel sources' hash):
-#   bash tools/r03_prof_all.sh [part...]    parts: a (C3 matrix), b (C3 variants), c (C1 C2), d (C4 C5), json
+#   bash tools/r03_prof_all.sh [part...]    parts: a (C3 matrix), b (C3 variants), c (C1 C2), d (C4 C5), e (rank 0's shard of 2 / 4 / 8 ranks at C3), json
 set -uo pipefail
 cd $GRAFT_REPO_ROOT
 S="--steps 10 --warmup 3"
@@ -23,6 +23,9 @@ for part in $parts; do
   d)
     bash tools/prof.sh r03_c4 --config c4 --steps 6 --warmup 2
     bash tools/prof.sh r03_c5 --config c5 --steps 6 --warmup 2 ;;
+  e)
+    # what ONE rank of the driver's N-GPU run launches: rank 0's image shard, rendered by one process without the gather
+    for w in 2 4 8; do bash tools/prof.sh r03_c3_shard_of$w --config c3 --shard-of $w $S; done ;;
   json)
     python3 tools/traffic_json.py gpurun_out/r03_traffic.json \
       "c3|oblique|sparse|2|1|1.0|60.0|0=gpurun_out/prof_r03_c3" "c3|front|sparse|2|1|1.0|60.0|0=gpurun_out/prof_r03_c3_front" \
@@ -30,6 +33,8 @@ for part in $parts; do
       "c3|oblique|sparse|2|1|4.0|60.0|0=gpurun_out/prof_r03_c3_rate4" "c3|oblique|sparse|2|1|1.0|45.0|0=gpurun_out/prof_r03_c3_fovy45" \
       "c3|oblique|sparse|2|1|1.0|60.0|1=gpurun_out/prof_r03_c3_sparse" "c3|oblique|sparse|1|1|1.0|60.0|0=gpurun_out/prof_r03_c3_gradient" \
       "c1|oblique|sparse|2|1|1.0|60.0|0=gpurun_out/prof_r03_c1" "c2|oblique|sparse|0|1|1.0|60.0|0=gpurun_out/prof_r03_c2" \
-      "c4|oblique|sparse|2|1|1.0|60.0|0=gpurun_out/prof_r03_c4" "c5|oblique|sparse|2|1|1.0|60.0|0=gpurun_out/prof_r03_c5" ;;
+      "c4|oblique|sparse|2|1|1.0|60.0|0=gpurun_out/prof_r03_c4" "c5|oblique|sparse|2|1|1.0|60.0|0=gpurun_out/prof_r03_c5" \
+      "c3|oblique|sparse|2|2|1.0|60.0|0=gpurun_out/prof_r03_c3_shard_of2" "c3|oblique|sparse|2|4|1.0|60.0|0=gpurun_out/prof_r03_c3_shard_of4" \
+      "c3|oblique|sparse|2|8|1.0|60.0|0=gpurun_out/prof_r03_c3_shard_of8" ;;
   esac
 done
