@@ -250,6 +250,8 @@ def main():
     ap.add_argument("--skip-empty", action="store_true", help="enable macrocell empty-space skipping (not the headline: fewer samples are fetched)")
     ap.add_argument("--rate", type=float, default=None, help="volume sampling rate override (the scene files say 4: serializer_vidi3d.cpp:402; renderbatch's default is 1)")
     ap.add_argument("--fovy", type=float, default=60.0, help="vertical field of view (renderbatch renders 60: renderer.h:149-152; the scene files say 45)")
+    ap.add_argument("--gather-every", type=int, default=1, help="N > 1: gather the tiles to rank 0 on every K-th step only (and at the end of the timed region) - progressive "
+                    "accumulation that is displayed when it is mapped (SURVEY 8e on C5); the default gathers every frame, as an interactive display would")
     ap.add_argument("--shard-of", type=int, default=0, help="ONE process renders rank --shard-rank's image shard of this many ranks, without a gather: a profilable stand-in for one rank of the N-GPU run (its counters are filed under world = N)")
     ap.add_argument("--shard-rank", type=int, default=0)
     ap.add_argument("--sparse-sampling", action="store_true", help="the foveated mode with the interactive app's default focus (apps/main_app.cpp:123-124)")
@@ -381,9 +383,13 @@ def worker(args, world):
             # one frame = march/shade/composite of this rank's tiles, then the gather of all tiles to rank 0.  The gather of
             # frame i runs on its own stream while frame i+1 renders (tiles.TileGather); the host waits once per frame
             ren.render_async()
-            gatherer.run()
+            step.count += 1
+            if step.count % max(args.gather_every, 1) == 0:
+                gatherer.run()
+                step.gathered = step.count
             ren.sync()
             gatherer.check()
+    step.count = step.gathered = 0
 
     def timed_leg(steps, warmup):
         """warmup untimed steps, then exactly `steps` steps between barrier + device-synchronise pairs"""
@@ -413,6 +419,9 @@ def worker(args, world):
             leg["phase_ms"][2] += st.composite_ms
             leg["last"] = st
         if gatherer is not None:
+            if step.gathered != step.count:   # --gather-every: the last frame has not been gathered yet
+                gatherer.run()
+                step.gathered = step.count
             gatherer.flush()   # the last frame's tiles reach rank 0's frame inside the timed region
         torch.cuda.synchronize()
         if dist is not None:
@@ -691,6 +700,7 @@ def worker(args, world):
             out["rccl_ranks"] = dist.get_world_size()
             out["backend"] = dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")
             out["device_count"] = torch.cuda.device_count()
+            out["gather"] = "every frame" if args.gather_every <= 1 else f"every {args.gather_every}th frame and the last one of the timed region (--gather-every)"
             out["ranks"] = rank_report
         if views is not None:
             out["roofline"]["views"] = views

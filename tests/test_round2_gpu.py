@@ -278,6 +278,13 @@ def test_two_ranks_on_one_card_at_the_8_gpu_configurations_shapes(config, n):
     w, h = (1920, 1080) if config == "c4" else (3840, 2160)
     assert d["n_gpus"] == 2 and d["per_frame"]["rays"] == w * h and d["dtype"] == ("u16" if config == "c4" else "f32")
     assert len(d["ranks"]["per_rank"]["kernel_ms"]) == 2 and d["ranks"]["work_imbalance_max_over_mean"] < 1.5
+    if config == "c5":
+        # progressive accumulation gathered only when it is mapped (SURVEY 8e on C5): same frames, one gather at the end of the timed region
+        out2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", config, "--n", str(n), "--steps", "3", "--warmup", "1",
+                               "--gather-every", "64"], env=env, capture_output=True, text=True, timeout=900)
+        assert out2.returncode == 0, out2.stderr[-2000:]
+        d2 = json.loads([l for l in out2.stdout.splitlines() if l.startswith("{")][-1])
+        assert d2["gather"].startswith("every 64th") and d["gather"] == "every frame" and d2["per_frame"] == d["per_frame"]
 
 
 # ---- view-dependent volume replicas (thin layouts) ----------------------------------------------------------------------------
