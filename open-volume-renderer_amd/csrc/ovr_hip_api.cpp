@@ -210,6 +210,8 @@ struct ovr_hip_renderer {
   unsigned long long* d_trace = nullptr;    // OVR_HIP_TRACE=1 diagnostic buffer
   size_t trace_words = 0;
   unsigned long long* h_counters = nullptr; // pinned
+  bool outside_hits = false;   // a frame of the running accumulation had a ray that hit the box from outside its silhouette (see finish_frame)
+  int frame_set = 0;           // the framebuffer set the frame in flight renders into
 
   // launch order of the march's 8x8-pixel workgroups (dense mode): owned blocks, longest rays first
   unsigned int* d_sched_src = nullptr; // owned blocks in image order (host-built: framebuffer size and shard)
@@ -293,7 +295,7 @@ int resize_framebuffers(ovr_hip_renderer* r, int w, int h)
   HIP_TRY(hipMemset(r->d_accum, 0, n * 4 * sizeof(float)));
   // workgroups of the march: 8x8 pixels (4 waves x 16 rays) in dense mode, 64 list entries in sparse mode
   const size_t nblk = std::max<size_t>((size_t)((w + 7) / 8) * (size_t)((h + 7) / 8), (n + 63) / 64) + 1;
-  HIP_TRY(hipMalloc((void**)&r->d_block_counters, nblk * 7 * sizeof(unsigned int)));
+  HIP_TRY(hipMalloc((void**)&r->d_block_counters, nblk * kBlockCounters * sizeof(unsigned int)));
   HIP_TRY(hipMalloc((void**)&r->pool.tile_first, nblk * 4 * sizeof(int)));
   HIP_TRY(hipMalloc((void**)&r->pool.tile_count, nblk * 4 * sizeof(unsigned int)));
   HIP_TRY(hipMalloc((void**)&r->pool.pix_state, std::max<size_t>(n, 1) * sizeof(float4)));
@@ -639,6 +641,7 @@ int enqueue_frame(ovr_hip_renderer* r)
 
   P.rgba = r->d_rgba[r->cur];
   nonzero_rect(r, r->d_rect[r->cur]); // what mapframe(HOST) will have to copy of this set (the committed camera is the one this frame renders)
+  r->frame_set = r->cur;
   P.grad = r->d_grad[r->cur];
   P.accum = r->d_accum;
   P.width = W;
@@ -849,6 +852,13 @@ int finish_frame(ovr_hip_renderer* r)
   r->stats.active_pixels = r->h_counters[4];
   r->stats.skipped_samples = r->h_counters[5];
   r->stats.skipped_shadow_samples = r->h_counters[6];
+  // The reference's box test switches a slab off for a ray whose direction component on that axis is below FLT_MIN (shaders_common.h:162-172,
+  // restated): such a ray hits the box wherever its origin lies along that axis - from OUTSIDE the box's silhouette if the origin is
+  // outside the slab (an axis-aligned camera's centre row / column; any camera now and then, by one pixel on the line where a component
+  // changes sign).  The march counts those hits; a frame that has one - or accumulates onto one - is mapped whole, not by its rectangle.
+  if (r->accumulate.current == 0 || r->frame_index <= 1) r->outside_hits = false;
+  if (r->h_counters[7] > 0) r->outside_hits = true;
+  if (r->outside_hits) { int* q = r->d_rect[r->frame_set]; q[0] = 0; q[1] = 0; q[2] = r->fbsize.current.w; q[3] = r->fbsize.current.h; }
   r->stats.lds_fallback_taps = r->stats.lds_unstaged_rounds = r->stats.lds_rounds = 0;
   if (r->P.lds_staging && !r->P.majorant && r->P.shading == 0 && !r->P.sparse_xy && r->P.vol.type == VOX_F32) {
     // the unshaded f32 march ran its LDS-staged variant: the two skip counters carried its diagnostics

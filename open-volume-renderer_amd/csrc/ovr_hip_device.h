@@ -527,6 +527,14 @@ __device__ __forceinline__ bool intersect_unit_box(float& t0, float& t1, f3 o, f
   t1 = fminf(t1, fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fmaxf(lz, hz)));
   return t1 > t0;
 }
+// The reference's quirk, restated above: a direction component below FLT_MIN switches its slab OFF - such a ray "hits" the box wherever
+// its origin lies along that axis.  True for a ray that takes this path with its origin outside the ignored slab: the only rays that can
+// hit the box from outside its silhouette (the host needs to know: mapframe(HOST) copies the silhouette's rectangle, ovr_hip_api.cpp)
+__device__ __forceinline__ bool ignored_slab_outside(f3 o, f3 d)
+{
+  return (fabsf(d.x) < FLT_MIN && !(o.x >= 0.f && o.x <= 1.f)) || (fabsf(d.y) < FLT_MIN && !(o.y >= 0.f && o.y <= 1.f)) ||
+         (fabsf(d.z) < FLT_MIN && !(o.z >= 0.f && o.z <= 1.f));
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // TEA, random.h:146-188
@@ -1029,11 +1037,11 @@ __device__ __forceinline__ void apply_batch(const ShadeReq& res, unsigned int ba
   }
 }
 
-constexpr int kNC = 7; // counters: rays, samples, shaded, shadow, active pixels, skipped samples, skipped shadow samples
+constexpr int kNC = kBlockCounters; // counters: rays, samples, shaded, shadow, active pixels, skipped samples, skipped shadow samples, hits through an ignored slab (ignored_slab_outside)
 // per-wave counters -> LDS -> one plain store of the workgroup's partial sums (lds must hold kWaves*kNC uints)
 __device__ __forceinline__ void store_block_counters(const RayMarchParams& P, unsigned int* red, int lane, int wave, unsigned int n_rays,
                                                      unsigned int n_samples, unsigned int n_shaded, unsigned int n_shadow, unsigned int n_active,
-                                                     unsigned int n_skipped, unsigned int n_shadow_skipped)
+                                                     unsigned int n_skipped, unsigned int n_shadow_skipped, unsigned int n_outside_hits)
 {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -1044,12 +1052,14 @@ __device__ __forceinline__ void store_block_counters(const RayMarchParams& P, un
     n_active += __shfl_down(n_active, off);
     n_skipped += __shfl_down(n_skipped, off);
     n_shadow_skipped += __shfl_down(n_shadow_skipped, off);
+    n_outside_hits += __shfl_down(n_outside_hits, off);
   }
   if (!P.block_counters) return;
   __syncthreads(); // LDS is dead at this point: reuse its front
   if (lane == 0) {
     red[wave * kNC + 0] = n_rays; red[wave * kNC + 1] = n_samples; red[wave * kNC + 2] = n_shaded;
     red[wave * kNC + 3] = n_shadow; red[wave * kNC + 4] = n_active; red[wave * kNC + 5] = n_skipped; red[wave * kNC + 6] = n_shadow_skipped;
+    red[wave * kNC + 7] = n_outside_hits;
   }
   __syncthreads();
   if (threadIdx.x < kNC) {
@@ -1240,7 +1250,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
 
   int ix, iy;
   const bool active = assign_pixel_quad(P, lane, wave, ix, iy);
-  unsigned int n_rays = 0, n_samples = 0, n_shaded = 0, n_shadow = 0, n_skipped = 0, n_shadow_skipped = 0;
+  unsigned int n_rays = 0, n_samples = 0, n_shaded = 0, n_shadow = 0, n_skipped = 0, n_shadow_skipped = 0, n_outside_hits = 0;
   VolConsts vc;
   MarchConsts mc;
   setup_consts(P, vc, mc);
@@ -1410,6 +1420,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
     gradient = mk3(0, 0, 0);
     bool live = active && intersect_unit_box(t0, t1, oo, od);
     if (active && owner) ++n_rays;
+    if (live && owner && ignored_slab_outside(oo, od)) ++n_outside_hits;
     SkipSpan span = skipspan_all(); // samples outside the hull, or in an unmarked segment of it, are in empty macrocells
     if (SKIP) {
       if (P.spp == 1) span = pro_span; // same ray, same [t0, t1] as in the prologue
@@ -1776,7 +1787,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
   // LDSB (never combined with skipping): the two skip counters carry the staging diagnostics instead
   store_block_counters(P, reinterpret_cast<unsigned int*>(lds_raw), lane, wave, n_rays, n_samples, n_shaded, n_shadow,
                        (active && owner && (!POOLED || P.spp_index == 0)) ? 1u : 0u, LDSB ? n_lds_fb_taps : n_skipped,
-                       LDSB ? n_lds_fb_rounds : n_shadow_skipped);
+                       LDSB ? n_lds_fb_rounds : n_shadow_skipped, n_outside_hits);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1927,7 +1938,7 @@ inline hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
   hipError_t e;
   const bool pooled = (SHADE != 0) && p.pool.reqs != nullptr;
   if (!pooled) {
-    const size_t lds = std::max<size_t>(tf_lds + table_lds_bytes(p, AM) + (size_t)kWaves * QCfg<SHADE, false>::QCAP * sizeof(ShadeReq), 64); // >= 64 B: the counter reduction reuses it
+    const size_t lds = std::max<size_t>(tf_lds + table_lds_bytes(p, AM) + (size_t)kWaves * QCfg<SHADE, false>::QCAP * sizeof(ShadeReq), (size_t)kWaves * kNC * sizeof(unsigned int)); // the counter reduction reuses it
     bool launched = false;
     if constexpr (VT == VOX_F32 && SHADE == 0 && AM <= 1 && !SKIP) {
       if (p.lds_staging && !p.sparse_xy) { // LDS-staged bricks (see raymarch_kernel): the bricks follow the tables and the TF

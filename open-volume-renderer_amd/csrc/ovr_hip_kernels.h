@@ -14,6 +14,7 @@ enum VoxelType : int { VOX_U8 = 0, VOX_I8 = 1, VOX_U16 = 2, VOX_I16 = 3, VOX_F32
                        VOX_U16_Q = 10, VOX_U8_Q = 11 };
 enum VolumeLayout : int { LAYOUT_GENERAL = 0, LAYOUT_THIN = 1, LAYOUT_THIN_T = 2, LAYOUT_QUAD = 3 };
 constexpr int kLayouts = 4;
+constexpr int kBlockCounters = 8; // per-workgroup partial counters of the march (rays, samples, shaded, shadow, active pixels, skipped, skipped shadow, hits through an ignored slab)
 
 // Volume layout in HBM ("x-apron bricks in macro blocks"):
 //   voxels are grouped into 128-byte bricks = one L1/L2 line.  A brick covers CX x 4 x (2|4) cells and stores CX+1 voxels
@@ -142,7 +143,7 @@ struct RayMarchParams {
   const unsigned char* occupancy; // per 4^3 macrocells: majorant > 0 in one of them or next to them (set with majorant)
   const unsigned char* occupancy_fine; // the same per macrocell (primary rays refine their skip interval with it)
   unsigned long long* trace;    // diagnostic (OVR_HIP_TRACE=1): 4 words per wave, null otherwise
-  unsigned int* block_counters; // workspace: raymarch_grid_blocks() * 7 per-workgroup partial sums
+  unsigned int* block_counters; // workspace: raymarch_grid_blocks() * kBlockCounters per-workgroup partial sums
   PoolDesc pool;
   VolumeDesc vol;
 };
@@ -155,7 +156,7 @@ size_t pool_shade_blocks();
 size_t raymarch_lds_bytes(int n_color, int n_alpha);
 // addressing mode the march / shade kernels take for a layout (0 / 1: 32-bit offsets, 2: 64-bit z table, 3: computed, no LDS tables)
 int volume_addressing_mode(const VolumeDesc& vd, int n_color, int n_alpha);
-// number of workgroups launch_raymarch will use (size of the block_counters workspace / 7)
+// number of workgroups launch_raymarch will use (size of the block_counters workspace / kBlockCounters)
 size_t raymarch_grid_blocks(const RayMarchParams& p);
 // sorts the n owned blocks of src (bx | by << 16, any order) by descending ray length into dst; uses p's camera and box
 // (workspace: schedule_workspace_elems(n) words)

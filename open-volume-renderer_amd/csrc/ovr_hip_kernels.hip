@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned int
     if (threadIdx.x == 0) atomicMax(&pool_ctrl[32 * (kPoolSubs + 1)], v);
   }
   __shared__ unsigned long long red[4][kNC];
-  unsigned long long acc[kNC] = { 0, 0, 0, 0, 0, 0, 0 };
+  unsigned long long acc[kNC] = {};
   const int stride = gridDim.x * 256;
   for (int b = blockIdx.x * 256 + threadIdx.x; b < n_blocks; b += stride) {
 #pragma unroll

@@ -33,7 +33,32 @@ def _cases(n_cases=72, seed=20261003):
     return out
 
 
-@pytest.mark.parametrize("c", _cases())
+def _cases_round3(n_cases=None, seed=20261004):
+    """round 3: the quad replica (layout 3, every voxel type), the scene files' sampling rate 4 (shadow stride 0.625 voxel) and runs of frames long
+    enough for the renderer to time its alternatives (ovr_hip_stats.tuning) under accumulation; OVR_SWEEP_CASES / OVR_SWEEP_SEED widen or move the sweep for a one-off hunt"""
+    import os
+    n_cases = n_cases or int(os.environ.get("OVR_SWEEP_CASES", "40"))
+    seed = int(os.environ.get("OVR_SWEEP_SEED", seed))
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n_cases):
+        rate = float(rng.choice([1.0, 2.0, 4.0]))
+        small = rate == 4.0
+        dims = tuple(int(rng.integers(9, 28 if small else 44)) for _ in range(3))
+        c = dict(
+            dtype=DTYPES[int(rng.integers(len(DTYPES)))], dims=dims, shading=int(rng.choice([0, 1, 2, 2])), spp=int(rng.choice([1, 1, 1, 2])),
+            frames=int(rng.choice([1, 3, 6, 11])), pipeline=int(rng.choice([0, 0, 1, 2])), skip=bool(rng.integers(3) == 0), sparse=bool(rng.integers(5) == 0),
+            shard=None if rng.integers(4) else (int(rng.integers(0, 2)), 2, 16, 16),
+            cam=str(rng.choice(["front", "oblique", "inside"])), rate=rate, tf=str(rng.choice(["sparse", "dense", "dense", "bumps"])),
+            size=(int(rng.integers(17, 50 if small else 90)), int(rng.integers(9, 40 if small else 70))),
+            spacing=tuple(float(rng.choice([1.0, 0.5, 2.0])) for _ in range(3)), convention=int(rng.integers(2)),
+            layout=int(rng.choice([-1, -1, 0, 3, 3, 1])), jitter=bool(rng.integers(6) == 0), default_range=False,
+        )
+        out.append(pytest.param(c, id=f"r3-{i:02d}-" + "-".join(str(c[k].__name__ if k == "dtype" else c[k]) for k in ("dtype", "shading", "rate", "frames", "pipeline", "skip", "sparse", "cam", "layout"))))
+    return out
+
+
+@pytest.mark.parametrize("c", _cases() + _cases_round3())
 def test_config(ovr, oracle, hip_renderer_factory, c):
     case = make_case(ovr, oracle, n=max(c["dims"]), dtype=c["dtype"], tf=c["tf"], cam=c["cam"], size=c["size"], shading=c["shading"], rate=c["rate"],
                      spp=c["spp"], convention=c["convention"], dims=c["dims"], spacing=c["spacing"], tf_n=128)
@@ -81,4 +106,5 @@ def test_config(ovr, oracle, hip_renderer_factory, c):
     compare(oracle, got, ref, name=str(c))
     assert st.samples + st.skipped_samples == cnt.samples, c
     assert st.frame_index == c["frames"]
+    assert st.tuning in (0, 1, 2)
     ren.close()

@@ -215,3 +215,37 @@ def test_mapframe_copies_only_the_box_rectangle(ovr, oracle, hip_renderer_factor
     ren.set_camera(ovr.Camera(eye, at, up, 60.0)); ren.commit(); ren.render()
     check("sparse")
     ren.close()
+
+
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_hits_through_an_ignored_slab_reach_the_host_mirror(ovr, oracle, hip_renderer_factory, accumulate):
+    """The reference's box test switches a slab off for a ray whose direction component on that axis is below FLT_MIN (shaders_common.h:162-172):
+    an axis-aligned camera's centre row hits the box although its rays pass ABOVE it - outside the rectangle the box projects into.
+    mapframe(HOST) copies that rectangle only while the march reports no such hit (found by the widened round-3 sweep: seed 11, case 33)."""
+    case = make_case(ovr, oracle, n=25, dtype=np.int8, tf="dense", cam="front", size=(59, 17), shading=2, rate=1.0, convention=1, dims=(25, 9, 17),
+                     spacing=(1.0, 2.0, 0.5), tf_n=128)
+    frames = 3 if accumulate else 1
+    ref, _, cnt = oracle_scene(oracle, case).render(frames=frames, accumulate=True)
+    ren = hip_setup(ovr, hip_renderer_factory(), case, accumulate=accumulate)
+
+    def frames_of(tag):
+        fb_h, fb_d = ovr.FrameBufferData(), ovr.FrameBufferData()
+        ren.mapframe(fb_h)
+        ren.mapframe(fb_d, device=True)
+        h = np.array(fb_h.rgba.data(), copy=True)
+        d = fb_d.rgba.data().cpu().numpy().reshape(h.shape)
+        assert np.array_equal(h.view(np.uint32), d.view(np.uint32)), tag
+        return h
+
+    for _ in range(frames):
+        ren.render()
+    got = frames_of("axis-aligned")
+    compare(oracle, got, ref, name="ignored slab")
+    row = got[8, :, 3]                                   # the centre row: sy = 8.5 / 17 = 0.5 exactly, ray direction y == 0
+    assert (row > 0).sum() >= 8 and (got[6, :, 3] == 0).all() and (got[10, :, 3] == 0).all()   # ... lit although the rows around it miss the box
+    # a camera without such rays: the stale row leaves the mirror again
+    eye, at, up = case["cam"]
+    ren.set_camera(ovr.Camera(tuple(np.array(eye) + np.array((3.1, -14.3, 2.2))), at, up, 60.0)); ren.commit(); ren.render()
+    moved = frames_of("moved")
+    assert (ren.stats().frame_index == 1 or not accumulate) and (moved[..., 3] > 0).any()
+    ren.close()
