@@ -13,6 +13,9 @@ DTYPES = [np.float32, np.uint8, np.uint16, np.int16, np.int8]
 
 
 def _cases(n_cases=72, seed=20261003):
+    import os
+    if os.environ.get("OVR_SWEEP_SEED_OLD"):   # a one-off hunt with another seed / more cases of the round-1/2 generator
+        seed, n_cases = int(os.environ["OVR_SWEEP_SEED_OLD"]), int(os.environ.get("OVR_SWEEP_CASES_OLD", n_cases))
     rng = np.random.default_rng(seed)
     rng2 = np.random.default_rng(seed + 2)   # round-2 dimensions, drawn from a second stream so that round 1's 72 cases stay as they were
     out = []

@@ -12,6 +12,7 @@ python bench.py --rate 4 --steps 5 --warmup 2 --no-cpu-baseline --no-views --no-
 python bench.py --tf dense --camera front --rate 4 --steps 5 --warmup 2 --no-cpu-baseline --no-views --no-skip-leg > $o/bench_c3_front_dense_rate4.json 2>/dev/null
 OVR_BENCH_FORCE_GATHER=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --no-cpu-baseline > $o/bench_c3_forced_gather_rccl.json 2> $o/fg.err
 OVR_BENCH_BACKEND=gloo OVR_BENCH_ONE_GPU=1 python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline > $o/bench_c3_2ranks_one_card_gloo.json 2> $o/2r.err
+for w in 2 4 8; do python bench.py --shard-of $w --no-cpu-baseline --no-views --no-skip-leg > $o/bench_c3_shard_of$w.json 2>/dev/null; done
 for f in $o/*.json; do python3 - $f <<'PY'
 import json,sys
 try:
