@@ -1,0 +1,152 @@
+"""Randomised walk through the renderer's state machine - the setters an interactive app calls between frames, in any order, on ONE renderer - with
+every mapped frame compared against the oracle rendering the current configuration from scratch for as many frames as the device says it has
+accumulated (ovr_hip_stats.frame_index).  Hunts what the scripted test_state_changes_on_one_renderer cannot: stale caches (schedule, replicas,
+macrocells, request pool, measured layout / pipeline decisions, the mapped rectangle), missed or spurious accumulation resets.
+usage: python tests/fuzz_states.py [episodes] [seed] [ops per episode]"""
+import sys
+sys.path[:0] = ['/root/repo', '/root/repo/tests', '/root/repo/oracle']
+import numpy as np
+import ovr_amd as ovr
+import oracle as O
+from helpers import make_case, oracle_scene, hip_setup, hip_frame, compare
+
+episodes = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+n_ops = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+DTYPES = [np.float32, np.uint8, np.uint16, np.int16, np.int8]
+failures = 0
+
+
+def episode(ep):
+    rng = np.random.default_rng(seed * 100003 + ep)
+    dims = tuple(int(rng.integers(9, 40)) for _ in range(3))
+    spacing = tuple(float(rng.choice([1.0, 0.5, 2.0])) for _ in range(3))
+    st8 = dict(dtype=DTYPES[int(rng.integers(len(DTYPES)))], dims=dims, spacing=spacing, tf=str(rng.choice(["sparse", "dense", "bumps"])), cam=str(rng.choice(["front", "oblique", "inside"])),
+               size=(int(rng.integers(17, 80)), int(rng.integers(9, 60))), shading=int(rng.integers(0, 3)), rate=1.0, convention=int(rng.integers(2)), tf_n=int(rng.choice([64, 128])))
+    case = make_case(ovr, O, n=max(dims), dtype=st8["dtype"], tf=st8["tf"], cam=st8["cam"], size=st8["size"], shading=st8["shading"], rate=st8["rate"],
+                     convention=st8["convention"], dims=dims, spacing=spacing, tf_n=st8["tf_n"])
+    noise = np.random.default_rng(5).random((16, 16, 64), dtype=np.float32)
+    ren = ovr.create_renderer("hip")
+    ren.set_volume_layouts(2)
+    hip_setup(ovr, ren, case, accumulate=True, pipeline=0)
+    ren.set_noise_tile(noise)
+    sparse, focus, shard, skip, jitter, accumulate = False, ((0.5, 0.45), 0.35, 0.15), None, False, False, True
+    log = [f"init {st8}"]
+
+    def check(tag):
+        kw = {}
+        if sparse:
+            kw.update(sparse=True, focus=focus, noise=noise)
+        if shard:
+            kw.update(shard=shard)
+        if jitter:
+            kw.update(jitter=1, noise=noise)
+        got = hip_frame(ovr, ren)[0]
+        st = ren.stats()
+        ref, _, cnt = oracle_scene(O, case, **kw).render(frames=int(st.frame_index), accumulate=accumulate)
+        if rng.integers(4) == 0:   # the 8-bit frame the device converts (image_to_rgba8), flipped like the PNG writer wants it
+            raw = hip_frame(ovr, ren)[0]
+            want = O.rgba8(raw, flip=True)
+            assert np.array_equal(np.array(ren.mapframe_rgba8(flip_vertical=True), copy=True).reshape(want.shape), want), tag + " rgba8"
+        if shard:
+            rank, world, tw, th = shard
+            mask = np.zeros(got.shape[:2], bool)
+            for tx, ty in ovr.tiles.owned_tiles(case["size"][0], case["size"][1], tw, th, rank, world):
+                mask[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw] = True
+            got = np.where(mask[..., None], got, 0.0).astype(np.float32)
+            ref = np.where(mask[..., None], ref, 0.0).astype(np.float32)
+        compare(O, got, ref, name=tag)
+        assert st.samples + st.skipped_samples == cnt.samples, (tag, st.samples, st.skipped_samples, cnt.samples)
+
+    try:
+        ren.render()
+        check("initial")
+        for k in range(n_ops):
+            op = int(rng.integers(0, 17))
+            if op == 0:
+                kind = str(rng.choice(["front", "oblique", "inside", "random"]))
+                if kind == "random":
+                    c = np.array(dims) * np.array(spacing) / 2.0
+                    d = rng.normal(size=3); d /= np.linalg.norm(d)
+                    if rng.integers(3) == 0:
+                        d = np.eye(3)[int(rng.integers(3))] * (1 if rng.integers(2) else -1)   # exactly along an axis
+                    eye = tuple(c + d * float(rng.uniform(0.3, 2.5)) * np.linalg.norm(c) * 2 + rng.normal(size=3) * float(rng.choice([0.0, 3.0])))
+                    up = (0.0, 1.0, 0.0) if abs(d[1]) < 0.9 else (0.0, 0.0, 1.0)
+                    case["cam"] = (eye, tuple(c), up)
+                else:
+                    case["cam"] = make_case(ovr, O, n=max(dims), dtype=st8["dtype"], cam=kind, dims=dims, spacing=spacing, convention=case["convention"], tf_n=64)["cam"]
+                ren.set_camera(ovr.Camera(*case["cam"], case["fovy"])); log.append(f"camera {kind} {case['cam']}")
+            elif op == 1:
+                case["size"] = (int(rng.integers(9, 90)), int(rng.integers(5, 70))); ren.set_fbsize(case["size"]); log.append(f"fbsize {case['size']}")
+            elif op == 2:
+                tf, n = str(rng.choice(["sparse", "dense", "bumps"])), int(rng.choice([16, 64, 128, 1024]))
+                case["colors"], case["alphas"], case["vr"] = ovr.synth.make_tfn(tf, n, st8["dtype"])
+                ren.set_transfer_function(case["colors"], case["alphas"], case["vr"]); log.append(f"tf {tf} {n}")
+            elif op == 3:
+                case["shading"] = int(rng.integers(0, 3)); ren.set_shading(case["shading"]); log.append(f"shading {case['shading']}")
+            elif op == 4:
+                p = int(rng.integers(0, 3)); ren.set_shading_pipeline(p); log.append(f"pipeline {p}")
+            elif op == 5:
+                l = int(rng.integers(-1, 4)); ren.set_layout_choice(l); log.append(f"layout {l}")
+            elif op == 6:
+                case["rate"] = float(rng.choice([0.5, 1.0, 2.0, 4.0])); ren.set_volume_sampling_rate(case["rate"]); log.append(f"rate {case['rate']}")
+            elif op == 7:
+                skip = bool(rng.integers(2)); ren.set_empty_space_skipping(skip); log.append(f"skip {skip}")
+            elif op == 8:
+                sparse = bool(rng.integers(2))
+                if sparse:
+                    focus = ((float(rng.uniform(0.2, 0.8)), float(rng.uniform(0.2, 0.8))), float(rng.uniform(0.1, 0.5)), float(rng.uniform(0.02, 0.3)))
+                    ren.set_focus(*focus)
+                ren.set_sparse_sampling(sparse); log.append(f"sparse {sparse} {focus}")
+            elif op == 9:
+                shard = None if rng.integers(2) else (int(rng.integers(0, 2)), 2, int(rng.choice([8, 16])), int(rng.choice([8, 16])))
+                ren.set_image_shard(*(shard or (0, 1, 16, 16))); log.append(f"shard {shard}")
+                # the pixels of tiles this rank does not own keep what they had: only owned tiles are compared (check)
+            elif op == 10:
+                # (not under sparse sampling: a sparse frame writes only its sampled pixels, so after a swap the other set shows the pixels of the
+                # frames rendered into IT - the reference's two sets behave the same way, device_impl.cpp:226-239 - while the oracle models one set)
+                if not sparse:
+                    ren.swap(); log.append("swap")
+                else:
+                    log.append("render only (no swap under sparse sampling)")
+            elif op == 11:
+                log.append("commit only")
+            elif op == 13:
+                case["spp"] = int(rng.choice([1, 1, 2, 3])); ren.set_sample_per_pixel(case["spp"]); log.append(f"spp {case['spp']}")
+            elif op == 14:
+                jitter = bool(rng.integers(2)); ren.set_pixel_jitter(1 if jitter else 0); log.append(f"blue-noise jitter {jitter}")
+            elif op == 15:
+                accumulate = bool(rng.integers(3) != 0); ren.set_frame_accumulation(accumulate); log.append(f"accumulate {accumulate}")
+            elif op == 16:   # a new volume of another shape and type on the same renderer (the app's "open file")
+                dims2 = tuple(int(rng.integers(9, 40)) for _ in range(3))
+                dt2 = DTYPES[int(rng.integers(len(DTYPES)))]
+                new = make_case(ovr, O, n=max(dims2), dtype=dt2, tf=str(rng.choice(["sparse", "dense", "bumps"])), cam="oblique", size=case["size"], shading=case["shading"], rate=case["rate"],
+                                spp=case["spp"], convention=case["convention"], dims=dims2, spacing=case["spacing"], tf_n=64)
+                case.update(new); st8["dtype"] = dt2; dims = dims2
+                ren.set_transfer_function(case["colors"], case["alphas"], case["vr"])
+                ren.init(ovr.Scene(volume=case["vol"], grid_origin=case["origin"], grid_spacing=case["spacing"], transfer_function=None, volume_sampling_rate=case["rate"]),
+                         ovr.Camera(*case["cam"], case["fovy"]))
+                ren.set_sparse_sampling(sparse)
+                log.append(f"new volume {dims2} {dt2.__name__}")
+            else:
+                log.append("render only")
+            ren.commit()
+            frames = int(rng.choice([1, 1, 2, 3, 5]))
+            for _ in range(frames):
+                ren.render()
+            log.append(f"  rendered {frames}: frame_index {ren.stats().frame_index} layout {ren.stats().layout} pipeline {ren.stats().pipeline} tuning {ren.stats().tuning}")
+            check(f"episode {ep} op {k}")
+    except AssertionError as e:
+        print(f"FAILED episode {ep} (seed {seed}): {str(e)[:600]}")
+        for line in log:
+            print("   ", line)
+        return 1
+    finally:
+        ren.close()
+    return 0
+
+
+for ep in range(episodes):
+    failures += episode(ep)
+print(f"{episodes} episodes, {failures} failed", flush=True)
+sys.exit(1 if failures else 0)

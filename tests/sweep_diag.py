@@ -1,5 +1,5 @@
 """Diagnoses cases of tests/test_config_sweep_gpu.py's round-3 sweep that miss the parity bar: where is the worst pixel, what are its alpha and its
-premultiplied colour on both sides?   usage: OVR_SWEEP_SEED=.. OVR_SWEEP_CASES=.. python tools/sweep_diag.py <case index> ..."""
+premultiplied colour on both sides?   usage: OVR_SWEEP_SEED=.. OVR_SWEEP_CASES=.. python tests/sweep_diag.py <case index> ..."""
 import os, sys
 sys.path[:0] = ['/root/repo', '/root/repo/tests', '/root/repo/oracle']
 import numpy as np
