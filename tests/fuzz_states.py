@@ -15,6 +15,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 n_ops = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 DTYPES = [np.float32, np.uint8, np.uint16, np.int16, np.int8]
 failures = 0
+LONG = __import__('os').environ.get('OVR_FUZZ_LONG') == '1'
 
 
 def episode(ep):
@@ -131,7 +132,7 @@ def episode(ep):
             else:
                 log.append("render only")
             ren.commit()
-            frames = int(rng.choice([1, 1, 2, 3, 5]))
+            frames = int(rng.choice([1, 1, 2, 3, 5] if not LONG else [1, 3, 14, 36]))   # LONG: past the 12-frame re-measurement and the 32-frame skipping probe
             for _ in range(frames):
                 ren.render()
             log.append(f"  rendered {frames}: frame_index {ren.stats().frame_index} layout {ren.stats().layout} pipeline {ren.stats().pipeline} tuning {ren.stats().tuning}")
