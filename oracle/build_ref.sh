@@ -41,6 +41,7 @@ hostobjs=$(echo "$objs" | tr ' ' '\n' | grep -v main_batch | tr '\n' ' ')
 $CXX -shared -o "$OUT/libovr_refhost.so" $hostobjs -ldl -lpthread
 $CXX -o "$OUT/renderbatch" $objs -rdynamic -ldl -lpthread
 $CXX $FLAGS "$HERE/ref_probe.cpp" -o "$OUT/ref_probe" -L"$OUT" -lovr_refhost -Wl,-rpath,'$ORIGIN' -ldl -lpthread
+$CXX $FLAGS "$HERE/ref_probe_wide.cpp" -o "$OUT/ref_probe_wide" -L"$OUT" -lovr_refhost -Wl,-rpath,'$ORIGIN' -ldl -lpthread
 $CXX $FLAGS "$HERE/ref_scene_probe.cpp" -o "$OUT/ref_scene_probe" -L"$OUT" -lovr_refhost -Wl,-rpath,'$ORIGIN' -ldl -lpthread
 $CXX $FLAGS "$HERE/plugin_probe.cpp" -o "$OUT/plugin_probe" -L"$OUT" -lovr_refhost -Wl,-rpath,'$ORIGIN' -rdynamic -ldl -lpthread
 echo "[build_ref] built $OUT/renderbatch, $OUT/libovr_refhost.so, $OUT/ref_probe, $OUT/ref_scene_probe and $OUT/plugin_probe"

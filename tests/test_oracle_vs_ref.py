@@ -96,3 +96,56 @@ def test_own_exr_writer_is_read_by_the_reference_loader(ovr, oracle, tmp_path):
     assert ref.LoadEXR(C.byref(data), C.byref(ww), C.byref(hh), path.encode(), C.byref(err)) == 0
     got = np.ctypeslib.as_array(data, shape=(h, w, 4)).view(np.uint32)[::-1]
     assert np.array_equal(got[..., [1, 2, 3, 0]], out)
+
+
+# ---- the same pins on WIDE seeded inputs (tests/golden/ref_probe_wide.npz, generated by tests/golden/make_ref_probe_wide.py through
+# ---- oracle/_ref/ref_probe_wide: the reference's own compiled functions) ------------------------------------------------------------
+WIDE = np.load(os.path.join(HERE, "golden", "ref_probe_wide.npz"))
+_f = lambda k: WIDE[k].view(np.float32)
+
+
+def test_rgba8_matches_reference_bit_exact_wide(oracle):
+    """every float within 6 ulp of k / 255 for all 256 k (where the truncating quantiser changes its answer), zeros, denormals, huge values,
+    infinities and 4096 random floats in [-0.5, 1.5]"""
+    img = _f("rgba8_in").reshape(1, -1, 4)
+    ref = WIDE["rgba8_out"].reshape(1, -1, 4)
+    assert np.array_equal(oracle.rgba8(img, flip=False), ref)
+    assert len(np.unique(ref)) == 256
+
+
+def test_camera_basis_matches_gdt_wide(oracle):
+    """400 random cameras at four scales (positions of order 0.01 ... 1000), random and axis-aligned up vectors, fovy 5 ... 120, any frame size"""
+    cin, cout = _f("camera_in").reshape(-1, 12).astype(np.float64), _f("camera_out").reshape(-1, 12)
+    worst = 0.0
+    for a, ref in zip(cin, cout):
+        got = np.asarray(oracle.camera_basis(a[0:3], a[3:6], a[6:9], a[9], int(a[10]), int(a[11])), dtype=np.float32)
+        # relative to the length of each basis vector (components near 0 carry the vector's absolute rounding error)
+        for k in range(0, 12, 3):
+            scale = max(float(np.linalg.norm(ref[k:k + 3])), 1e-30)
+            worst = max(worst, float(np.abs(got[k:k + 3] - ref[k:k + 3]).max()) / scale)
+    assert worst <= 6e-7, worst   # the oracle writes dot() as an fma chain (what nvcc contracts to), host gdt does not
+
+
+def test_affine_transforms_match_gdt_wide(oracle):
+    """200 random instance transforms translate(origin) * scale(s), s from 0.05 to 3000 per axis, and points"""
+    ain, aout = _f("affine_in").reshape(-1, 9).astype(np.float64), _f("affine_out").reshape(-1, 12)
+    worst = 0.0
+    for a, ref in zip(ain, aout):
+        got = np.asarray(oracle.xfm_probe(a[0:3], a[3:6], a[6:9]), dtype=np.float32)
+        for k in range(0, 12, 3):
+            scale = max(float(np.abs(ref[k:k + 3]).max()), 1e-30)
+            worst = max(worst, float(np.abs(got[k:k + 3] - ref[k:k + 3]).max()) / scale)
+    assert worst <= 1e-6, worst   # gdt inverts through adjoint / det; the oracle restates the diagonal inverse as 1 / s
+
+
+def test_exr_half_conversion_matches_reference_bit_exact_wide(oracle):
+    """16 384 floats over the whole half range and beyond - exponents 2^-27 ... 2^17, a quarter of them exact ties between two halves,
+    others one bit to either side of a tie - through the reference's save_image("*.exr") + load_exr: same bits from the oracle's rule"""
+    fin = _f("exr_in").reshape(4, 1024, 4)
+    out = WIDE["exr_out"].reshape(4, 1024, 4)
+    lib = oracle.load()
+    half = oracle.float_to_half(fin)
+    back = np.array([lib.ovr_oracle_half_to_float(int(v)) for v in half.ravel()], dtype=np.float32).view(np.uint32).reshape(half.shape)
+    assert np.array_equal(back[..., [1, 2, 3, 0]], out)
+    o = out.view(np.float32)
+    assert np.isinf(o).any() and (o == 0).any() and ((np.abs(o) > 0) & (np.abs(o) < 6.2e-5)).any()   # overflow, underflow and subnormal halves all occur

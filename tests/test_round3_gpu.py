@@ -249,3 +249,30 @@ def test_hits_through_an_ignored_slab_reach_the_host_mirror(ovr, oracle, hip_ren
     moved = frames_of("moved")
     assert (ren.stats().frame_index == 1 or not accumulate) and (moved[..., 3] > 0).any()
     ren.close()
+
+
+def test_device_frame_output_against_the_references_own_conversions(ovr, oracle, hip_renderer_factory):
+    """rgba8_kernel and rgba16f_kernel on the WIDE vectors the reference's compiled image_to_rgba8 and save_image("*.exr") + load_exr produced
+    (tests/golden/ref_probe_wide.npz): the vectors are written into the device framebuffer, the device converts them, the bits must be the
+    reference's - every float within 6 ulp of k / 255, 16 384 floats over the half range with a quarter of them exact ties"""
+    import torch
+    wide = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_probe_wide.npz"))
+    lib = oracle.load()
+    for key, size in (("rgba8", (60, 31)), ("exr", (64, 64))):
+        vin = wide[key + "_in"].view(np.float32)
+        assert vin.size == size[0] * size[1] * 4
+        case = make_case(ovr, oracle, n=8, tf="dense", cam="oblique", size=size, shading=0)
+        ren = hip_setup(ovr, hip_renderer_factory(), case)
+        ren.render()
+        fb = ovr.FrameBufferData()
+        ren.mapframe(fb, device=True)
+        fb.rgba.data().view(-1).copy_(torch.from_numpy(vin.copy()).to(fb.rgba.data().device))
+        torch.cuda.synchronize()
+        if key == "rgba8":
+            got = ren.mapframe_rgba8(flip_vertical=False, device=True).cpu().numpy().reshape(-1)
+            assert np.array_equal(got, wide["rgba8_out"])
+        else:
+            half = ren.mapframe_rgba16f(flip_vertical=False, device=True).cpu().numpy().reshape(-1, 4)
+            back = np.array([lib.ovr_oracle_half_to_float(int(v)) for v in half.ravel()], dtype=np.float32).view(np.uint32).reshape(-1, 4)
+            assert np.array_equal(back[:, [1, 2, 3, 0]].reshape(-1), wide["exr_out"])
+        ren.close()
