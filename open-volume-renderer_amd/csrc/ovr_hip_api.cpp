@@ -641,6 +641,10 @@ int enqueue_frame(ovr_hip_renderer* r)
 
   P.rgba = r->d_rgba[r->cur];
   nonzero_rect(r, r->d_rect[r->cur]); // what mapframe(HOST) will have to copy of this set (the committed camera is the one this frame renders)
+  if (r->shard.current.world > 1) { // an image shard leaves the tiles of the other ranks as they are - whatever an earlier, unsharded frame put there,
+    int* q = r->d_rect[r->cur];     // also outside the box's rectangle: such a set is mapped whole (found by tests/fuzz_states.py, seeds 61 / 62)
+    q[0] = 0; q[1] = 0; q[2] = W; q[3] = H;
+  }
   r->frame_set = r->cur;
   P.grad = r->d_grad[r->cur];
   P.accum = r->d_accum;

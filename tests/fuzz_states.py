@@ -43,6 +43,11 @@ def episode(ep):
         if jitter:
             kw.update(jitter=1, noise=noise)
         got = hip_frame(ovr, ren)[0]
+        fbd = ovr.FrameBufferData()
+        ren.mapframe(fbd, device=True)   # the host mirror is a copy of the device frame - of ALL of it, whatever rectangle was refreshed
+        for lay, host in (("rgba", got), ("grad", hip_frame(ovr, ren)[1])):
+            dev_frame = getattr(fbd, lay).data().cpu().numpy().reshape(host.shape)
+            assert np.array_equal(dev_frame.view(np.uint32), host.view(np.uint32)), tag + f" host mirror != device frame ({lay})"
         st = ren.stats()
         ref, _, cnt = oracle_scene(O, case, **kw).render(frames=int(st.frame_index), accumulate=accumulate)
         if rng.integers(4) == 0:   # the 8-bit frame the device converts (image_to_rgba8), flipped like the PNG writer wants it

@@ -276,3 +276,34 @@ def test_device_frame_output_against_the_references_own_conversions(ovr, oracle,
             back = np.array([lib.ovr_oracle_half_to_float(int(v)) for v in half.ravel()], dtype=np.float32).view(np.uint32).reshape(-1, 4)
             assert np.array_equal(back[:, [1, 2, 3, 0]].reshape(-1), wide["exr_out"])
         ren.close()
+
+
+def test_the_mirror_of_a_frame_rendered_after_an_image_shard(ovr, oracle, hip_renderer_factory):
+    """an image shard leaves the tiles of the other ranks as an earlier frame left them - also outside the rectangle the box projects into now;
+    mapframe(HOST) must not assume zeros there, and after the shard is switched off the mirror must show the new whole frame
+    (found by tests/fuzz_states.py, seeds 61 / 62: host frame != device frame)"""
+    case = make_case(ovr, oracle, n=24, tf="dense", cam="inside", size=(45, 43), shading=2)
+    ren = hip_setup(ovr, hip_renderer_factory(), case, accumulate=False)
+
+    def mirror_equals_device(tag):
+        fb_h, fb_d = ovr.FrameBufferData(), ovr.FrameBufferData()
+        ren.mapframe(fb_h)
+        ren.mapframe(fb_d, device=True)
+        h = np.array(fb_h.rgba.data(), copy=True)
+        assert np.array_equal(h.view(np.uint32), fb_d.rgba.data().cpu().numpy().reshape(h.shape).view(np.uint32)), tag
+        return h
+
+    ren.render()
+    full = mirror_equals_device("camera inside: every pixel lit")
+    assert (full[..., 3] > 0).mean() > 0.9
+    ren.set_image_shard(0, 2, 16, 8); ren.commit(); ren.render()
+    mirror_equals_device("sharded")
+    case["cam"] = tuple(ovr.synth.make_camera("front", 24))                      # the box now covers the middle of the frame only
+    ren.set_camera(ovr.Camera(*case["cam"], case["fovy"])); ren.commit(); ren.render()
+    mirror_equals_device("sharded, small rectangle: the other rank's tiles still hold the first frame")
+    ren.set_image_shard(0, 1, 16, 8); ren.commit(); ren.render()
+    whole = mirror_equals_device("unsharded again")
+    ref, _, _ = oracle_scene(oracle, case).render()
+    compare(oracle, whole, ref, name="after the shard")
+    assert (whole[:, :4, 3] == 0).all()                                           # the frame's border is outside the box again
+    ren.close()
