@@ -16,6 +16,14 @@ n_ops = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 DTYPES = [np.float32, np.uint8, np.uint16, np.int16, np.int8]
 failures = 0
 LONG = __import__('os').environ.get('OVR_FUZZ_LONG') == '1'
+# OVR_FUZZ_GATHER=1: every frame also goes through the N > 1 frame path with ONE rank - tiles.TileGather over gloo: pack behind the frame, the
+# collective on its own stream, the scatter one call later - and the gathered frame must equal the device frame
+GATHER = __import__('os').environ.get('OVR_FUZZ_GATHER') == '1'
+if GATHER:
+    import torch
+    import torch.distributed as dist
+    __import__('os').environ.setdefault('MASTER_ADDR', '127.0.0.1'); __import__('os').environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group('gloo', rank=0, world_size=1)
 
 
 def episode(ep):
@@ -31,6 +39,26 @@ def episode(ep):
     ren.set_volume_layouts(2)
     hip_setup(ovr, ren, case, accumulate=True, pipeline=0)
     ren.set_noise_tile(noise)
+    gat = [None]
+
+    def new_gatherer():
+        if GATHER:
+            ren.set_image_shard(0, 1, 16, 16); ren.commit()   # the tile size the payload slots are cut for (bench.py does the same)
+            ren.sync()
+            w, h = case["size"]
+            gat[0] = ovr.tiles.TileGather(ren, w, h, 16, 0, 1, torch.device("cuda", 0))
+
+    def render_one():
+        if not GATHER:
+            ren.render()
+            return
+        ren.render_async(); gat[0].run(); ren.sync()
+        try:
+            gat[0].check()
+        except RuntimeError:          # the frame overflowed its pool after its tiles were packed and was rendered again: gather the good frame
+            gat[0].run(); ren.sync(); gat[0].check()
+
+    new_gatherer()
     sparse, focus, shard, skip, jitter, accumulate = False, ((0.5, 0.45), 0.35, 0.15), None, False, False, True
     log = [f"init {st8}"]
 
@@ -43,6 +71,9 @@ def episode(ep):
         if jitter:
             kw.update(jitter=1, noise=noise)
         got = hip_frame(ovr, ren)[0]
+        if GATHER:
+            gat[0].flush(); ren.sync(); torch.cuda.synchronize()
+            assert np.array_equal(gat[0].frame.cpu().numpy().view(np.uint32), got.view(np.uint32)), tag + " gathered frame != rendered frame"
         fbd = ovr.FrameBufferData()
         ren.mapframe(fbd, device=True)   # the host mirror is a copy of the device frame - of ALL of it, whatever rectangle was refreshed
         for lay, host in (("rgba", got), ("grad", hip_frame(ovr, ren)[1])):
@@ -65,7 +96,7 @@ def episode(ep):
         assert st.samples + st.skipped_samples == cnt.samples, (tag, st.samples, st.skipped_samples, cnt.samples)
 
     try:
-        ren.render()
+        render_one()
         check("initial")
         for k in range(n_ops):
             op = int(rng.integers(0, 17))
@@ -104,6 +135,8 @@ def episode(ep):
                     focus = ((float(rng.uniform(0.2, 0.8)), float(rng.uniform(0.2, 0.8))), float(rng.uniform(0.1, 0.5)), float(rng.uniform(0.02, 0.3)))
                     ren.set_focus(*focus)
                 ren.set_sparse_sampling(sparse); log.append(f"sparse {sparse} {focus}")
+            elif op == 9 and GATHER:
+                log.append("render only (no shard changes under the gather)")
             elif op == 9:
                 shard = None if rng.integers(2) else (int(rng.integers(0, 2)), 2, int(rng.choice([8, 16])), int(rng.choice([8, 16])))
                 ren.set_image_shard(*(shard or (0, 1, 16, 16))); log.append(f"shard {shard}")
@@ -137,9 +170,11 @@ def episode(ep):
             else:
                 log.append("render only")
             ren.commit()
+            if op == 1:
+                new_gatherer()
             frames = int(rng.choice([1, 1, 2, 3, 5] if not LONG else [1, 3, 14, 36]))   # LONG: past the 12-frame re-measurement and the 32-frame skipping probe
             for _ in range(frames):
-                ren.render()
+                render_one()
             log.append(f"  rendered {frames}: frame_index {ren.stats().frame_index} layout {ren.stats().layout} pipeline {ren.stats().pipeline} tuning {ren.stats().tuning}")
             check(f"episode {ep} op {k}")
     except AssertionError as e:
