@@ -19,6 +19,7 @@ LONG = __import__('os').environ.get('OVR_FUZZ_LONG') == '1'
 # OVR_FUZZ_GATHER=1: every frame also goes through the N > 1 frame path with ONE rank - tiles.TileGather over gloo: pack behind the frame, the
 # collective on its own stream, the scatter one call later - and the gathered frame must equal the device frame
 GATHER = __import__('os').environ.get('OVR_FUZZ_GATHER') == '1'
+NONFINITE = __import__('os').environ.get('OVR_FUZZ_NONFINITE') == '1'   # float volumes with a few NaN / Inf voxels
 if GATHER:
     import torch
     import torch.distributed as dist
@@ -35,6 +36,10 @@ def episode(ep):
     case = make_case(ovr, O, n=max(dims), dtype=st8["dtype"], tf=st8["tf"], cam=st8["cam"], size=st8["size"], shading=st8["shading"], rate=st8["rate"],
                      convention=st8["convention"], dims=dims, spacing=spacing, tf_n=st8["tf_n"])
     noise = np.random.default_rng(5).random((16, 16, 64), dtype=np.float32)
+    if NONFINITE and st8["dtype"] == np.float32:   # a few NaN / +-Inf voxels: fmaxf / fminf / clamp semantics of the reference's device build
+        v = case["vol"]
+        idx = rng.integers(0, v.size, 6)
+        v.reshape(-1)[idx] = np.array([np.nan, np.inf, -np.inf, np.nan, 3.0e38, -3.0e38], np.float32)
     ren = ovr.create_renderer("hip")
     ren.set_volume_layouts(2)
     hip_setup(ovr, ren, case, accumulate=True, pipeline=0)
@@ -92,7 +97,14 @@ def episode(ep):
                 mask[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw] = True
             got = np.where(mask[..., None], got, 0.0).astype(np.float32)
             ref = np.where(mask[..., None], ref, 0.0).astype(np.float32)
-        compare(O, got, ref, name=tag)
+        try:
+            compare(O, got, ref, name=tag)
+        except AssertionError as e:
+            d = np.abs(got - ref)
+            d = np.where(np.isnan(d), np.inf, d)
+            y, x, ch = np.unravel_index(np.argmax(d), d.shape)
+            raise AssertionError(f"{e}; worst pixel ({x},{y}) channel {ch}: hip {got[y, x]} oracle {ref[y, x]}; pixels over 2e-4: {(d.max(axis=-1) > 2e-4).sum()}; "
+                                 f"layout {st.layout} pipeline {st.pipeline} shading {case['shading']}")
         assert st.samples + st.skipped_samples == cnt.samples, (tag, st.samples, st.skipped_samples, cnt.samples)
 
     try:
