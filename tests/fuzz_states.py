@@ -33,8 +33,10 @@ def episode(ep):
     spacing = tuple(float(rng.choice([1.0, 0.5, 2.0])) for _ in range(3))
     st8 = dict(dtype=DTYPES[int(rng.integers(len(DTYPES)))], dims=dims, spacing=spacing, tf=str(rng.choice(["sparse", "dense", "bumps"])), cam=str(rng.choice(["front", "oblique", "inside"])),
                size=(int(rng.integers(17, 80)), int(rng.integers(9, 60))), shading=int(rng.integers(0, 3)), rate=1.0, convention=int(rng.integers(2)), tf_n=int(rng.choice([64, 128])))
+    origin = tuple(float(x) for x in rng.choice([0.0, -7.5, 13.0], 3))
     case = make_case(ovr, O, n=max(dims), dtype=st8["dtype"], tf=st8["tf"], cam=st8["cam"], size=st8["size"], shading=st8["shading"], rate=st8["rate"],
-                     convention=st8["convention"], dims=dims, spacing=spacing, tf_n=st8["tf_n"])
+                     convention=st8["convention"], dims=dims, spacing=spacing, tf_n=st8["tf_n"], origin=origin, fovy=float(rng.choice([60.0, 60.0, 35.0, 95.0])))
+    st8["origin"], st8["fovy"] = origin, case["fovy"]
     noise = np.random.default_rng(5).random((16, 16, 64), dtype=np.float32)
     if NONFINITE and st8["dtype"] == np.float32:   # a few NaN / +-Inf voxels: fmaxf / fminf / clamp semantics of the reference's device build
         v = case["vol"]
@@ -111,11 +113,11 @@ def episode(ep):
         render_one()
         check("initial")
         for k in range(n_ops):
-            op = int(rng.integers(0, 17))
+            op = int(rng.integers(0, 19))
             if op == 0:
                 kind = str(rng.choice(["front", "oblique", "inside", "random"]))
                 if kind == "random":
-                    c = np.array(dims) * np.array(spacing) / 2.0
+                    c = np.array(case["origin"]) + np.array(dims) * np.array(spacing) / 2.0
                     d = rng.normal(size=3); d /= np.linalg.norm(d)
                     if rng.integers(3) == 0:
                         d = np.eye(3)[int(rng.integers(3))] * (1 if rng.integers(2) else -1)   # exactly along an axis
@@ -123,7 +125,7 @@ def episode(ep):
                     up = (0.0, 1.0, 0.0) if abs(d[1]) < 0.9 else (0.0, 0.0, 1.0)
                     case["cam"] = (eye, tuple(c), up)
                 else:
-                    case["cam"] = make_case(ovr, O, n=max(dims), dtype=st8["dtype"], cam=kind, dims=dims, spacing=spacing, convention=case["convention"], tf_n=64)["cam"]
+                    case["cam"] = make_case(ovr, O, n=max(dims), dtype=st8["dtype"], cam=kind, dims=dims, spacing=spacing, convention=case["convention"], tf_n=64, origin=case["origin"])["cam"]
                 ren.set_camera(ovr.Camera(*case["cam"], case["fovy"])); log.append(f"camera {kind} {case['cam']}")
             elif op == 1:
                 case["size"] = (int(rng.integers(9, 90)), int(rng.integers(5, 70))); ren.set_fbsize(case["size"]); log.append(f"fbsize {case['size']}")
@@ -168,11 +170,22 @@ def episode(ep):
                 jitter = bool(rng.integers(2)); ren.set_pixel_jitter(1 if jitter else 0); log.append(f"blue-noise jitter {jitter}")
             elif op == 15:
                 accumulate = bool(rng.integers(3) != 0); ren.set_frame_accumulation(accumulate); log.append(f"accumulate {accumulate}")
+            elif op == 17:   # the same camera with another field of view
+                case["fovy"] = float(rng.choice([20.0, 45.0, 60.0, 100.0]))
+                ren.set_camera(ovr.Camera(*case["cam"], case["fovy"])); log.append(f"fovy {case['fovy']}")
+            elif op == 18:   # a transfer-function range that covers part of the data, or an invalid one (-> the data range, volume.cpp:131-145)
+                lo0, hi0 = ovr.synth.make_tfn("dense", 8, st8["dtype"])[2]
+                a, b = sorted(rng.uniform(0.0, 1.0, 2))
+                if rng.integers(4) == 0:   # an invalid range after a valid one KEEPS the range in effect (set_value_range ignores it, volume.cpp:135)
+                    ren.set_transfer_function(case["colors"], case["alphas"], (1.0, -1.0)); log.append(f"value range (1, -1): stays {case['vr']}")
+                else:
+                    case["vr"] = (float(lo0 + a * (hi0 - lo0)), float(lo0 + max(b, a + 0.05) * (hi0 - lo0)))
+                    ren.set_transfer_function(case["colors"], case["alphas"], case["vr"]); log.append(f"value range {case['vr']}")
             elif op == 16:   # a new volume of another shape and type on the same renderer (the app's "open file")
                 dims2 = tuple(int(rng.integers(9, 40)) for _ in range(3))
                 dt2 = DTYPES[int(rng.integers(len(DTYPES)))]
                 new = make_case(ovr, O, n=max(dims2), dtype=dt2, tf=str(rng.choice(["sparse", "dense", "bumps"])), cam="oblique", size=case["size"], shading=case["shading"], rate=case["rate"],
-                                spp=case["spp"], convention=case["convention"], dims=dims2, spacing=case["spacing"], tf_n=64)
+                                spp=case["spp"], convention=case["convention"], dims=dims2, spacing=case["spacing"], tf_n=64, origin=case["origin"], fovy=case["fovy"])
                 case.update(new); st8["dtype"] = dt2; dims = dims2
                 ren.set_transfer_function(case["colors"], case["alphas"], case["vr"])
                 ren.init(ovr.Scene(volume=case["vol"], grid_origin=case["origin"], grid_spacing=case["spacing"], transfer_function=None, volume_sampling_rate=case["rate"]),
