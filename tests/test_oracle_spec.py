@@ -112,7 +112,10 @@ class Spec:
             tx, ty = t0, min(t1, t0 + self.step)
             while ty > tx and alpha < np.float32(0.9999):
                 pos = self.org + 0.5 * (tx + ty) * d
-                p = np.clip(self.to_object(pos), 0.0, 1.0)
+                # the UNCLAMPED object-space position goes to the gradient (shaders_raymarching.cu:112-113,128-129); only the sampler clamps
+                # (shaders_common.h:189-191).  It matters for rays outside the box - those the box test lets through by ignoring the slab of an
+                # axis they are parallel to (found by a random oracle-vs-spec hunt: an axis-aligned camera's centre row)
+                p = self.to_object(pos)
                 s = self.tap(p)
                 rgb, a = self.tf(s)
                 a = self.correct(a, ty - tx)
@@ -184,3 +187,22 @@ def test_homogeneous_volume_closed_forms(ovr, oracle):
         assert np.allclose(centre[:3], [0.2, 0.6, 0.9], atol=1e-5)
     # fractional last step: opacity correction 1 - (1 - a)^dt
     assert abs(oracle.load().ovr_oracle_opacity_correction(0.3, 1.0, 0.25) - (1 - 0.7 ** 0.25)) < 1e-6
+
+
+@pytest.mark.parametrize("size,cam,shading", [((7, 7), "front", 2), ((6, 7), "front", 2), ((9, 5), "front", 1), ((8, 6), "inside", 2)])
+def test_oracle_agrees_with_the_spec_on_rays_outside_the_box(ovr, oracle, size, cam, shading):
+    """An axis-aligned camera with an odd frame size: the centre row / column runs exactly parallel to an axis, the reference's box test ignores that
+    slab, and such rays march OUTSIDE the box where the eye lies outside it (here: above it) - the sampler clamps their positions, the gradient
+    gets the unclamped one (shaders_raymarching.cu:112-129).  Non-cubic grid, anisotropic spacing, an origin off zero."""
+    dims, spacing, origin = (5, 5, 14), (2.0, 2.0, 0.5), (6.0, 0.0, -3.5)
+    case = make_case(ovr, oracle, n=14, dtype=np.float32, tf="dense", cam=cam, size=size, shading=shading, dims=dims, spacing=spacing, origin=origin, fovy=90.0, tf_n=16)
+    ref, _, cnt = oracle_scene(oracle, case).render()
+    sp = Spec(case["vol"], case["colors"], case["alphas"], case["vr"], case["cam"], case["size"], case["fovy"], case["rate"], shading, origin=origin, spacing=spacing)
+    w, h = size
+    n_tot, worst = 0, 0.0
+    for iy in range(h):
+        for ix in range(w):
+            px, n, _ = sp.ray(ix, iy)
+            n_tot += n
+            worst = max(worst, float(np.abs(px[:3] * px[3] - ref[iy, ix, :3] * ref[iy, ix, 3]).max()), float(abs(px[3] - ref[iy, ix, 3])))
+    assert n_tot == cnt.samples and cnt.samples > 0 and worst < 5e-5, (n_tot, cnt.samples, worst)
