@@ -2,11 +2,12 @@
 uncompressed, uniform values, arbitrary bit patterns and 15 decades of magnitudes - loaded by the REFERENCE's tinyexr (LoadEXR in oracle/_ref/libovr_refhost.so):
 the floats it returns must be the halves that were written, bit for bit.   usage: python tests/exr_hunt.py"""
 import sys, os, ctypes as C, tempfile
-sys.path[:0]=['/root/repo','/root/repo/oracle']
+import os as _os; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path[:0]=[_R,_R + '/oracle']
 import numpy as np
 import ovr_amd as ovr
 import oracle as O
-ref = C.CDLL('/root/repo/oracle/_ref/libovr_refhost.so')
+ref = C.CDLL(_R + '/oracle/_ref/libovr_refhost.so')
 ref.LoadEXR.argtypes = [C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.POINTER(C.c_char_p)]
 lib = O.load()
 rng = np.random.default_rng(3)

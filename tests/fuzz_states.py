@@ -4,7 +4,8 @@ accumulated (ovr_hip_stats.frame_index).  Hunts what the scripted test_state_cha
 macrocells, request pool, measured layout / pipeline decisions, the mapped rectangle), missed or spurious accumulation resets.
 usage: python tests/fuzz_states.py [episodes] [seed] [ops per episode]"""
 import sys
-sys.path[:0] = ['/root/repo', '/root/repo/tests', '/root/repo/oracle']
+import os as _os; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path[:0] = [_R, _R + '/tests', _R + '/oracle']
 import numpy as np
 import ovr_amd as ovr
 import oracle as O

@@ -1,7 +1,8 @@
 """One-off hunt: the sparse-sampling mask (generate_mask.cu:55-120 restated) for random frame sizes up to 4K, noise tiles, focus windows, base noise
 and frame indices - the device's compacted pixel list against the oracle's, bit for bit.   usage: python tests/mask_hunt.py [cases] [seed]"""
 import sys
-sys.path[:0] = ['/root/repo', '/root/repo/tests', '/root/repo/oracle']
+import os as _os; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path[:0] = [_R, _R + '/tests', _R + '/oracle']
 import numpy as np
 import ovr_amd as ovr
 import oracle as O

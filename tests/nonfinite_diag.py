@@ -1,7 +1,8 @@
 """Which combination of non-finite / huge voxels makes the HIP frame differ from the oracle's?  (diagnostic; python tests/nonfinite_diag.py)"""
 import itertools
 import sys
-sys.path[:0] = ['/root/repo', '/root/repo/tests', '/root/repo/oracle']
+import os as _os; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path[:0] = [_R, _R + '/tests', _R + '/oracle']
 import numpy as np
 import ovr_amd as ovr
 import oracle as O

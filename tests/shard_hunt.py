@@ -3,7 +3,8 @@ scattered into one frame, which must equal the unsharded frame bit for bit; the 
 (tiles.pack_tiles_host).   usage: python tests/shard_hunt.py [cases] [seed]"""
 import ctypes as C
 import sys
-sys.path[:0] = ['/root/repo', '/root/repo/tests', '/root/repo/oracle']
+import os as _os; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path[:0] = [_R, _R + '/tests', _R + '/oracle']
 import numpy as np
 import torch
 import ovr_amd as ovr

@@ -2,7 +2,8 @@
 origins, voxel types, shading modes, cameras (also exactly along an axis, frame sizes odd and even), transfer functions, sampling rates 0.5 ... 4, fields of view.
 Premultiplied colour and alpha within 5e-5, sample counts within the float32 / float64 borderline cases.   usage: python tests/spec_hunt.py [cases] [seed]"""
 import sys
-sys.path[:0]=['/root/repo','/root/repo/tests','/root/repo/oracle']
+import os as _os; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path[:0]=[_R,_R + '/tests',_R + '/oracle']
 import numpy as np
 import ovr_amd as ovr
 import oracle as O

@@ -1,7 +1,8 @@
 """Diagnoses cases of tests/test_config_sweep_gpu.py's round-3 sweep that miss the parity bar: where is the worst pixel, what are its alpha and its
 premultiplied colour on both sides?   usage: OVR_SWEEP_SEED=.. OVR_SWEEP_CASES=.. python tests/sweep_diag.py <case index> ..."""
 import os, sys
-sys.path[:0] = ['/root/repo', '/root/repo/tests', '/root/repo/oracle']
+import os as _os; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path[:0] = [_R, _R + '/tests', _R + '/oracle']
 import numpy as np
 import ovr_amd as ovr
 import oracle as O

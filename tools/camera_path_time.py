@@ -4,7 +4,8 @@ the shipped scenes in - the scene files' sampling rate 4 with a dense transfer f
 for the renderer to measure layout and pipeline: the decision measured while the camera rested is kept while it moves.
 usage: python tools/camera_path_time.py [n] [rate] [tf]"""
 import sys, time
-sys.path[:0] = ['/root/repo', '/root/repo/tests']
+import os as _os; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path[:0] = [_R, _R + '/tests']
 import numpy as np, torch, ovr_amd as ovr
 from test_full_size_gpu import _setup
 

@@ -2,7 +2,8 @@
 sampling rate, shading mode, sparse sampling, empty-space skipping - to spot modes that cost more than their work explains.
 usage: python tools/explore_modes.py [n]"""
 import itertools, sys, time
-sys.path[:0] = ['/root/repo', '/root/repo/tests']
+import os as _os; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path[:0] = [_R, _R + '/tests']
 import numpy as np, torch, ovr_amd as ovr
 from test_full_size_gpu import _setup
 

@@ -1,6 +1,7 @@
 """PCIe-inclusive frame hand-over: time of mapframe(HOST) (RGBA32F + gradient layer), RGBA32F only, and mapframe_rgba8(HOST)"""
 import sys, time
-sys.path.insert(0, '/root/repo')
+import os as _os; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path.insert(0, _R)
 import torch, ovr_amd as ovr
 n, size = 256, (1920, 1080)
 vol = ovr.synth.make_volume_torch(n, torch.device('cuda', 0), 'float32')

@@ -4,7 +4,8 @@ march of one shard meets the shade kernel of another); compared with ONE rendere
 reference's render() blocks per frame.   usage: python tools/overlap_probe.py [frames]"""
 import sys
 import time
-sys.path[:0] = ['/root/repo', '/root/repo/tests']
+import os as _os; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path[:0] = [_R, _R + '/tests']
 import torch, ovr_amd as ovr
 from test_full_size_gpu import _setup
 

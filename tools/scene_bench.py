@@ -3,10 +3,11 @@ transfer function, value range and camera at 1920x1080 with renderbatch's settin
 accumulation) - on a synthetic field mapped into the scene's value range, because the datasets do not ship.  With the plain kernels and
 with empty-space skipping enabled (the plugin's default).   usage: python tools/scene_bench.py [scene substring]"""
 import os, sys, time
-sys.path[:0] = ['/root/repo', '/root/repo/tests']
+import os as _os; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path[:0] = [_R, _R + '/tests']
 import numpy as np, torch, ovr_amd as ovr
 
-SCENES = os.path.join('/root/repo', 'tests', 'golden', 'scenes')
+SCENES = os.path.join(_R, 'tests', 'golden', 'scenes')
 pick = sys.argv[1] if len(sys.argv) > 1 else ''
 dev = torch.device('cuda', 0)
 

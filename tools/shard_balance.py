@@ -4,7 +4,8 @@ OVR_SHARD_CONFIG=c4 | c5 rehearses BASELINE's 8-GPU configurations (2048^3 u16 a
 blue-noise pixel jitter) instead of C3."""
 import os
 import sys
-sys.path[:0] = ['/root/repo', '/root/repo/tests']
+import os as _os; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path[:0] = [_R, _R + '/tests']
 import numpy as np, torch, ovr_amd as ovr
 from test_full_size_gpu import _setup
 

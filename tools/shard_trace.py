@@ -1,5 +1,6 @@
 import sys
-sys.path[:0] = ['/root/repo', '/root/repo/tests']
+import os as _os; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path[:0] = [_R, _R + '/tests']
 import torch, ovr_amd as ovr
 from test_full_size_gpu import _setup
 world, tile = int(sys.argv[1]), int(sys.argv[2])

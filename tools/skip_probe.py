@@ -1,6 +1,7 @@
 """march time with empty-space skipping for: an all-transparent TF (every round skipped by the ray interval), the bench TF"""
 import sys
-sys.path[:0] = ['/root/repo', '/root/repo/tests']
+import os as _os; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path[:0] = [_R, _R + '/tests']
 import numpy as np, torch, ovr_amd as ovr
 n, size = 1024, (1920, 1080)
 vol = ovr.synth.make_volume_torch(n, torch.device('cuda', 0), 'float32')

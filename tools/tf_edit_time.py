@@ -2,7 +2,8 @@
 uploads the tables and - with empty-space skipping, the plugin's default - rebuilds the majorant and occupancy grids.
 usage: python tools/tf_edit_time.py [n]"""
 import sys, time
-sys.path[:0] = ['/root/repo', '/root/repo/tests']
+import os as _os; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path[:0] = [_R, _R + '/tests']
 import numpy as np, torch, ovr_amd as ovr
 from test_full_size_gpu import _setup
 
