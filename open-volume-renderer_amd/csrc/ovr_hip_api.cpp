@@ -1086,6 +1086,8 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
   if (vt == VOX_U8) vd.value_scale = 1.f / 255.f;
   if (vt == VOX_I8) { vd.value_scale = 1.f / 127.f; vd.value_min_clamp = -127.f; }
   const size_t bytes = (size_t)vd.bytes;
+  if (!layout_offsets_fit(vd))
+    return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_volume: one z layer of the volume exceeds 2^32 stored voxels (x * y too large for the 32-bit in-plane offsets)");
 
   for (int k = 0; k < kLayouts; ++k) {
     if (r->d_replica[k]) HIP_TRY(hipFree(r->d_replica[k]));
@@ -1115,7 +1117,7 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
     volume_layout(replica_voxel_type(vt, LAYOUT_THIN_T), vd.nx, vd.ny, vd.nz, t2);
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    if (r->layouts.current == 2 || (double)(t1.bytes + t2.bytes) <= 0.4 * (double)free_b) {
+    if (layout_offsets_fit(t1) && layout_offsets_fit(t2) && (r->layouts.current == 2 || (double)(t1.bytes + t2.bytes) <= 0.4 * (double)free_b)) {
       const VolumeDesc* ts[2] = { &t1, &t2 };
       hipError_t e = hipSuccess;
       for (int k = 1; k <= 2 && e == hipSuccess; ++k) {
@@ -1149,7 +1151,7 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const double built = (double)(r->volume_bytes - bytes); // the thin replicas, already allocated
-    if (r->layouts.current == 2 || (double)tq.bytes + built <= 0.4 * ((double)free_b + built)) {
+    if (layout_offsets_fit(tq) && (r->layouts.current == 2 || (double)tq.bytes + built <= 0.4 * ((double)free_b + built))) {
       hipError_t e = hipMalloc(&r->d_replica[LAYOUT_QUAD], (size_t)tq.bytes + 64);
       if (e == hipSuccess) e = hipMemset(r->d_replica[LAYOUT_QUAD], 0, (size_t)tq.bytes + 64);
       if (e == hipSuccess) {
@@ -1240,6 +1242,7 @@ int ovr_hip_query_addressing_mode(const int32_t dims[3], int value_type, int32_t
   if (layout < 0 || layout >= kLayouts || rt < 0) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_query_addressing_mode: the type has no such layout");
   VolumeDesc vd{};
   volume_layout(rt, dims[0], dims[1], dims[2], vd);
+  if (!layout_offsets_fit(vd)) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_query_addressing_mode: one z layer of this layout exceeds 2^32 elements - it is not built");
   return volume_addressing_mode(vd, n_colors, n_alphas);
 }
 

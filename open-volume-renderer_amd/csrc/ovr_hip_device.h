@@ -186,7 +186,10 @@ template <int VT> struct BrickMap {
   // exact for x < 65536: q = floor(x / d) = mulhi(x, ceil(2^32 / d))
   static __host__ __device__ __forceinline__ unsigned div_cx(unsigned x) { return (unsigned)(((unsigned long long)x * ((0xffffffffull / V::cx) + 1ull)) >> 32); }
   static __host__ __device__ __forceinline__ unsigned div_mbx(unsigned b) { return (unsigned)(((unsigned long long)b * ((0xffffffffull / V::mbx) + 1ull)) >> 32); }
-  static __host__ __device__ __forceinline__ unsigned X(unsigned x) // offset of voxel x as the LOWER member of a pair
+  // offset of STORED POSITION u as the LOWER member of a pair.  Stored position = voxel index + 1 (round 4): position 0 is a copy of
+  // voxel 0, positions past voxel n - 1 repeat it - the pair of voxel index i in [-1, n - 1] is positions (i + 1, i + 2), which is the
+  // reference's clamp-to-edge pair (clamp(i), clamp(i + 1)) without a clamp in the tap (shaders_common.h:186-193, cuda_buffer.h:248-287)
+  static __host__ __device__ __forceinline__ unsigned X(unsigned x)
   {
     const unsigned b = div_cx(x), xr = x - b * V::cx;
     const unsigned m = div_mbx(b), bm = b - m * V::mbx;
@@ -202,8 +205,9 @@ template <int VT> struct BrickMap {
   }
 };
 
-// quad replicas: offsets in voxels (elements of T); cell (x, y, z) -> 4 elements at X(x) + Y(y) + Z(z); cells x-fastest inside a brick, bricks
-// x-fastest inside macro blocks of 32^3 cells, macro blocks x-fastest
+// quad replicas: offsets in voxels (elements of T); cell (u, v, z) -> 4 elements at X(u) + Y(v) + Z(z); cells x-fastest inside a brick, bricks
+// x-fastest inside macro blocks of 32^3 cells, macro blocks x-fastest.  Cell (u, v) = (x + 1, y + 1) holds the voxels (clamp(x), clamp(x + 1)) x
+// (clamp(y), clamp(y + 1)) for x in [-1, nx - 1], y in [-1, ny - 1] (round 4: the lower faces' clamp-to-edge pairs are cells of their own)
 template <int VT> struct QuadMap {
   typedef Vox<VT> V;
   static constexpr unsigned SX = 2, BV = 128u / (unsigned)sizeof(typename V::T);   // elements per brick
@@ -227,8 +231,9 @@ template <> struct BrickMap<VOX_U8_Q> : QuadMap<VOX_U8_Q> {};
 
 struct VolConsts {
   const void* data;
-  // per-axis offset tables in LDS (AM 0 / 1): tx[x] = X(x), ty[y] = Y(y), tz[z] = Z(z), bytes (AM 0) or elements (AM 1);
-  // ty / tz hold one extra entry equal to the last one, so (i, i + 1) is clamp-to-edge without a select
+  // per-axis offset tables in LDS (AM 0 / 1 / 2), bytes (AM 0) or elements (AM 1 / 2).  The pointers are BIASED by one entry: tab_x[i] is
+  // valid for the voxel index i = -1 ... n - 1 (lower member of the pair), tab_y[i] / tab_z[i] for i = -1 ... n; index -1 addresses a copy of
+  // voxel 0 and index n a copy of voxel n - 1, so (i, i + 1) is the reference's clamp-to-edge pair for every i = floor(x) without a select
   const unsigned int *tab_x, *tab_y, *tab_z;
   const unsigned long long* tab_z64; // AM 2: z offsets need 64 bits (>= 2^32 stored voxels)
   int nx1, ny1, nz1; // n - 1
@@ -238,20 +243,30 @@ struct VolConsts {
   int mcx1, mcy1, mcz1;  // macrocell grid dims - 1
   unsigned int macro_y;          // stored elements between macro rows: MV * macros_x
   unsigned long long macro_z;    // stored elements between macro layers: MV * macros_x * macros_y
-  float fx1, fy1, fz1;
   f3 cs, cb;
   float vscale, vmin;
 };
 
-__device__ __forceinline__ void axis_tap(float po, float cs, float cb, float fn1, int n1, int& i0, int& i1, float& f)
+// (int)floor(x) as ONE instruction (the compiler only selects v_cvt_flr_i32_f32 under no-NaNs math; x is never NaN here)
+__device__ __forceinline__ int floor_to_int(float x)
 {
-  const float p = clamp01(po);                       // sample_volume_object_space clamps p to [0,1]
-  float x = fmaf(p, cs, cb);                         // cell-centred: p*N - 0.5
-  x = clampf(x, 0.f, fn1);                           // == clamp-to-edge addressing: taps (i0, min(i0+1, n-1))
-  // x >= 0: truncation is floor, and v_fract_f32 = x - floor(x) (an exact subtraction) - two instructions instead of floor, sub, cvt
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+// One axis of tex3D's linear filter with clamp addressing (shaders_common.h:186-193; cuda_buffer.h:248-287): x = p * N - 0.5 lies in
+// [-0.5, N - 0.5], the texels are (clamp(i0), clamp(i0 + 1)) for i0 = floor(x) in [-1, N - 1], the weight is x - i0.  Every layout stores a
+// copy of voxel 0 at index -1 and of voxel N - 1 at index N (in the data along the pair axis, in the offset tables along the others), so
+// neither the coordinate nor the indices are clamped (round 4; before, x was clamped to [0, N - 1] and the half voxel outside the first
+// centre read (voxel 0, voxel 1) with weight 0 where the reference reads (0, 0): 0 x NaN for a non-finite voxel 1).  In that zone the weight
+// is immaterial - lerp(a, a, f) = fma(f, a - a, a) is a for finite a and NaN otherwise, whatever f in [0, 1) - and for x >= 0 v_fract_f32 is the
+// exact x - floor(x) of the reference's filter (in full precision: the oracle's convention).
+__device__ __forceinline__ void axis_tap(float po, float cs, float cb, int& i0, float& f)
+{
+  const float p = clamp01(po);                       // sample_volume_object_space clamps p to [0,1] (NaN -> 0)
+  const float x = fmaf(p, cs, cb);                   // cell-centred: p*N - 0.5
   f = __builtin_amdgcn_fractf(x);
-  i0 = (int)x;
-  i1 = min(i0 + 1, n1);
+  i0 = floor_to_int(x);
 }
 
 // One trilinear tap, split in two so that several taps can be in flight before the first is consumed
@@ -259,7 +274,7 @@ __device__ __forceinline__ void axis_tap(float po, float cs, float cb, float fn1
 struct Tap {
   float c000, c100, c010, c110, c001, c101, c011, c111;
   float fx, fy, fz;
-  int x0, y0, z0; // lower corner of the footprint (live only between tap_coords and tap_loads)
+  int x0, y0, z0; // lower corner of the footprint = floor of the texel coordinate, -1 ... n - 1 (live only between tap_coords and tap_loads)
 };
 
 // macrocell (16^3 voxels, reference accel/spatial_partition.h:24) whose value range covers the footprint (i0, i0 + 1) on
@@ -267,11 +282,9 @@ struct Tap {
 
 __device__ __forceinline__ void tap_coords(const VolConsts& vc, f3 p, Tap& t)
 {
-  int x1, y1, z1;
-  axis_tap(p.x, vc.cs.x, vc.cb.x, vc.fx1, vc.nx1, t.x0, x1, t.fx);
-  axis_tap(p.y, vc.cs.y, vc.cb.y, vc.fy1, vc.ny1, t.y0, y1, t.fy);
-  axis_tap(p.z, vc.cs.z, vc.cb.z, vc.fz1, vc.nz1, t.z0, z1, t.fz);
-  (void)x1; (void)y1; (void)z1;
+  axis_tap(p.x, vc.cs.x, vc.cb.x, t.x0, t.fx);
+  axis_tap(p.y, vc.cs.y, vc.cb.y, t.y0, t.fy);
+  axis_tap(p.z, vc.cs.z, vc.cb.z, t.z0, t.fz);
 }
 
 __device__ __forceinline__ unsigned int tap_cell(const VolConsts& vc, const Tap& t)
@@ -290,13 +303,13 @@ __device__ __forceinline__ void tap_loads(const VolConsts& vc, Tap& t)
   typedef typename Vox<VT>::P P;
   if constexpr (Vox<VT>::kQuad) { // quad replica: the (x, y) footprint of a z slice is ONE load (16 / 8 / 4 bytes)
     typedef typename Vox<VT>::Q Q;
-    const int z1 = min(t.z0 + 1, vc.nz1);
     Q q0, q1;
     if (AM == 3) {
-      const unsigned o = M::X((unsigned)t.x0) + M::Y((unsigned)t.y0, vc.macro_y);
+      const unsigned z0 = (unsigned)max(t.z0, 0), z1 = (unsigned)min(t.z0 + 1, vc.nz1);
+      const unsigned o = M::X((unsigned)(t.x0 + 1)) + M::Y((unsigned)(t.y0 + 1), vc.macro_y);
       const T* base = static_cast<const T*>(vc.data);
-      const unsigned long long oz0 = (unsigned long long)M::Zlo((unsigned)t.z0) + (unsigned long long)((unsigned)t.z0 >> 5) * vc.macro_z;
-      const unsigned long long oz1 = (unsigned long long)M::Zlo((unsigned)z1) + (unsigned long long)((unsigned)z1 >> 5) * vc.macro_z;
+      const unsigned long long oz0 = (unsigned long long)M::Zlo(z0) + (unsigned long long)(z0 >> 5) * vc.macro_z;
+      const unsigned long long oz1 = (unsigned long long)M::Zlo(z1) + (unsigned long long)(z1 >> 5) * vc.macro_z;
       q0 = *reinterpret_cast<const Q*>(base + (oz0 + o)); q1 = *reinterpret_cast<const Q*>(base + (oz1 + o));
     }
     else if (AM == 2) {
@@ -317,7 +330,6 @@ __device__ __forceinline__ void tap_loads(const VolConsts& vc, Tap& t)
         q0 = *reinterpret_cast<const Q*>(cb + (oz0 + o)); q1 = *reinterpret_cast<const Q*>(cb + (oz1 + o));
       }
     }
-    (void)z1;
     t.c000 = (float)q0.x; t.c100 = (float)q0.y; t.c010 = (float)q0.z; t.c110 = (float)q0.w;
     t.c001 = (float)q1.x; t.c101 = (float)q1.y; t.c011 = (float)q1.z; t.c111 = (float)q1.w;
     return;
@@ -325,20 +337,19 @@ __device__ __forceinline__ void tap_loads(const VolConsts& vc, Tap& t)
   // layout coordinates (a, b, c): a = the pair axis (the volume's x; its y in a transposed replica), b = the other of the two
   constexpr bool TR = Vox<VT>::kTransposed;
   const int a0 = TR ? t.y0 : t.x0, b0 = TR ? t.x0 : t.y0, z0 = t.z0;
-  const int nb1 = TR ? vc.nx1 : vc.ny1;
-  const int b1 = min(b0 + 1, nb1), z1 = min(z0 + 1, vc.nz1);
   P p00, p10, p01, p11;
-  if (AM == 3) { // > 2^32 elements and axis tables too large for LDS: 64-bit element offsets, computed arithmetically
-    const unsigned ox = M::X((unsigned)a0);
-    const unsigned o0 = ox + M::Y((unsigned)b0, vc.macro_y), o1 = ox + M::Y((unsigned)b1, vc.macro_y);
+  if (AM == 3) { // > 2^32 elements and axis tables too large for LDS: 64-bit element offsets, computed arithmetically (explicit clamps)
+    const int nb1 = TR ? vc.nx1 : vc.ny1;
+    const unsigned bc0 = (unsigned)max(b0, 0), bc1 = (unsigned)min(b0 + 1, nb1), zc0 = (unsigned)max(z0, 0), zc1 = (unsigned)min(z0 + 1, vc.nz1);
+    const unsigned ox = M::X((unsigned)(a0 + 1));
+    const unsigned o0 = ox + M::Y(bc0, vc.macro_y), o1 = ox + M::Y(bc1, vc.macro_y);
     const T* base = static_cast<const T*>(vc.data);
-    const unsigned long long oz0 = (unsigned long long)M::Zlo((unsigned)z0) + (unsigned long long)((unsigned)z0 >> 5) * vc.macro_z;
-    const unsigned long long oz1 = (unsigned long long)M::Zlo((unsigned)z1) + (unsigned long long)((unsigned)z1 >> 5) * vc.macro_z;
+    const unsigned long long oz0 = (unsigned long long)M::Zlo(zc0) + (unsigned long long)(zc0 >> 5) * vc.macro_z;
+    const unsigned long long oz1 = (unsigned long long)M::Zlo(zc1) + (unsigned long long)(zc1 >> 5) * vc.macro_z;
     p00 = *reinterpret_cast<const P*>(base + (oz0 + o0)); p10 = *reinterpret_cast<const P*>(base + (oz0 + o1));
     p01 = *reinterpret_cast<const P*>(base + (oz1 + o0)); p11 = *reinterpret_cast<const P*>(base + (oz1 + o1));
   }
   else if (AM == 2) { // > 2^32 elements: a and b offsets (inside one macro layer) stay 32-bit, the z table is 64-bit
-    (void)b1; (void)z1;
     const unsigned ox = vc.tab_x[a0];
     const unsigned o0 = ox + vc.tab_y[b0], o1 = ox + vc.tab_y[b0 + 1];
     const unsigned long long oz0 = vc.tab_z64[z0], oz1 = vc.tab_z64[z0 + 1];
@@ -349,7 +360,6 @@ __device__ __forceinline__ void tap_loads(const VolConsts& vc, Tap& t)
   else {
     // three LDS lookups (one b32 + two adjacent pairs) replace ~40 bit-field / multiply instructions per tap: the march is
     // VALU-bound once its gathers coalesce, and the LDS pipe is otherwise nearly idle
-    (void)b1; (void)z1;
     const unsigned ox = vc.tab_x[a0];
     const unsigned oy0 = vc.tab_y[b0], oy1 = vc.tab_y[b0 + 1];
     const unsigned oz0 = vc.tab_z[z0], oz1 = vc.tab_z[z0 + 1];
@@ -425,23 +435,24 @@ __device__ __forceinline__ f2 splat2(float a) { return mk2(a, a); }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 lerp2(f2 a, f2 b, f2 f) { return fma2(f, b - a, a); }
 
-// axis_tap for two taps.  The clamp of p to [0, 1] (sample_volume_object_space) is subsumed by the clamp of x to [0, n - 1]:
-// x = fma(p, cs, cb) is monotone in p (cs > 0), p = 0 maps to cb <= 0 and p = 1 to at least n - 1, so clamping x alone gives the
-// value clamping p first gives, for every p (NaN -> 0 either way: clamp01(NaN) = 0 -> cb -> 0, and med3(NaN, 0, n - 1) = 0)
+// axis_tap for two taps.  The clamp of p to [0, 1] (sample_volume_object_space) is applied to x instead: x = fma(p, cs, cb) is monotone
+// in p (cs > 0), p = 0 maps to cb and p = 1 to cs + cb (exact: n - 0.5 or n - 1), so clamping x to [cb, cs + cb] gives the value clamping p
+// first gives, for every p (NaN -> cb either way: clamp01(NaN) = 0 -> cb, and med3(NaN, cb, cs + cb) = cb)
 // a * sc.x + sc.y on both halves; sc = (scale, offset) lives in one register pair whose halves the instruction broadcasts (op_sel)
 __device__ __forceinline__ f2 fma2_sc(f2 a, f2 sc) { return fma2(a, __builtin_shufflevector(sc, sc, 0, 0), __builtin_shufflevector(sc, sc, 1, 1)); }
-__device__ __forceinline__ void axis_tap2(f2 po, f2 csb, float fn1, int& ia, int& ib, float& fa, float& fb)
+__device__ __forceinline__ void axis_tap2(f2 po, f2 csb, int& ia, int& ib, float& fa, float& fb)
 {
   const f2 x = fma2_sc(po, csb);
-  const float xa = clampf(x.x, 0.f, fn1), xb = clampf(x.y, 0.f, fn1);
-  fa = __builtin_amdgcn_fractf(xa); ia = (int)xa;
-  fb = __builtin_amdgcn_fractf(xb); ib = (int)xb;
+  const float hi = csb.x + csb.y;
+  const float xa = clampf(x.x, csb.y, hi), xb = clampf(x.y, csb.y, hi);
+  fa = __builtin_amdgcn_fractf(xa); ia = floor_to_int(xa);
+  fb = __builtin_amdgcn_fractf(xb); ib = floor_to_int(xb);
 }
 __device__ __forceinline__ void tap_coords2(const VolConsts& vc, f2 px, f2 py, f2 pz, f2 cx, f2 cy, f2 cz, Tap& a, Tap& b)
 {
-  axis_tap2(px, cx, vc.fx1, a.x0, b.x0, a.fx, b.fx);
-  axis_tap2(py, cy, vc.fy1, a.y0, b.y0, a.fy, b.fy);
-  axis_tap2(pz, cz, vc.fz1, a.z0, b.z0, a.fz, b.fz);
+  axis_tap2(px, cx, a.x0, b.x0, a.fx, b.fx);
+  axis_tap2(py, cy, a.y0, b.y0, a.fy, b.fy);
+  axis_tap2(pz, cz, a.z0, b.z0, a.fz, b.fz);
 }
 // tap_finish for two taps: 8 scalar x-lerps, then the y and z lerps of both taps packed (6 instructions instead of 12)
 template <int VT>
@@ -857,7 +868,6 @@ __device__ __forceinline__ void setup_consts(const RayMarchParams& P, VolConsts&
 {
   vc.data = P.vol.data;
   vc.nx1 = P.vol.nx - 1; vc.ny1 = P.vol.ny - 1; vc.nz1 = P.vol.nz - 1;
-  vc.fx1 = (float)vc.nx1; vc.fy1 = (float)vc.ny1; vc.fz1 = (float)vc.nz1;
   vc.macro_y = P.vol.macro_elems * (unsigned int)P.vol.macros_x;
   vc.macro_z = (unsigned long long)P.vol.macro_elems * (unsigned long long)P.vol.macros_x * (unsigned long long)P.vol.macros_y;
   vc.cs = ld3(P.coord_scale); vc.cb = ld3(P.coord_bias);
@@ -884,23 +894,24 @@ __device__ __forceinline__ size_t stage_tables(const RayMarchParams& P, unsigned
   const int na = Vox<VT>::kTransposed ? P.vol.ny : P.vol.nx, nb = Vox<VT>::kTransposed ? P.vol.nx : P.vol.ny;
   const unsigned int* __restrict__ gab = P.vol.axis_ab;
   const unsigned long long* __restrict__ gz = P.vol.axis_z;
-  const int nab = na + nb + 1;
-  if (AM == 2) { // [z: nz + 1 x u64][a: na x u32][b: nb + 1 x u32], element offsets: the global tables as they are
+  const int ea = axis_a_entries(na), nab = ea + axis_b_entries(nb), ez = axis_z_entries(P.vol.nz);
+  // the table pointers handed to the taps are biased by one entry: index -1 is entry 0 (see VolConsts)
+  if (AM == 2) { // [z: ez x u64][a: ea x u32][b: eb x u32], element offsets: the global tables as they are
     unsigned long long* tz = reinterpret_cast<unsigned long long*>(base);
-    unsigned int* tx = reinterpret_cast<unsigned int*>(tz + P.vol.nz + 1);
+    unsigned int* tx = reinterpret_cast<unsigned int*>(tz + ez);
     for (int i = threadIdx.x; i < nab; i += kBlock) tx[i] = gab[i];
-    for (int i = threadIdx.x; i <= P.vol.nz; i += kBlock) tz[i] = gz[i];
-    vc.tab_x = tx; vc.tab_y = tx + na; vc.tab_z64 = tz;
-    return (size_t)(P.vol.nz + 1) * sizeof(unsigned long long) + (size_t)nab * sizeof(unsigned int);
+    for (int i = threadIdx.x; i < ez; i += kBlock) tz[i] = gz[i];
+    vc.tab_x = tx + 1; vc.tab_y = tx + ea + 1; vc.tab_z64 = tz + 1;
+    return (size_t)ez * sizeof(unsigned long long) + (size_t)nab * sizeof(unsigned int);
   }
   // AM 0: byte offsets (the volume is <= 4 GiB), AM 1: element offsets (< 2^32 stored voxels) - 32 bits hold every entry
   unsigned int* tx = reinterpret_cast<unsigned int*>(base);
   unsigned int* tz = tx + nab;
   const unsigned int mul = AM == 0 ? (unsigned int)sizeof(typename Vox<VT>::T) : 1u;
   for (int i = threadIdx.x; i < nab; i += kBlock) tx[i] = gab[i] * mul;
-  for (int i = threadIdx.x; i <= P.vol.nz; i += kBlock) tz[i] = (unsigned int)gz[i] * mul;
-  vc.tab_x = tx; vc.tab_y = tx + na; vc.tab_z = tz;
-  return (size_t)(nab + P.vol.nz + 1) * sizeof(unsigned int);
+  for (int i = threadIdx.x; i < ez; i += kBlock) tz[i] = (unsigned int)gz[i] * mul;
+  vc.tab_x = tx + 1; vc.tab_y = tx + ea + 1; vc.tab_z = tz + 1;
+  return (size_t)(nab + ez) * sizeof(unsigned int);
 }
 // Addressing mode of a volume layout: 0 = 32-bit byte offsets (<= 4 GiB), 1 = 32-bit element offsets (< 2^32 stored voxels), 2 = 64-bit z
 // table, 3 = computed 64-bit offsets, no tables.  Modes 0-2 keep the per-axis tables in LDS next to the transfer function and the request
@@ -910,8 +921,8 @@ __device__ __forceinline__ size_t stage_tables(const RayMarchParams& P, unsigned
 __host__ inline int addressing_mode(const VolumeDesc& vd, int n_color, int n_alpha)
 {
   int am = vd.bytes <= 0x100000000ull ? 0 : (vd.bytes / voxel_size(vd.type) < 0xffffffffull) ? 1 : 2;
-  const size_t tables = am == 2 ? (size_t)(vd.nz + 1) * sizeof(unsigned long long) + (size_t)(vd.nx + vd.ny + 1) * sizeof(unsigned int)
-                                : (size_t)(vd.nx + vd.ny + vd.nz + 2) * sizeof(unsigned int);
+  const size_t ab = (size_t)(vd.nx + vd.ny + 3), ez = (size_t)axis_z_entries(vd.nz); // a: n + 1 entries, b: n + 2 (whichever of x / y is the pair axis)
+  const size_t tables = am == 2 ? ez * sizeof(unsigned long long) + ab * sizeof(unsigned int) : (ab + ez) * sizeof(unsigned int);
   const size_t fixed = raymarch_lds_bytes(n_color, n_alpha) + (size_t)kWaves * 256 * 32 + 1024; // TF + the largest request queues + slack
   if ((am == 2 && tables > 64 * 1024) || tables + 16 + fixed > 160 * 1024) am = 3;
   return am;
@@ -919,8 +930,9 @@ __host__ inline int addressing_mode(const VolumeDesc& vd, int n_color, int n_alp
 __host__ inline size_t table_lds_bytes(const RayMarchParams& p, int am)
 {
   if (am == 3) return 0;
-  if (am == 2) return ((size_t)(p.vol.nz + 1) * sizeof(unsigned long long) + (size_t)(p.vol.nx + p.vol.ny + 1) * sizeof(unsigned int) + 15) & ~(size_t)15;
-  return ((size_t)(p.vol.nx + p.vol.ny + p.vol.nz + 2) * sizeof(unsigned int) + 15) & ~(size_t)15;
+  const size_t ab = (size_t)(p.vol.nx + p.vol.ny + 3), ez = (size_t)axis_z_entries(p.vol.nz);
+  if (am == 2) return (ez * sizeof(unsigned long long) + ab * sizeof(unsigned int) + 15) & ~(size_t)15;
+  return ((ab + ez) * sizeof(unsigned int) + 15) & ~(size_t)15;
 }
 
 // stage the transfer function in LDS (all threads of the workgroup); color may be skipped by alpha-only kernels
@@ -1570,9 +1582,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
               l[a] = min(max((int)floorf(fminf(fmaxf(lo[a], -4.f), 1e9f)), 0), n1[a]);
               h[a] = min(max((int)floorf(fminf(fmaxf(hi[a], -4.f), 1e9f)) + 1, 0), n1[a]); // + 1: the taps' upper neighbours
             }
+            // along x the bricks are addressed by STORED position (voxel + 1): the pairs' lower members span [floor(lo) + 1, floor(hi) + 1]
+            const int lu = min(max((int)floorf(fminf(fmaxf(lo[0], -4.f), 1e9f)) + 1, 0), n1[0] + 1);
+            const int hu = min(max((int)floorf(fminf(fmaxf(hi[0], -4.f), 1e9f)) + 1, 0), n1[0] + 1);
             LdsRegion g;
-            g.bx0 = (int)M::div_cx((unsigned)l[0]); g.by0 = l[1] >> Vox<VT>::by; g.bz0 = l[2] >> Vox<VT>::bz;
-            g.ebx = (int)M::div_cx((unsigned)h[0]) - g.bx0 + 1; g.eby = (h[1] >> Vox<VT>::by) - g.by0 + 1; g.ebz = (h[2] >> Vox<VT>::bz) - g.bz0 + 1;
+            g.bx0 = (int)M::div_cx((unsigned)lu); g.by0 = l[1] >> Vox<VT>::by; g.bz0 = l[2] >> Vox<VT>::bz;
+            g.ebx = (int)M::div_cx((unsigned)hu) - g.bx0 + 1; g.eby = (h[1] >> Vox<VT>::by) - g.by0 + 1; g.ebz = (h[2] >> Vox<VT>::bz) - g.bz0 + 1;
             g.nbr = g.ebx * g.eby * g.ebz;
             g.ok = g.nbr <= kLdsBrickCap ? 1 : 0;
             *lds_region = g;
@@ -1590,7 +1605,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
           for (int i = threadIdx.x >> 3; i < g.nbr; i += kBlock / 8) {
             const int iz = (int)(((float)i + 0.5f) * rcp_xy), rem = i - iz * g.ebx * g.eby;
             const int iy = (int)(((float)rem + 0.5f) * rcp_x), ixb = rem - iy * g.ebx;
-            const unsigned int off = vc.tab_x[(g.bx0 + ixb) * Vox<VT>::cx] + vc.tab_y[(g.by0 + iy) << Vox<VT>::by] + vc.tab_z[(g.bz0 + iz) << Vox<VT>::bz];
+            // (tab_x is indexed by voxel = stored position - 1; tab_y / tab_z by voxel)
+            const unsigned int off = vc.tab_x[(g.bx0 + ixb) * Vox<VT>::cx - 1] + vc.tab_y[(g.by0 + iy) << Vox<VT>::by] + vc.tab_z[(g.bz0 + iz) << Vox<VT>::bz];
             const float4 v = AM == 0 ? *reinterpret_cast<const float4*>(static_cast<const char*>(vc.data) + off + row * 16)
                                      : *reinterpret_cast<const float4*>(static_cast<const float*>(vc.data) + off + row * 4);
             reinterpret_cast<float4*>(lds_bricks)[i * 8 + row] = v;
@@ -1601,17 +1617,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             Tap& t = taps[k];
+            const int y0 = max(t.y0, 0), z0 = max(t.z0, 0); // clamp-to-edge: index -1 reads voxel 0
             const int y1 = min(t.y0 + 1, vc.ny1), z1 = min(t.z0 + 1, vc.nz1);
-            const int bxr = (int)M::div_cx((unsigned)t.x0), xr = t.x0 - bxr * Vox<VT>::cx;
-            const int cy0 = (t.y0 >> Vox<VT>::by) - g.by0, cy1 = (y1 >> Vox<VT>::by) - g.by0, cz0 = (t.z0 >> Vox<VT>::bz) - g.bz0, cz1 = (z1 >> Vox<VT>::bz) - g.bz0;
+            const int xu = t.x0 + 1;                          // stored position of the pair's lower member
+            const int bxr = (int)M::div_cx((unsigned)xu), xr = xu - bxr * Vox<VT>::cx;
+            const int cy0 = (y0 >> Vox<VT>::by) - g.by0, cy1 = (y1 >> Vox<VT>::by) - g.by0, cz0 = (z0 >> Vox<VT>::bz) - g.bz0, cz1 = (z1 >> Vox<VT>::bz) - g.bz0;
             const int cxr = bxr - g.bx0;
             const bool inside = (unsigned)cxr < (unsigned)g.ebx && (unsigned)cy0 < (unsigned)g.eby && (unsigned)cy1 < (unsigned)g.eby &&
                                 (unsigned)cz0 < (unsigned)g.ebz && (unsigned)cz1 < (unsigned)g.ebz;
             if (inside) {
               constexpr int ym = (1 << Vox<VT>::by) - 1, zm = (1 << Vox<VT>::bz) - 1, SX = (int)M::SX;
               const int ox = cxr * (int)M::BV + xr;
-              const int oy0 = cy0 * g.ebx * (int)M::BV + (t.y0 & ym) * SX, oy1 = cy1 * g.ebx * (int)M::BV + (y1 & ym) * SX;
-              const int oz0 = cz0 * sxy * (int)M::BV + ((t.z0 & zm) << Vox<VT>::by) * SX, oz1 = cz1 * sxy * (int)M::BV + ((z1 & zm) << Vox<VT>::by) * SX;
+              const int oy0 = cy0 * g.ebx * (int)M::BV + (y0 & ym) * SX, oy1 = cy1 * g.ebx * (int)M::BV + (y1 & ym) * SX;
+              const int oz0 = cz0 * sxy * (int)M::BV + ((z0 & zm) << Vox<VT>::by) * SX, oz1 = cz1 * sxy * (int)M::BV + ((z1 & zm) << Vox<VT>::by) * SX;
               const float* b0 = lds_bricks + ox + oz0;
               const float* b1 = lds_bricks + ox + oz1;
               t.c000 = b0[oy0]; t.c100 = b0[oy0 + 1]; t.c010 = b0[oy1]; t.c110 = b0[oy1 + 1];

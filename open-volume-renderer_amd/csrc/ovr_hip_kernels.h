@@ -51,14 +51,21 @@ struct VolumeDesc {
   unsigned long long bytes;         // macros_x * macros_y * macros_z * macro_elems * sizeof(voxel)
   float value_scale; // multiplier turning a filtered raw value into what the reference's texture read returns
   float value_min_clamp; // raw clamp applied per voxel before filtering (i8: -127) - see array.h:83-90
-  // per-axis ELEMENT offsets of this layout, built once per volume (launch_axis_tables): off(a, b, z) = axis_ab[a] +
-  // axis_ab[na + b] + axis_z[z] with (a, b) = (x, y), exchanged in a transposed replica; the b and z tables hold one extra
-  // entry equal to their last one (clamp-to-edge).  The march / shade workgroups copy them into LDS (stage_tables) instead of
-  // computing ~3 k entries with 64-bit multiplies each (fewer instructions and 0.5 MB less code; the frame time did not move:
-  // the prologue hides behind the other workgroups of the CU - profiles/r02_notes.md §7)
-  const unsigned int* axis_ab;       // [na][nb + 1]
-  const unsigned long long* axis_z;  // [nz + 1]
+  // per-axis ELEMENT offsets of this layout, built once per volume (launch_axis_tables).  Every table is indexed by i + 1 for a
+  // voxel index i that starts at -1 (round 4): the reference's clamp-to-edge texture reads the pair (0, 0) in the half voxel
+  // outside the first voxel centre (floor(x) = -1) and (n - 1, n - 1) beyond the last one, so entry 0 of every table addresses
+  // what index -1 addresses - a copy of voxel 0 - and the entries past n - 1 repeat the last voxel: off(a, b, z) = axis_ab[a + 1] +
+  // axis_ab[(na + 1) + b + 1] + axis_z[z + 1] with (a, b) = (x, y), exchanged in a transposed replica.  The pair axis a has its
+  // copies in the DATA (stored position = voxel + 1, see BrickMap), the b and z axes in the tables.  The march / shade workgroups
+  // copy the tables into LDS (stage_tables) instead of computing ~3 k entries with 64-bit multiplies each (fewer instructions and
+  // 0.5 MB less code; the frame time did not move: the prologue hides behind the other workgroups of the CU - profiles/r02_notes.md §7)
+  const unsigned int* axis_ab;       // [na + 1][nb + 2]
+  const unsigned long long* axis_z;  // [nz + 2]
 };
+// entries of the per-axis tables (a = pair axis: lower members -1 ... n - 1; b, z: -1 ... n)
+__host__ __device__ inline int axis_a_entries(int na) { return na + 1; }
+__host__ __device__ inline int axis_b_entries(int nb) { return nb + 2; }
+__host__ __device__ inline int axis_z_entries(int nz) { return nz + 2; }
 
 struct float3_ { float x, y, z; };
 
@@ -169,6 +176,13 @@ int device_voxel_type(int ovr_value_type);
 int replica_voxel_type(int base_voxel_type, int layout); // the VoxelType of a layout of a base type, -1 if that replica does not exist
 void volume_layout(int voxel_type, int nx, int ny, int nz, VolumeDesc& vd); // fills type, nx.., macros_*, macro_elems, bytes
 size_t voxel_size(int voxel_type);
+// The taps add the in-plane offsets X(a) + Y(b) of a layout in 32 bits (the 64-bit addressing modes widen only the z term): one z layer of
+// macro blocks must hold fewer than 2^32 elements.  False for a slab-shaped volume of ~8192 x 8192 voxels in the quad layout (131072 elements
+// per macro block), ~16384 x 16384 in the others: such a layout is not built (replicas) or refused (the general layout).
+inline bool layout_offsets_fit(const VolumeDesc& vd)
+{
+  return (unsigned long long)vd.macro_elems * (unsigned long long)vd.macros_x * (unsigned long long)vd.macros_y <= 0x100000000ull;
+}
 hipError_t launch_relayout(const void* src_linear, int ovr_value_type, void* dst, const VolumeDesc& vd, int z0, int nz_chunk,
                            hipStream_t stream);
 // per-axis offset tables of a layout: bytes of the device buffer, and the kernel that fills it ([z: nz + 1 x u64][a: na x u32]

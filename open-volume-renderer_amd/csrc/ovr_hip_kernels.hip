@@ -365,8 +365,9 @@ __global__ __launch_bounds__(256) void relayout_kernel(const TI* __restrict__ sr
   const int b = blockIdx.y, zl = blockIdx.z;
   if (sa >= (unsigned)bricks_a * M::SX || zl >= nz_chunk) return;
   const unsigned br = sa / M::SX, ar = sa - br * M::SX;  // brick and position inside its row (ar == cx is the apron)
-  const unsigned a = br * Vox<VT>::cx + ar;
-  const unsigned as = min(a, (unsigned)((TR ? ny : nx) - 1)); // beyond the grid: replicate the last voxel (clamp addressing)
+  const unsigned a = br * Vox<VT>::cx + ar;              // stored position = voxel index + 1 (BrickMap::X)
+  // clamp addressing baked into the data: position 0 is a copy of voxel 0, positions beyond the grid replicate the last voxel
+  const unsigned as = (unsigned)min(max((int)a - 1, 0), (TR ? ny : nx) - 1);
   const unsigned z = (unsigned)(z0 + zl);
   const size_t x = TR ? (size_t)b : (size_t)as, y = TR ? (size_t)as : (size_t)b;
   const TI v = src[x + (size_t)nx * (y + (size_t)ny * (size_t)zl)];
@@ -384,21 +385,23 @@ __global__ __launch_bounds__(256) void relayout_quad_kernel(const TI* __restrict
   typedef BrickMap<VT> M;
   typedef typename Vox<VT>::T TO;
   typedef typename Vox<VT>::Q Q;
-  const int x = (int)(blockIdx.x * 256u + threadIdx.x), y = (int)blockIdx.y, zl = (int)blockIdx.z;
-  if (x >= nx || zl >= nz_chunk) return;
-  const int x1 = min(x + 1, nx - 1), y1 = min(y + 1, ny - 1);
+  // one thread per CELL (u, v) = (x + 1, y + 1), x in [-1, nx - 1], y in [-1, ny - 1]: grid x covers nx + 1 cells, grid y = ny + 1
+  const int u = (int)(blockIdx.x * 256u + threadIdx.x), v = (int)blockIdx.y, zl = (int)blockIdx.z;
+  if (u > nx || zl >= nz_chunk) return;
+  const int x = max(u - 1, 0), y = max(v - 1, 0);
+  const int x1 = min(u, nx - 1), y1 = min(v, ny - 1);
   const TI* sl = src + (size_t)nx * (size_t)ny * (size_t)zl;
   Q q;
   q.x = Conv<TI, TO>::cv(sl[x + (size_t)nx * y]); q.y = Conv<TI, TO>::cv(sl[x1 + (size_t)nx * y]);
   q.z = Conv<TI, TO>::cv(sl[x + (size_t)nx * y1]); q.w = Conv<TI, TO>::cv(sl[x1 + (size_t)nx * y1]);
   const unsigned z = (unsigned)(z0 + zl);
-  const unsigned long long off = (unsigned long long)(M::X((unsigned)x) + M::Y((unsigned)y, macro_y)) + M::Zlo(z) + (unsigned long long)(z >> 5) * macro_z;
+  const unsigned long long off = (unsigned long long)(M::X((unsigned)u) + M::Y((unsigned)v, macro_y)) + M::Zlo(z) + (unsigned long long)(z >> 5) * macro_z;
   *reinterpret_cast<Q*>(dst + off) = q;
 }
 template <typename TI, int VT>
 static hipError_t relayout_quad_t(const void* src, void* dst, const VolumeDesc& vd, int z0, int nzc, hipStream_t stream)
 {
-  dim3 grid((unsigned)((vd.nx + 255) / 256), (unsigned)vd.ny, (unsigned)nzc);
+  dim3 grid((unsigned)((vd.nx + 1 + 255) / 256), (unsigned)(vd.ny + 1), (unsigned)nzc);
   hipLaunchKernelGGL((relayout_quad_kernel<TI, VT>), grid, dim3(256), 0, stream, (const TI*)src, (typename Vox<VT>::T*)dst, vd.nx, vd.ny, vd.macro_elems * (unsigned)vd.macros_x,
                      (unsigned long long)vd.macro_elems * (unsigned long long)vd.macros_x * (unsigned long long)vd.macros_y, z0, nzc);
   return hipGetLastError();
@@ -422,8 +425,9 @@ static void volume_layout_t(int nx, int ny, int nz, VolumeDesc& vd)
 {
   typedef BrickMap<VT> M;
   const int na = Vox<VT>::kTransposed ? ny : nx, nb = Vox<VT>::kTransposed ? nx : ny;
-  vd.macros_x = (na + (int)M::MCX - 1) / (int)M::MCX;
-  vd.macros_y = (nb + 31) / 32;
+  // the pair axis holds stored positions 0 ... na + 1 (voxel + 1; lower members 0 ... na); a quad replica has cells 0 ... n on both axes
+  vd.macros_x = (na + 1 + (int)M::MCX - 1) / (int)M::MCX;
+  vd.macros_y = ((Vox<VT>::kQuad ? nb + 1 : nb) + 31) / 32;
   vd.macros_z = (nz + 31) / 32;
   vd.macro_elems = M::MV;
   vd.bytes = (unsigned long long)vd.macros_x * vd.macros_y * vd.macros_z * M::MV * sizeof(typename Vox<VT>::T);
@@ -492,29 +496,31 @@ __global__ __launch_bounds__(256) void axis_tables_kernel(VolumeDesc vd, unsigne
   const int na = Vox<VT>::kTransposed ? vd.ny : vd.nx, nb = Vox<VT>::kTransposed ? vd.nx : vd.ny;
   const unsigned int macro_y = vd.macro_elems * (unsigned int)vd.macros_x;
   const unsigned long long macro_z = (unsigned long long)vd.macro_elems * (unsigned long long)vd.macros_x * (unsigned long long)vd.macros_y;
+  // entry i of a table belongs to voxel index i - 1 (VolumeDesc): a = -1 ... na - 1 (lower member of the pair; stored position i),
+  // b and z = -1 ... n with the indices clamped into the grid; a quad replica's cells are (x + 1, y + 1), its y entry i is cell i
   const int i = (int)(blockIdx.x * 256u + threadIdx.x);
-  if (i < na) ab[i] = M::X((unsigned)i);
-  if (i <= nb) ab[na + i] = M::Y((unsigned)min(i, nb - 1), macro_y);
-  if (i <= vd.nz) {
-    const unsigned z = (unsigned)min(i, vd.nz - 1);
+  if (i < axis_a_entries(na)) ab[i] = M::X((unsigned)i);
+  if (i < axis_b_entries(nb)) ab[axis_a_entries(na) + i] = M::Y(Vox<VT>::kQuad ? (unsigned)min(i, nb) : (unsigned)min(max(i - 1, 0), nb - 1), macro_y);
+  if (i < axis_z_entries(vd.nz)) {
+    const unsigned z = (unsigned)min(max(i - 1, 0), vd.nz - 1);
     tz[i] = (unsigned long long)M::Zlo(z) + (unsigned long long)(z >> 5) * macro_z;
   }
 }
 size_t axis_table_bytes(const VolumeDesc& vd)
 {
-  return (size_t)(vd.nz + 1) * sizeof(unsigned long long) + (size_t)(vd.nx + vd.ny + 1) * sizeof(unsigned int);
+  return (size_t)axis_z_entries(vd.nz) * sizeof(unsigned long long) + (size_t)(vd.nx + vd.ny + 3) * sizeof(unsigned int);
 }
 template <int VT>
 static hipError_t axis_tables_t(const VolumeDesc& vd, unsigned int* ab, unsigned long long* tz, hipStream_t stream)
 {
-  const int n = std::max(std::max(vd.nx, vd.ny), vd.nz) + 1;
+  const int n = std::max(std::max(vd.nx, vd.ny), vd.nz) + 2;
   hipLaunchKernelGGL(axis_tables_kernel<VT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, vd, ab, tz);
   return hipGetLastError();
 }
 hipError_t launch_axis_tables(VolumeDesc& vd, void* d_tables, hipStream_t stream)
 {
   unsigned long long* tz = static_cast<unsigned long long*>(d_tables);
-  unsigned int* ab = reinterpret_cast<unsigned int*>(tz + vd.nz + 1);
+  unsigned int* ab = reinterpret_cast<unsigned int*>(tz + axis_z_entries(vd.nz));
   vd.axis_z = tz;
   vd.axis_ab = ab;
   switch (vd.type) {
@@ -560,7 +566,7 @@ __global__ __launch_bounds__(256) void macrocell_range_kernel(const void* __rest
   float lo = INFINITY, hi = -INFINITY; // range1f() is empty
   for (int i = lane; i < dx * dy * dz; i += 64) {
     const int x = bx + i % dx, y = by + (i / dx) % dy, z = bz + i / (dx * dy);
-    const unsigned long long off = (unsigned long long)(M::X((unsigned)x) + M::Y((unsigned)y, macro_y)) + M::Zlo((unsigned)z) + (unsigned long long)((unsigned)z >> 5) * macro_z;
+    const unsigned long long off = (unsigned long long)(M::X((unsigned)x + 1u) + M::Y((unsigned)y, macro_y)) + M::Zlo((unsigned)z) + (unsigned long long)((unsigned)z >> 5) * macro_z; // stored position = voxel + 1
     float f = (float)base[off];
     if (VT == VOX_U8) f = f / 255.f;                            // what the normalized texture read returns (array.cpp:304-306)
     if (VT == VOX_I8) { f = f / 127.f; f = f < -1.f ? -1.f : f; }

@@ -150,7 +150,10 @@ def test_march_kernels_keep_their_register_budget(tmp_path):
         # no scratch - but for the pinned skipping variants, where 3 spilled dwords in a cold path were measured 27 % faster than
         # giving up the third wave (transposed thin layout, C3 side view: march 0.345 vs 0.439 ms)
         pinned = re.search(r"raymarch_kernelILi\d+ELi\d+ELi[01]ELb1ELb1E", n) is not None
-        assert k[".private_segment_fixed_size"] <= (16 if pinned else 0), (n, k)
+        # (round 4) the computed-offset mode (AM 3: a dimension of tens of thousands of voxels, no LDS tables) clamps its indices explicitly
+        # since the layouts carry the clamp-to-edge copies; its in-place skipping march keeps 5 dwords in scratch - a cold path of a cold mode
+        am3 = re.search(r"raymarch_kernelILi\d+ELi\d+ELi3ELb0ELb1E", n) is not None
+        assert k[".private_segment_fixed_size"] <= (16 if pinned else 32 if am3 else 0), (n, k)
         # raymarch_kernel<VT, SHADE, AM, POOLED = true, SKIP, LDSB>: ...ILi<vt>ELi<shade>ELi<am>ELb1E...; the 64-bit addressing modes
         # (AM 2, 3) may take more (measured: no difference on C4, the only configuration that uses them)
         # ...ELb<pooled>ELb<skip>ELb<ldsb>ELb<deep>E: the deep variant (image shards) runs 6 instructions per round at 2 waves on purpose
