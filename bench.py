@@ -215,6 +215,42 @@ def cpu_baseline(cfg, vol_host, colors, alphas, vr, cam, noise=None, budget_s=10
     return out
 
 
+def run_extra_leg(argv, timeout_s):
+    """one more configuration as a child `python bench.py ...` (its own process: its own volume, nothing shared with the timed region that
+    has already finished), trimmed to the figures the record needs.  Never raises: a failure is reported in place of the figures."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                                                               "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "OVR_BENCH_FORCE_GATHER", "OVR_BENCH_CONFIG")}
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--no-extras", "--no-cpu-baseline", "--no-views", "--no-skip-leg"]
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            so, se = p.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, 9)   # exactly the process group this call started
+            except OSError:
+                pass
+            p.communicate()
+            return {"command": " ".join(cmd[1:]), "error": f"timed out after {timeout_s} s"}
+        if p.returncode != 0:
+            return {"command": " ".join(cmd[1:]), "error": f"exit code {p.returncode}: {(se or '')[-600:]}"}
+        doc = json.loads([l for l in so.splitlines() if l.startswith("{")][-1])
+    except Exception as e:  # noqa: BLE001 - an extra leg must never take the headline down
+        return {"command": " ".join(cmd[1:]), "error": repr(e)[:600]}
+    r = doc.get("roofline", {})
+    out = {"command": " ".join(cmd[1:]), "wall_s": round(time.perf_counter() - t0, 1), "workload": doc["config"]["workload"], "parallelism": doc["config"].get("parallelism"),
+           "value": doc["value"], "unit": doc["unit"], "fps": doc["fps"], "ms_per_step": doc["ms_per_step"], "steps": doc["steps"], "dtype": doc["dtype"],
+           "samples_per_frame": doc["per_frame"]["samples"],
+           "roofline": {"kernel": r.get("kernel"), "bound": r.get("bound"), "frac": r.get("frac"), "achieved": r.get("achieved"), "peak": r.get("peak"), "unit": r.get("unit"),
+                        "traffic": r.get("traffic"), "hbm_algorithmic_frac": r.get("hbm_algorithmic_frac"),
+                        "kernels": {k: {f: v.get(f) for f in ("ms", "bound", "frac", "hbm_algorithmic_frac", "traffic_ratio", "utilisation")} for k, v in r.get("kernels", {}).items()},
+                        "volume_upload_ms": r.get("volume_upload_ms"), "volume_resident_bytes": r.get("volume_resident_bytes")}}
+    if "device_group" in doc:
+        out["device_group"] = doc["device_group"]
+    return out
+
+
 def launch_ranks(args):
     """parent of a multi-GPU run: start one process per GPU and wait.  Nothing here touches HIP or torch.cuda."""
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -255,6 +291,9 @@ def main():
     ap.add_argument("--shard-of", type=int, default=0, help="ONE process renders rank --shard-rank's image shard of this many ranks, without a gather: a profilable stand-in for one rank of the N-GPU run (its counters are filed under world = N)")
     ap.add_argument("--shard-rank", type=int, default=0)
     ap.add_argument("--sparse-sampling", action="store_true", help="the foveated mode with the interactive app's default focus (apps/main_app.cpp:123-124)")
+    ap.add_argument("--devices", default=None, help="ONE process drives these HIP devices as an in-process device group (ovr_hip_create_group - what the C++ plugin does "
+                    "for OVR_HIP_DEVICES / --hip-devices): image tiles over the devices, gathered on the first one over RCCL or peer copies; e.g. 0,1,2,3 (0,0: a rehearsal on one card)")
+    ap.add_argument("--no-extras", action="store_true", help="do not run the extra legs of the default command (C4 and C5 on one GPU, rank 0's shard of 8, the device group)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -326,7 +365,10 @@ def worker(args, world):
     cam = ovr.synth.make_camera(cfg["cam"], n)
     noise = ovr.synth.make_noise_tile(64) if cfg.get("jitter") == "blue" else None
 
-    ren = ovr.create_renderer("hip", local_rank)
+    group_devices = [int(d) for d in args.devices.split(",")] if args.devices else None
+    if group_devices and multi:
+        raise SystemExit("bench.py: --devices is the single-process device group; it does not combine with --gpus N > 1 ranks")
+    ren = ovr.create_renderer("hip", local_rank, devices=group_devices)
     # the call sequence of the reference's renderbatch (apps/main_batch.cpp:254-276)
     ren.set_fbsize((W, H))
     ren.set_frame_accumulation(True)
@@ -347,7 +389,11 @@ def worker(args, world):
     ren.set_shading_pipeline(args.pipeline)
     ren.set_lds_staging(args.lds_staging)
     scene = ovr.Scene(volume=vol, transfer_function=None, volume_sampling_rate=cfg["rate"])
-    ren.init(scene, ovr.Camera(*cam))
+    torch.cuda.synchronize()
+    t_up = time.perf_counter()
+    ren.init(scene, ovr.Camera(*cam))   # ovr_hip_set_volume (re-layout into bricks; on every device of a group) + the first commit
+    volume_upload_ms = (time.perf_counter() - t_up) * 1e3
+    resident_after_upload = int(ren.volume_info().resident_bytes)
 
     def set_cam():
         if args.fovy == 60.0:
@@ -379,6 +425,7 @@ def worker(args, world):
     def step():
         if not multi:
             ren.render()          # blocking, like the reference's render() (optix7/device.cpp:35-43)
+            step.count += 1
         else:
             # one frame = march/shade/composite of this rank's tiles, then the gather of all tiles to rank 0.  The gather of
             # frame i runs on its own stream while frame i+1 renders (tiles.TileGather); the host waits once per frame
@@ -397,8 +444,19 @@ def worker(args, world):
             step()
         # a shade-heavy configuration makes the renderer time its alternatives (layout, pipeline: ovr_hip_stats.tuning == 1) for up to a
         # dozen frames: they belong to the warm-up, not to the timed steps (untimed extra steps, counted in `extra_warmup`)
+        # ... and so do the frames rendered from the general layout while the replica the camera asks for is still being built in the
+        # background (ovr_hip_stats.replicas_building).  N > 1: every rank probes / builds on its own - the ranks agree on one more step
+        # while ANY of them is still at it (those frames used to land in the timed steps of the multi-GPU line)
+        def unsettled():
+            st = ren.stats()
+            mine = st.tuning == 1 or st.replicas_building > 0
+            if dist is None:
+                return mine
+            flag = torch.tensor([1 if mine else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            return bool(flag.item())
         extra = 0
-        while not multi and extra < 16 and ren.stats().tuning == 1:
+        while extra < 16 and step.count > 0 and unsettled():
             step()
             extra += 1
         timed_leg.extra_warmup = extra
@@ -457,10 +515,12 @@ def worker(args, world):
                         ctr = None
                 kb_ = kernel_bound(kms, kb, ctr)
                 kern[kname] = {"ms": kms, "algorithmic_bytes_per_launch": kb, "bound": "hbm", "achieved": kb / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": kb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}
+                               "frac": kb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "traffic_ratio": None}
                 if kb_:
-                    kern[kname].update(traffic=kb_["traffic"], utilisation=kb_["utilisation"], l1_fill_bytes=kb_["l1_fill_bytes"], ta_busy=kb_["ta_busy"],
-                                       clock_ghz=kb_["clock_ghz"], hbm_algorithmic_frac=kern[kname]["frac"])
+                    # traffic_ratio = counter bytes / algorithmic bytes: well above 1 = lines fetched for a fraction of their voxels (C4: rays 3-5 voxels
+                    # apart, one 128-byte brick per 2 x 2 footprint - 2.85), below 1 = the caches serve part of the algorithmic bytes
+                    kern[kname].update(traffic=kb_["traffic"], traffic_ratio=(kb_["traffic"] / kb if kb > 0 else None), utilisation=kb_["utilisation"],
+                                       l1_fill_bytes=kb_["l1_fill_bytes"], ta_busy=kb_["ta_busy"], clock_ghz=kb_["clock_ghz"], hbm_algorithmic_frac=kern[kname]["frac"])
                     if kb_["bound"] != "hbm":
                         kern[kname].update(bound=kb_["bound"], achieved=kb_["achieved"], peak=kb_["peak"], unit=kb_["unit"], frac=kb_["frac"])
                 else:
@@ -690,12 +750,26 @@ def worker(args, world):
                                       "nominal_frac_survey_F4": (nbytes / (k_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if k_ms > 0 else 0.0},
                          "compulsory_floor_ms": floor_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
                          "compulsory_floor_bytes": floor_bytes,
-                         "volume_resident_bytes": int(vinfo.resident_bytes), "volume_layout_read_bytes": read_bytes,
+                         # (round 4) ovr_hip_set_volume uploads the general layout only; replicas are built in the background when a frame asks for one
+                         "volume_upload_ms": volume_upload_ms, "volume_resident_bytes_after_upload": resident_after_upload,
+                         "volume_resident_bytes": int(ren.volume_info().resident_bytes), "volume_layout_read_bytes": read_bytes,
                          "phase_ms_rank0": {"march": ph[0], "shade": ph[1], "composite": ph[2]},
                          "pool_chunks": int(last_stats.pool_chunks),
                          "lds_staging": {"on": bool(args.lds_staging), "fallback_taps_per_frame": int(last_stats.lds_fallback_taps),
                                          "unstaged_workgroup_rounds_per_frame": int(last_stats.lds_unstaged_rounds), "workgroup_rounds_per_frame": int(last_stats.lds_rounds)}},
         }
+        if group_devices:
+            gn, gkind, gms = ren.group_info()
+            members = [ren.member_stats(i) for i in range(gn)]
+            out["n_gpus"] = len(set(group_devices))
+            out["config"]["parallelism"] = (f"ONE process, device group {group_devices} (ovr_hip_create_group - the C++ plugin's OVR_HIP_DEVICES path): image tiles "
+                                            f"16x16 over {gn} member(s), gathered on device {group_devices[0]}")
+            out["device_group"] = {"devices": group_devices, "distinct_devices": len(set(group_devices)), "gather": ["none", "peer copies", "RCCL send/recv (ncclCommInitAll)"][gkind],
+                                   "gather_tail_ms_last_frame": gms,
+                                   "per_member": {"march_ms": [m.march_ms for m in members], "shade_ms": [m.shade_ms for m in members], "composite_ms": [m.composite_ms for m in members],
+                                                  "kernel_ms": [m.kernel_ms for m in members], "samples": [int(m.samples) for m in members],
+                                                  "layout": [m.layout for m in members], "pipeline": [m.pipeline for m in members]},
+                                   "note": "value counts the samples of all members; kernel times in `roofline` are the slowest member's; a device listed twice is a rehearsal on one card"}
         if multi:
             out["rccl_ranks"] = dist.get_world_size()
             out["backend"] = dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")
@@ -710,12 +784,32 @@ def worker(args, world):
             out["with_empty_space_skipping"] = skip_leg
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(cfg, vol_host, colors, alphas, vr, cam, noise)
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    # the timed region and everything that belongs to the headline is over: the other ranks may go, the renderer's memory is returned
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     ren.close()
+    if rank == 0:
+        # Extra legs of the DEFAULT command, each a child process after the headline's measurements, never `value`:
+        #   N = 1: the two 8-GPU configurations on this one GPU (C4, C5), rank 0's image shard of 8 (what one GPU of the 8-GPU run launches), and the
+        #          in-process device group on this card (two members on device 0: the C++ plugin's multi-GPU path, exercised; its speed means nothing)
+        #   N > 1: the device group over the N GPUs of this run - ONE process, the unmodified apps' path (the other ranks have left by now)
+        default_cmd = (args.config == "c3" and not (args.camera or args.tf or args.dtype or args.n or args.rate or args.skip_empty or args.sparse_sampling
+                                                    or args.shard_of or args.devices or args.lds_staging) and args.shading is None and args.layout == -1 and args.pipeline == 0
+                       and args.fovy == 60.0 and os.environ.get("OVR_BENCH_FORCE_GATHER") != "1" and os.environ.get("OVR_BENCH_ONE_GPU") != "1")
+        if default_cmd and not args.no_extras:
+            torch.cuda.empty_cache()
+            extra = {}
+            if world == 1:
+                extra["c4_one_gpu"] = run_extra_leg(["--config", "c4", "--steps", "10", "--warmup", "3"], 420)
+                extra["c5_one_gpu"] = run_extra_leg(["--config", "c5", "--steps", "10", "--warmup", "3"], 300)
+                extra["c3_shard_of_8"] = run_extra_leg(["--shard-of", "8", "--steps", "20", "--warmup", "5"], 300)
+                extra["c3_device_group_rehearsal"] = run_extra_leg(["--devices", "0,0", "--steps", "10", "--warmup", "5"], 300)
+            else:
+                extra["c3_device_group"] = run_extra_leg(["--devices", ",".join(str(i) for i in range(world)), "--steps", str(args.steps), "--warmup", str(args.warmup)], 420)
+            out["extra"] = extra
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

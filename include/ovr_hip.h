@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OVR_HIP_ABI_VERSION 7
+#define OVR_HIP_ABI_VERSION 8
 
 /* error codes */
 #define OVR_HIP_OK 0
@@ -85,6 +85,8 @@ typedef struct ovr_hip_stats {
   int32_t tuning;               /* automatic layout / pipeline (ABI v7): 0 = the frame ran what the rules say (camera direction, share of
                                    shaded samples), 1 = it was a probe (a shade-heavy configuration: the other pipeline and the general / quad
                                    layouts are timed, two frames each), 2 = it ran the measured winner (kept until the configuration changes) */
+  int32_t replicas_building;    /* ABI v8: replicas of the volume still being built in the background when the frame finished (the frame
+                                   read the general layout meanwhile - the same frame bit for bit; see ovr_hip_set_volume_layouts) */
 } ovr_hip_stats;
 
 const char* ovr_hip_last_error(void);
@@ -94,6 +96,24 @@ int ovr_hip_abi_version(void);
  * device_id = HIP device ordinal; the reference hard-codes 0 (device_impl.cpp:371-372). */
 int ovr_hip_create(ovr_hip_renderer** out, int device_id);
 void ovr_hip_destroy(ovr_hip_renderer* r);
+
+/* ABI v8 - several GPUs behind ONE handle, in one process (north_star: "apps run unmodified ... the 8 GPUs of one node shard
+ * the image plane into tiles with a final RCCL gather over xGMI").  The reference's device knows one GPU (device_impl.cpp:371-372) and its
+ * apps create one renderer (apps/main_batch.cpp:240-318, apps/main_app.cpp:233-278): the returned handle is used exactly like the one of
+ * ovr_hip_create - every setter, commit, render, mapframe, swap - and drives n_devices renderers, one per listed device: the volume is
+ * replicated, device k renders the image tiles (tx + ty) % n == k (16 x 16 pixels; OVR_HIP_TILE=WxH, or ovr_hip_set_image_shard(r, 0, 1,
+ * w, h)), and at the end of every frame the tiles of devices 1 ... n-1 travel to device_ids[0] - ncclSend / ncclRecv between the
+ * communicators of this process (librccl is loaded at run time) when the devices are distinct, peer-to-peer copies otherwise or when RCCL is
+ * absent (OVR_HIP_GATHER=rccl|copy forces one) - where one launch per layer scatters them into the leader's framebuffer.  Pixels, TEA seeds and
+ * accumulation are per pixel: the frame is the single-device frame bit for bit.  A device may be listed more than once (a rehearsal on one
+ * card).  n_devices == 1 is ovr_hip_create.  ovr_hip_get_stats sums the members' counters and reports the slowest member's times;
+ * OVR_HIP_MAP_GRAD=0 leaves the gradient layer out of the gather (it is then valid for device 0's tiles only). */
+int ovr_hip_create_group(ovr_hip_renderer** out, const int32_t* device_ids, int32_t n_devices);
+/* n_devices (1 for an ordinary renderer), how the tiles travel (0 = no group, 1 = peer copies, 2 = RCCL), and the host time the last frame
+ * spent after its slowest member had finished (waiting for the shipments + the scatter), milliseconds; any pointer may be NULL */
+int ovr_hip_group_info(const ovr_hip_renderer* r, int32_t* n_devices, int32_t* gather_kind, double* gather_ms);
+/* the counters of ONE member's last frame (member 0 = the leader's own tiles) */
+int ovr_hip_get_member_stats(const ovr_hip_renderer* r, int32_t member, ovr_hip_stats* out);
 
 /* Use a caller-owned hipStream_t for all device work (e.g. torch's current stream); NULL = private streams,
  * one per framebuffer set like DoubleBufferObject (optix7_common.h:328-414). */

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -116,7 +117,16 @@ struct ovr_hip_renderer {
   void* d_replica[kLayouts] = {};  // [3] = the quad replica (f32 volumes)
   void* d_axis[kLayouts] = {}; // per layout: its per-axis offset tables (VolumeDesc::axis_ab / axis_z)
   VolumeDesc vd_replica[kLayouts] = {};
-  Queued<int> layouts;      // ovr_hip_set_volume_layouts: which replicas the next ovr_hip_set_volume builds
+  // Replicas are built in the background (round 4): ovr_hip_set_volume uploads the general layout only and PLANS the others (which exist
+  // for the type, fit the 40 % rule and the 32-bit in-plane offsets); a replica is allocated and re-bricked from the general layout on
+  // build_stream the first time the layout rule, the tuner or a forced choice asks for it.  Every layout gives the same frame bit for bit,
+  // so frames keep rendering from the general layout until the build has finished (a forced choice and the tuner's probes wait for it on the
+  // device).  C3: 40 GB and four relayout passes at every ovr_hip_set_volume became 5.9 GB and one.
+  //   0 = no such replica, 1 = planned (vd_replica[k] is its geometry, nothing allocated), 2 = being built (build_ev[k] pending), 3 = resident
+  int replica_state[kLayouts] = {};
+  hipStream_t build_stream = nullptr;
+  hipEvent_t build_ev[kLayouts] = {};
+  Queued<int> layouts;      // ovr_hip_set_volume_layouts: which replicas the next ovr_hip_set_volume plans (2: builds at once)
   Queued<int> layout_choice; // -1 = automatic (camera direction / the previous frame's work), 0..3 = forced (falls back to general if not resident)
   // Automatic choice of the volume layout and of the shading pipeline, second stage (round 3).  The rules of round 2 - thin replicas for
   // axis views, in place once half the samples are shaded - were fitted on frames bound by HBM bytes.  Frames that shade (nearly) every
@@ -134,6 +144,8 @@ struct ovr_hip_renderer {
   TuneCand tune_cand[6] = {};
   int tune_n = 0, tune_cur = 0;
   int tune_layout = -1, tune_pipeline = 0; // decided (-1 / 0 = leave it to the rules)
+  int tune_rule_choice = -1;   // what the layout rule said for the camera the measurement was made with: a measured LAYOUT is only kept
+                               // across camera moves while the rule still says the same (the thin replicas are view-dependent)
   int tune_frame = -1;         // candidate index of the frame in flight, -1 = not a tuned frame
   bool tune_on = true;
   // A camera that moves on every frame (the interactive app) never sits still long enough to be measured: when only the camera changed, a
@@ -232,6 +244,24 @@ struct ovr_hip_renderer {
   // roomy for this configuration - the last frame since the last commit that changed anything used at most half of it
   bool pool_roomy = false;
   bool packed_early = false; // the pending frame's tiles were packed without waiting for it
+
+  // ---- device group (ovr_hip_create_group): one process drives several GPUs, each member renders the image tiles of rank group_rank of
+  // group_size (ovr_hip_set_image_shard semantics, volume replicated) and the leader - members[0], the handle the caller holds - gathers the
+  // followers' tiles into its own framebuffer at the end of every frame.  A follower is an ordinary renderer whose `leader` is set.
+  std::vector<ovr_hip_renderer*> members; // leader only: every member, itself first
+  ovr_hip_renderer* leader = nullptr;     // follower only
+  int group_rank = 0;
+  int gather_kind = 0;                    // leader: 0 = no group, 1 = peer copies, 2 = RCCL send / recv
+  hipStream_t comm_stream = nullptr;      // every member: where its payload travels (the render stream goes on with the next frame)
+  hipEvent_t ev_packed = nullptr, ev_shipped = nullptr;
+  float* d_payload[2] = { nullptr, nullptr };  // follower: its packed tiles, [0] RGBA, [1] gradient layer
+  float* d_gather[2] = { nullptr, nullptr };   // leader: every member's payload, group_stride[] floats apart
+  size_t payload_floats[2] = { 0, 0 }, group_stride[2] = { 0, 0 };
+  int group_fb[5] = { 0, 0, 0, 0, 0 };    // what the gather buffers were sized for: W, H, tile_w, tile_h, size
+  bool group_grad = true;                 // the gradient layer travels too (OVR_HIP_MAP_GRAD=0: RGBA only, like the plugin's mapframe)
+  void* rccl_comm = nullptr;              // every member of an RCCL group: its communicator
+  ovr_hip_stats own_stats{};              // leader: its own frame's counters (stats holds the group's sums)
+  double group_gather_ms = 0.0;           // leader: host time of the last frame's gather tail (after the slowest member's frame: wait for the shipments + scatter)
 
   hipStream_t stream() const { return use_user_stream ? user_stream : own_stream[cur]; }
 };
@@ -466,6 +496,8 @@ SparseMaskParams make_mask_params(ovr_hip_renderer* r, int frame_index, int32_t*
 }
 
 int launch_frame(ovr_hip_renderer* r);
+int finish_frame(ovr_hip_renderer* r); // resolves the frame in flight: one renderer, or a device group incl. its gather
+int finish_frame_one(ovr_hip_renderer* r);
 
 // Screen-space bounding rectangle (pixels, aligned outwards to 8, two pixels of margin for the sub-pixel jitter) of the volume's box
 // under the committed camera: a ray outside it misses the box and its pixel is exactly 0 in every layer (background 0, alpha 0,
@@ -604,6 +636,63 @@ int build_schedule_list(ovr_hip_renderer* r)
   return 0;
 }
 
+// ---- replicas built in the background (see replica_state)
+void drop_replica(ovr_hip_renderer* r, int k)
+{
+  if (r->d_replica[k] && k != LAYOUT_GENERAL) { (void)hipFree(r->d_replica[k]); r->volume_bytes -= (size_t)r->vd_replica[k].bytes; }
+  if (r->d_axis[k] && k != LAYOUT_GENERAL) (void)hipFree(r->d_axis[k]);
+  if (k != LAYOUT_GENERAL) { r->d_replica[k] = nullptr; r->d_axis[k] = nullptr; }
+  r->replica_state[k] = 0;
+}
+
+// allocate replica k and enqueue its construction from the general layout on build_stream; on an allocation failure the replica is
+// given up (an optimisation: the general layout renders the same frames) and `err` says why
+int start_replica_build(ovr_hip_renderer* r, int k, std::string* err)
+{
+  if (r->replica_state[k] != 1) return 0;
+  VolumeDesc& t = r->vd_replica[k];
+  hipError_t e = hipMalloc(&r->d_replica[k], (size_t)t.bytes + 64); // + slack: the pair load of the very last element
+  if (e == hipSuccess) e = hipMalloc(&r->d_axis[k], axis_table_bytes(t));
+  if (e == hipSuccess) {
+    t.data = r->d_replica[k];
+    r->volume_bytes += (size_t)t.bytes;
+    e = hipMemsetAsync(r->d_replica[k], 0, (size_t)t.bytes + 64, r->build_stream); // padding voxels are never sampled, but must be finite
+  }
+  if (e == hipSuccess) e = launch_axis_tables(t, r->d_axis[k], r->build_stream);
+  if (e == hipSuccess) {
+    VolumeDesc g = r->vd_replica[LAYOUT_GENERAL];
+    g.data = r->d_volume;
+    e = launch_rebrick(g, r->d_replica[k], t, r->build_stream);
+  }
+  if (e == hipSuccess) e = hipEventRecord(r->build_ev[k], r->build_stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(r->build_stream);
+    if (err) *err = hipGetErrorString(e);
+    if (r->d_replica[k] && t.data) r->volume_bytes -= (size_t)t.bytes;
+    if (r->d_replica[k]) (void)hipFree(r->d_replica[k]);
+    if (r->d_axis[k]) (void)hipFree(r->d_axis[k]);
+    r->d_replica[k] = nullptr; r->d_axis[k] = nullptr; t.data = nullptr;
+    r->replica_state[k] = 0;
+    return 0;
+  }
+  r->replica_state[k] = 2;
+  return 0;
+}
+
+// the layout a frame on stream `st` reads when it asks for `choice`: the replica if it is resident; if it is still being built, the replica
+// when the frame may wait for it on the device (forced choice, tuner), else the general layout (same frame bit for bit)
+int resolve_layout(ovr_hip_renderer* r, int choice, bool may_wait, hipStream_t st)
+{
+  if (choice <= LAYOUT_GENERAL || choice >= kLayouts || r->replica_state[choice] == 0) return LAYOUT_GENERAL;
+  if (r->replica_state[choice] == 1) (void)start_replica_build(r, choice, nullptr);
+  if (r->replica_state[choice] == 2 && hipEventQuery(r->build_ev[choice]) == hipSuccess) r->replica_state[choice] = 3;
+  if (r->replica_state[choice] == 3) return choice;
+  if (r->replica_state[choice] == 2 && may_wait && hipStreamWaitEvent(st, r->build_ev[choice], 0) == hipSuccess) return choice;
+  (void)hipGetLastError();
+  return LAYOUT_GENERAL;
+}
+
 // Impl::render up to and including the launch (device_impl.cpp:199-262); no host synchronisation
 int enqueue_frame(ovr_hip_renderer* r)
 {
@@ -641,7 +730,8 @@ int enqueue_frame(ovr_hip_renderer* r)
 
   P.rgba = r->d_rgba[r->cur];
   nonzero_rect(r, r->d_rect[r->cur]); // what mapframe(HOST) will have to copy of this set (the committed camera is the one this frame renders)
-  if (r->shard.current.world > 1) { // an image shard leaves the tiles of the other ranks as they are - whatever an earlier, unsharded frame put there,
+  if (r->shard.current.world > 1 && r->members.size() <= 1) { // (a group leader's set is complete after every frame: its rectangle holds)
+    // an image shard leaves the tiles of the other ranks as they are - whatever an earlier, unsharded frame put there,
     int* q = r->d_rect[r->cur];     // also outside the box's rectangle: such a set is mapped whole (found by tests/fuzz_states.py, seeds 61 / 62)
     q[0] = 0; q[1] = 0; q[2] = W; q[3] = H;
   }
@@ -680,23 +770,32 @@ int enqueue_frame(ovr_hip_renderer* r)
     // second stage (see tune_state): the layout / pipeline under test, or the measured winner
     r->tune_frame = -1;
     const bool tune_l = r->layout_choice.current < 0, tune_p = r->pipeline.current == 0;
+    bool may_wait = !tune_l; // a forced layout is what the frame reads, even if the replica has to be built first
+    if (choice < 0 || choice >= kLayouts || r->replica_state[choice] == 0) choice = LAYOUT_GENERAL;
+    const int rule_choice = choice;
     if (r->tune_on && (tune_l || tune_p)) {
-      if (choice < 0 || choice >= kLayouts || !r->d_replica[choice]) choice = LAYOUT_GENERAL;
       if (r->tune_state == 0) { // the rules' candidate
         r->tune_cand[0] = { tune_l ? choice : -1, 0, 0, 0.f };
         r->tune_n = 1; r->tune_cur = 0; r->tune_phase = 0;
         r->tune_layout = -1; r->tune_pipeline = 0;
         r->tune_frame = 0;
+        r->tune_rule_choice = rule_choice;
       }
       else if (r->tune_state == 1) {
         const auto& c = r->tune_cand[r->tune_cur];
-        if (c.layout >= 0) choice = c.layout;
+        if (tune_l && c.layout >= 0) { choice = c.layout; may_wait = true; } // (a forced layout is never overridden by a probe)
         r->tune_pipeline = c.pipeline;
         r->tune_frame = r->tune_cur;
       }
-      else if (r->tune_layout >= 0 && tune_l) choice = r->tune_layout;
+      else if (r->tune_layout >= 0 && tune_l) {
+        // a measured layout outlives camera moves only while the layout rule still says what it said when the measurement was made:
+        // the thin replicas are view-dependent (an axis view's winner loses 30-60 % at an oblique angle), and general / quad were
+        // measured against THAT rule's choice.  The measured pipeline stays (the regime decides it, not the view).
+        if (rule_choice != r->tune_rule_choice) r->tune_layout = -1;
+        else { choice = r->tune_layout; may_wait = true; }
+      }
     }
-    if (choice < 0 || choice >= kLayouts || !r->d_replica[choice]) choice = LAYOUT_GENERAL;
+    choice = resolve_layout(r, choice, may_wait, st);
     const float vs = P.vol.value_scale, vm = P.vol.value_min_clamp;
     P.vol = r->vd_replica[choice];
     P.vol.value_scale = vs;
@@ -809,7 +908,7 @@ int launch_frame(ovr_hip_renderer* r)
   return 0;
 }
 
-int finish_frame(ovr_hip_renderer* r)
+int finish_frame_one(ovr_hip_renderer* r)
 {
   if (!r->async_pending) return 0;
   HIP_TRY(hipStreamSynchronize(r->stream()));
@@ -874,6 +973,12 @@ int finish_frame(ovr_hip_renderer* r)
   r->stats.frame_index = r->frame_index;
   r->sparse_prev_pixels = r->P.sparse_xy ? r->stats.active_pixels : 0;
   r->stats.skipping_kernels = r->frame_used_skip ? 1 : 0;
+  r->stats.replicas_building = 0;
+  for (int k = 1; k < kLayouts; ++k) {
+    if (r->replica_state[k] == 2 && hipEventQuery(r->build_ev[k]) == hipSuccess) r->replica_state[k] = 3;
+    if (r->replica_state[k] == 2) r->stats.replicas_building++;
+  }
+  (void)hipGetLastError(); // hipErrorNotReady of the query is not an error
   r->stats.tuning = r->tune_frame >= 0 ? 1 : (r->tune_on && r->tune_state == 2 && (r->tune_layout >= 0 || r->tune_pipeline != 0)) ? 2 : 0;
   if (r->tune_frame == 0 && r->tune_state == 0) r->stats.tuning = 0; // the first frame of a configuration runs the rules' choice
   if (r->tune_frame >= 0 && r->tune_state < 2) { // measured choice of layout and pipeline (see tune_state)
@@ -898,7 +1003,10 @@ int finish_frame(ovr_hip_renderer* r)
     auto add_layouts = [&](int pipeline) {
       const int base = r->tune_cand[0].layout;
       for (int l : { (int)LAYOUT_GENERAL, (int)LAYOUT_QUAD })
-        if (tune_l && l != base && r->d_replica[l] && r->tune_n < 6) r->tune_cand[r->tune_n++] = { l, pipeline, 0, 0.f };
+        if (tune_l && l != base && (l == LAYOUT_GENERAL || r->replica_state[l] != 0) && r->tune_n < 6) {
+          r->tune_cand[r->tune_n++] = { l, pipeline, 0, 0.f };
+          if (r->replica_state[l] == 1) (void)start_replica_build(r, l, nullptr); // built while the candidates before it are timed
+        }
       r->tune_phase = 1;
     };
     if (r->tune_state == 0) {
@@ -972,6 +1080,188 @@ int finish_frame(ovr_hip_renderer* r)
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Device group: the image-plane shard of SURVEY.md 8e INSIDE one process, behind the same handle - what the reference's unmodified
+// apps reach through the plugin (north_star: "apps run unmodified ... the 8 GPUs of one node shard the image plane into
+// tiles with a final RCCL gather over xGMI").  Every member renders its own tiles of the frame on its own device (volume replicated,
+// TEA seeds by global pixel index: the assembled frame is the single-GPU frame bit for bit); at the end of the frame each follower packs
+// its tiles, its comm_stream ships them to the leader's device - ncclSend / ncclRecv over RCCL's communicators of this process
+// (ncclCommInitAll) when the devices are distinct, peer-to-peer copies otherwise (OVR_HIP_GATHER=rccl|copy forces one) - and the leader
+// scatters all payloads into its framebuffer with one launch per layer.  mapframe / swap / accumulation work on the leader's
+// framebuffer as with one device.  The reference has one device (device_impl.cpp:371-372) and nothing to mirror here.
+// ------------------------------------------------------------------------------------------------------------------
+struct RcclApi { // resolved at run time: libovr_hip.so does not link RCCL, a host without it falls back to peer copies
+  void* lib = nullptr;
+  int (*CommInitAll)(void**, int, const int*) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+const RcclApi& rccl_api()
+{
+  static const RcclApi api = [] {
+    RcclApi a;
+    for (const char* name : { "librccl.so.1", "librccl.so" })
+      if ((a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!a.lib) return a;
+    a.CommInitAll = (int (*)(void**, int, const int*))dlsym(a.lib, "ncclCommInitAll");
+    a.CommDestroy = (int (*)(void*))dlsym(a.lib, "ncclCommDestroy");
+    a.GroupStart = (int (*)())dlsym(a.lib, "ncclGroupStart");
+    a.GroupEnd = (int (*)())dlsym(a.lib, "ncclGroupEnd");
+    a.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(a.lib, "ncclSend");
+    a.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(a.lib, "ncclRecv");
+    a.GetErrorString = (const char* (*)(int))dlsym(a.lib, "ncclGetErrorString");
+    a.ok = a.CommInitAll && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv;
+    return a;
+  }();
+  return api;
+}
+constexpr int kNcclFloat = 7; // ncclFloat32, rccl.h
+
+#define GROUP_FORWARD(r, call)                                                                                          \
+  do {                                                                                                                  \
+    for (size_t i_ = 1; i_ < (r)->members.size(); ++i_) {                                                               \
+      ovr_hip_renderer* m = (r)->members[i_];                                                                           \
+      if (int e_ = (call)) { (void)hipSetDevice((r)->device); return e_; }                                              \
+    }                                                                                                                   \
+    if ((r)->members.size() > 1) (void)hipSetDevice((r)->device);                                                       \
+  } while (0)
+
+// (re)size the payload and gather buffers for the committed framebuffer size and tiles
+int group_buffers(ovr_hip_renderer* L)
+{
+  const int n = (int)L->members.size();
+  const ShardP& s0 = L->shard.current;
+  const int W = L->fbsize.current.w, H = L->fbsize.current.h;
+  if (L->group_fb[0] == W && L->group_fb[1] == H && L->group_fb[2] == s0.tw && L->group_fb[3] == s0.th && L->group_fb[4] == n) return 0;
+  size_t most = 0;
+  for (int i = 0; i < n; ++i) {
+    ovr_hip_renderer* m = L->members[i];
+    const size_t px = (size_t)count_owned_tiles(W, H, s0.tw, s0.th, i, n) * s0.tw * s0.th;
+    most = std::max(most, px);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->comm_stream));
+    for (int c = 0; c < 2; ++c) {
+      if (m->d_payload[c]) HIP_TRY(hipFree(m->d_payload[c]));
+      m->d_payload[c] = nullptr;
+      m->payload_floats[c] = px * (c == 0 ? 4 : 3);
+      if (i > 0 && px > 0 && (c == 0 || L->group_grad)) HIP_TRY(hipMalloc((void**)&m->d_payload[c], m->payload_floats[c] * sizeof(float)));
+    }
+  }
+  HIP_TRY(hipSetDevice(L->device));
+  for (int c = 0; c < 2; ++c) {
+    if (L->d_gather[c]) HIP_TRY(hipFree(L->d_gather[c]));
+    L->d_gather[c] = nullptr;
+    L->group_stride[c] = ((most * (c == 0 ? 4 : 3) + 11) / 12) * 12; // floats; a multiple of 3 and of 4: whole pixels in either layer
+    if (most > 0 && (c == 0 || L->group_grad)) HIP_TRY(hipMalloc((void**)&L->d_gather[c], L->group_stride[c] * (size_t)n * sizeof(float)));
+  }
+  L->group_fb[0] = W; L->group_fb[1] = H; L->group_fb[2] = s0.tw; L->group_fb[3] = s0.th; L->group_fb[4] = n;
+  return 0;
+}
+
+// follower m: pack the tiles of the frame in flight (or just finished) and send them to the leader; the shipment ends in m->ev_shipped
+int group_ship(ovr_hip_renderer* L, ovr_hip_renderer* m)
+{
+  const int n = (int)L->members.size();
+  const int W = L->fbsize.current.w, H = L->fbsize.current.h;
+  const ShardP& s = m->shard.current;
+  HIP_TRY(hipSetDevice(m->device));
+  if (m->payload_floats[0] == 0) { HIP_TRY(hipEventRecord(m->ev_shipped, m->comm_stream)); return 0; }
+  // ovr_hip_pack_tiles resolves a frame whose request pool is not yet known to be roomy before it packs (a pool overflow renders the frame again)
+  if (int e = ovr_hip_pack_tiles(m, m->d_payload[0], m->payload_floats[0] * sizeof(float))) return e;
+  if (L->group_grad) HIP_TRY(launch_pack_tiles(m->d_grad[m->cur], m->d_payload[1], W, H, s.tw, s.th, s.rank, s.world, m->stream(), 3));
+  HIP_TRY(hipEventRecord(m->ev_packed, m->stream()));
+  HIP_TRY(hipStreamWaitEvent(m->comm_stream, m->ev_packed, 0));
+  if (L->gather_kind == 2) {
+    const RcclApi& N = rccl_api();
+    HIP_TRY(hipSetDevice(L->device));
+    HIP_TRY(hipStreamWaitEvent(L->comm_stream, m->ev_packed, 0)); // (the matching recv must not start before the payload exists - harmless, but keeps the pair aligned)
+    int rc = N.GroupStart();
+    for (int c = 0; c < 2 && rc == 0; ++c) {
+      if (c == 1 && !L->group_grad) break;
+      rc = N.Send(m->d_payload[c], m->payload_floats[c], kNcclFloat, 0, m->rccl_comm, m->comm_stream);
+      if (rc == 0) rc = N.Recv(L->d_gather[c] + (size_t)m->group_rank * L->group_stride[c], m->payload_floats[c], kNcclFloat, m->group_rank, L->rccl_comm, L->comm_stream);
+    }
+    const int rc2 = N.GroupEnd();
+    if (rc != 0 || rc2 != 0) return fail(OVR_HIP_EDEVICE, std::string("[hip] RCCL send / recv of a group member's tiles failed: ") + (N.GetErrorString ? N.GetErrorString(rc != 0 ? rc : rc2) : "?"));
+    HIP_TRY(hipEventRecord(m->ev_shipped, L->comm_stream)); // the receive side: ordered after every earlier member's receive on that stream
+    (void)n;
+    return 0;
+  }
+  for (int c = 0; c < 2; ++c) {
+    if (c == 1 && !L->group_grad) break;
+    float* dst = L->d_gather[c] + (size_t)m->group_rank * L->group_stride[c];
+    if (m->device == L->device) HIP_TRY(hipMemcpyAsync(dst, m->d_payload[c], m->payload_floats[c] * sizeof(float), hipMemcpyDeviceToDevice, m->comm_stream));
+    else HIP_TRY(hipMemcpyPeerAsync(dst, L->device, m->d_payload[c], m->device, m->payload_floats[c] * sizeof(float), m->comm_stream));
+  }
+  HIP_TRY(hipEventRecord(m->ev_shipped, m->comm_stream));
+  return 0;
+}
+
+int group_finish(ovr_hip_renderer* L)
+{
+  const int n = (int)L->members.size();
+  bool any = L->async_pending;
+  for (int i = 1; i < n; ++i) any = any || L->members[i]->async_pending;
+  if (!any) return 0;
+  const int W = L->fbsize.current.w, H = L->fbsize.current.h;
+  if (int e = group_buffers(L)) return e;
+  // 1. the followers pack behind their frames and ship on their comm streams while everything still renders
+  for (int i = 1; i < n; ++i)
+    if (int e = group_ship(L, L->members[i])) { (void)hipSetDevice(L->device); return e; }
+  // 2. every frame to its end (a follower whose request pool overflowed renders again: its early payload is stale)
+  HIP_TRY(hipSetDevice(L->device));
+  if (int e = finish_frame_one(L)) return e;
+  for (int i = 1; i < n; ++i) {
+    ovr_hip_renderer* m = L->members[i];
+    HIP_TRY(hipSetDevice(m->device));
+    if (int e = finish_frame_one(m)) { (void)hipSetDevice(L->device); return e; }
+    if (m->stats.stale_tiles)
+      if (int e = group_ship(L, m)) { (void)hipSetDevice(L->device); return e; }
+  }
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  // 3. the leader scatters the payloads into the framebuffer set the frame rendered into
+  HIP_TRY(hipSetDevice(L->device));
+  hipStream_t st = L->stream();
+  for (int i = 1; i < n; ++i) HIP_TRY(hipStreamWaitEvent(st, L->members[i]->ev_shipped, 0));
+  const ShardP& s = L->shard.current;
+  if (W > 0 && H > 0 && L->d_gather[0]) {
+    HIP_TRY(launch_unpack_tiles(L->d_gather[0], L->d_rgba[L->frame_set], W, H, s.tw, s.th, -1, n, L->group_stride[0], st, 4, 0));
+    if (L->group_grad && L->d_gather[1]) HIP_TRY(launch_unpack_tiles(L->d_gather[1], L->d_grad[L->frame_set], W, H, s.tw, s.th, -1, n, L->group_stride[1], st, 3, 0));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  L->group_gather_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+  // 4. the frame's counters: sums over the members, times of the slowest
+  L->own_stats = L->stats;
+  for (int i = 1; i < n; ++i) {
+    const ovr_hip_stats& a = L->members[i]->stats;
+    ovr_hip_stats& t = L->stats;
+    t.rays += a.rays; t.samples += a.samples; t.shaded_samples += a.shaded_samples; t.shadow_samples += a.shadow_samples;
+    t.active_pixels += a.active_pixels; t.skipped_samples += a.skipped_samples; t.skipped_shadow_samples += a.skipped_shadow_samples;
+    t.pool_chunks += a.pool_chunks;
+    t.kernel_ms = std::max(t.kernel_ms, a.kernel_ms); t.march_ms = std::max(t.march_ms, a.march_ms);
+    t.shade_ms = std::max(t.shade_ms, a.shade_ms); t.composite_ms = std::max(t.composite_ms, a.composite_ms);
+    t.replicas_building += a.replicas_building;
+    if (a.tuning == 1) t.tuning = 1;
+    if (L->members[i]->outside_hits) { // a hit through an ignored slab on any member: the leader's set is mapped whole (see finish_frame_one)
+      int* q = L->d_rect[L->frame_set]; q[0] = 0; q[1] = 0; q[2] = W; q[3] = H;
+    }
+  }
+  L->stats.stale_tiles = 0;
+  return 0;
+}
+
+int finish_frame(ovr_hip_renderer* r)
+{
+  if (r->members.size() > 1) return group_finish(r);
+  return finish_frame_one(r);
+}
+
 } // namespace
 
 extern "C" {
@@ -998,6 +1288,8 @@ int ovr_hip_create(ovr_hip_renderer** out, int device_id)
     HIP_TRY(hipStreamCreate(&r->own_stream[0]));
     HIP_TRY(hipStreamCreate(&r->own_stream[1]));
     for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&r->ev[i]));
+    HIP_TRY(hipStreamCreate(&r->build_stream));
+    for (int k = 0; k < kLayouts; ++k) HIP_TRY(hipEventCreateWithFlags(&r->build_ev[k], hipEventDisableTiming));
     HIP_TRY(hipMalloc((void**)&r->d_counters, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc((void**)&r->d_sparse_count, sizeof(unsigned long long)));
     HIP_TRY(hipMalloc((void**)&r->d_data_range, 2 * sizeof(float)));
@@ -1022,11 +1314,100 @@ int ovr_hip_create(ovr_hip_renderer** out, int device_id)
   return 0;
 }
 
+int ovr_hip_create_group(ovr_hip_renderer** out, const int32_t* device_ids, int32_t n_devices)
+{
+  if (!out) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_create_group: null output pointer");
+  *out = nullptr;
+  if (!device_ids || n_devices < 1 || n_devices > 64) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_create_group: 1 to 64 device ordinals expected");
+  ovr_hip_renderer* L = nullptr;
+  if (int e = ovr_hip_create(&L, device_ids[0])) return e;
+  if (n_devices == 1) { *out = L; return 0; } // one device: an ordinary renderer
+  L->members.push_back(L);
+  auto build = [&]() -> int {
+    for (int i = 1; i < n_devices; ++i) {
+      ovr_hip_renderer* m = nullptr;
+      if (int e = ovr_hip_create(&m, device_ids[i])) return e;
+      m->leader = L;
+      m->group_rank = i;
+      L->members.push_back(m);
+    }
+    int tw = 16, th = 16; // measured work max / mean over 8 ranks 1.07 (1.33 with 64 x 64): DESIGN.md section 5
+    if (const char* t = getenv("OVR_HIP_TILE")) { int a = 0, b = 0; if (sscanf(t, "%dx%d", &a, &b) == 2 && a > 0 && b > 0) { tw = a; th = b; } }
+    bool distinct = true;
+    for (int i = 0; i < n_devices; ++i)
+      for (int j = 0; j < i; ++j) distinct = distinct && device_ids[i] != device_ids[j];
+    for (int i = 0; i < n_devices; ++i) {
+      ovr_hip_renderer* m = L->members[i];
+      HIP_TRY(hipSetDevice(m->device));
+      HIP_TRY(hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&m->ev_packed, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&m->ev_shipped, hipEventDisableTiming));
+      ShardP s; s.rank = i; s.world = n_devices; s.tw = tw; s.th = th;
+      m->shard.current = m->shard.queued = s;
+      m->sched_list_dirty = true;
+      for (int j = 0; j < n_devices; ++j) // direct xGMI / PCIe peer access where the platform has it (the copies work without, staged by the runtime)
+        if (device_ids[j] != m->device) { int can = 0; if (hipDeviceCanAccessPeer(&can, m->device, device_ids[j]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(device_ids[j], 0); }
+      (void)hipGetLastError(); // hipErrorPeerAccessAlreadyEnabled is not an error
+    }
+    HIP_TRY(hipSetDevice(L->device));
+    if (const char* g = getenv("OVR_HIP_MAP_GRAD")) L->group_grad = g[0] != '0';
+    const char* want = getenv("OVR_HIP_GATHER");
+    const bool force_rccl = want && std::string(want) == "rccl", force_copy = want && std::string(want) == "copy";
+    if (want && !force_rccl && !force_copy) return fail(OVR_HIP_EINVAL, "[hip] OVR_HIP_GATHER must be 'rccl' or 'copy'");
+    L->gather_kind = 1;
+    if (!force_copy && distinct && rccl_api().ok) { // one communicator per device of this process (ncclCommInitAll refuses a device listed twice)
+      std::vector<void*> comms((size_t)n_devices, nullptr);
+      std::vector<int> devs(device_ids, device_ids + n_devices);
+      const int rc = rccl_api().CommInitAll(comms.data(), n_devices, devs.data());
+      if (rc == 0) {
+        for (int i = 0; i < n_devices; ++i) L->members[i]->rccl_comm = comms[(size_t)i];
+        L->gather_kind = 2;
+      }
+      else if (force_rccl) return fail(OVR_HIP_EDEVICE, std::string("[hip] ncclCommInitAll failed: ") + (rccl_api().GetErrorString ? rccl_api().GetErrorString(rc) : "?"));
+      HIP_TRY(hipSetDevice(L->device));
+    }
+    else if (force_rccl) return fail(OVR_HIP_EDEVICE, distinct ? "[hip] OVR_HIP_GATHER=rccl but librccl.so could not be loaded" : "[hip] OVR_HIP_GATHER=rccl needs distinct devices (RCCL refuses a device listed twice)");
+    return 0;
+  };
+  if (int e = build()) { const std::string msg = g_last_error; ovr_hip_destroy(L); g_last_error = msg; return e; }
+  *out = L;
+  return 0;
+}
+
+int ovr_hip_group_info(const ovr_hip_renderer* r, int32_t* n_devices, int32_t* gather_kind, double* gather_ms)
+{
+  if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
+  if (n_devices) *n_devices = r->members.size() > 1 ? (int32_t)r->members.size() : 1;
+  if (gather_kind) *gather_kind = r->members.size() > 1 ? r->gather_kind : 0;
+  if (gather_ms) *gather_ms = r->members.size() > 1 ? r->group_gather_ms : 0.0;
+  return 0;
+}
+
+int ovr_hip_get_member_stats(const ovr_hip_renderer* r, int32_t member, ovr_hip_stats* out)
+{
+  if (!r || !out) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_get_member_stats: null argument");
+  const int n = r->members.size() > 1 ? (int)r->members.size() : 1;
+  if (member < 0 || member >= n) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_get_member_stats: no such member");
+  if (r->async_pending) return fail(OVR_HIP_ESTATE, "[hip] ovr_hip_get_member_stats: a frame is still in flight (call ovr_hip_sync)");
+  *out = n > 1 ? (member == 0 ? r->own_stats : r->members[(size_t)member]->stats) : r->stats;
+  return 0;
+}
+
 void ovr_hip_destroy(ovr_hip_renderer* r)
 {
   if (!r) return;
+  for (size_t i = 1; i < r->members.size(); ++i) ovr_hip_destroy(r->members[i]); // a group leader takes its followers with it
+  r->members.clear();
   (void)hipSetDevice(r->device);
   (void)hipDeviceSynchronize();
+  if (r->rccl_comm && rccl_api().ok) (void)rccl_api().CommDestroy(r->rccl_comm);
+  for (int c = 0; c < 2; ++c) {
+    if (r->d_payload[c]) (void)hipFree(r->d_payload[c]);
+    if (r->d_gather[c]) (void)hipFree(r->d_gather[c]);
+  }
+  if (r->comm_stream) (void)hipStreamDestroy(r->comm_stream);
+  if (r->ev_packed) (void)hipEventDestroy(r->ev_packed);
+  if (r->ev_shipped) (void)hipEventDestroy(r->ev_shipped);
   (void)free_framebuffers(r);
   for (int k = 0; k < kLayouts; ++k) {
     if (r->d_replica[k]) (void)hipFree(r->d_replica[k]);
@@ -1054,12 +1435,16 @@ void ovr_hip_destroy(ovr_hip_renderer* r)
   if (r->d_trace) (void)hipFree(r->d_trace);
   for (int i = 0; i < 2; ++i)
     if (r->own_stream[i]) (void)hipStreamDestroy(r->own_stream[i]);
+  if (r->build_stream) (void)hipStreamDestroy(r->build_stream);
+  for (int k = 0; k < kLayouts; ++k)
+    if (r->build_ev[k]) (void)hipEventDestroy(r->build_ev[k]);
   delete r;
 }
 
 int ovr_hip_set_stream(ovr_hip_renderer* r, void* s)
 {
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
+  if (r->members.size() > 1 && s) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_stream: a device group renders on one stream per device");
   if (int e = finish_frame(r)) return e;
   r->user_stream = (hipStream_t)s;
   r->use_user_stream = (s != nullptr);
@@ -1089,12 +1474,14 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
   if (!layout_offsets_fit(vd))
     return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_volume: one z layer of the volume exceeds 2^32 stored voxels (x * y too large for the 32-bit in-plane offsets)");
 
+  HIP_TRY(hipStreamSynchronize(r->build_stream)); // (covered by the device synchronisation above; kept explicit: a build reads the old general layout)
   for (int k = 0; k < kLayouts; ++k) {
     if (r->d_replica[k]) HIP_TRY(hipFree(r->d_replica[k]));
     r->d_replica[k] = nullptr;
     if (r->d_axis[k]) HIP_TRY(hipFree(r->d_axis[k]));
     r->d_axis[k] = nullptr;
     r->vd_replica[k] = VolumeDesc{};
+    r->replica_state[k] = 0;
   }
   r->d_volume = nullptr;
   r->have_volume = false; // until the new one is completely resident: a failure below must not leave a half-built volume renderable
@@ -1104,87 +1491,55 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
   r->volume_bytes = bytes;
   vd.data = r->d_volume;
   r->vd_replica[0] = vd;
-  // thin replicas for views along a volume axis (ovr_hip_kernels.h).  mode 1 (default): built when the type has them and they
-  // fit comfortably (all replicas <= 40 % of the free HBM); mode 2: always (an allocation failure is an error); mode 0: never
+  r->replica_state[0] = 3;
+  // The other layouts (ovr_hip_kernels.h: thin replicas for views along a volume axis, the quad replica for frames that shade every sample) are
+  // only PLANNED here and built in the background when a frame first asks for one (replica_state).  mode 1 (default): planned when the type has
+  // them and they fit comfortably (all replicas <= 40 % of the free HBM); mode 2: all of them, built before this call returns (an allocation
+  // failure is an error); mode 0: none.  OVR_HIP_QUAD=0 leaves the quad replica out (measurements).
   {
     std::lock_guard<std::mutex> lk(r->mtx);
     (void)r->layouts.update();
   }
-  int n_layouts = 1;
-  if (r->layouts.current != 0 && replica_voxel_type(vt, LAYOUT_THIN) >= 0) {
-    VolumeDesc t1 = vd, t2 = vd;
-    volume_layout(replica_voxel_type(vt, LAYOUT_THIN), vd.nx, vd.ny, vd.nz, t1);
-    volume_layout(replica_voxel_type(vt, LAYOUT_THIN_T), vd.nx, vd.ny, vd.nz, t2);
+  {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    if (layout_offsets_fit(t1) && layout_offsets_fit(t2) && (r->layouts.current == 2 || (double)(t1.bytes + t2.bytes) <= 0.4 * (double)free_b)) {
-      const VolumeDesc* ts[2] = { &t1, &t2 };
-      hipError_t e = hipSuccess;
-      for (int k = 1; k <= 2 && e == hipSuccess; ++k) {
-        e = hipMalloc(&r->d_replica[k], (size_t)ts[k - 1]->bytes + 64);
-        if (e == hipSuccess) e = hipMemset(r->d_replica[k], 0, (size_t)ts[k - 1]->bytes + 64);
+    double planned = 0.0;
+    auto plan = [&](int k) { VolumeDesc t = vd; t.data = nullptr; t.axis_ab = nullptr; t.axis_z = nullptr; volume_layout(replica_voxel_type(vt, k), vd.nx, vd.ny, vd.nz, t); return t; };
+    if (r->layouts.current != 0 && replica_voxel_type(vt, LAYOUT_THIN) >= 0) {
+      const VolumeDesc t1 = plan(LAYOUT_THIN), t2 = plan(LAYOUT_THIN_T);
+      if (layout_offsets_fit(t1) && layout_offsets_fit(t2) && (r->layouts.current == 2 || (double)(t1.bytes + t2.bytes) <= 0.4 * (double)free_b)) {
+        r->vd_replica[LAYOUT_THIN] = t1; r->vd_replica[LAYOUT_THIN_T] = t2;
+        r->replica_state[LAYOUT_THIN] = r->replica_state[LAYOUT_THIN_T] = 1;
+        planned += (double)(t1.bytes + t2.bytes);
       }
-      if (e == hipSuccess) {
-        for (int k = 1; k <= 2; ++k) {
-          r->vd_replica[k] = *ts[k - 1];
-          r->vd_replica[k].data = r->d_replica[k];
-          r->volume_bytes += (size_t)ts[k - 1]->bytes;
-        }
-        n_layouts = 3;
-      }
-      else { // no room after all: the replicas are an optimisation, the general layout alone renders the same frames
-        (void)hipGetLastError();
-        for (int k = 1; k <= 2; ++k) {
-          if (r->d_replica[k]) (void)hipFree(r->d_replica[k]);
-          r->d_replica[k] = nullptr;
-        }
-        if (r->layouts.current == 2) return fail(OVR_HIP_EDEVICE, std::string("[hip] volume replicas requested (layouts mode 2) but their allocation failed: ") + hipGetErrorString(e));
-      }
+      else if (r->layouts.current == 2) return fail(OVR_HIP_EINVAL, "[hip] volume replicas requested (layouts mode 2) but one z layer of a thin replica exceeds 2^32 elements");
     }
-  }
-  // quad replica (ovr_hip_kernels.h: a tap is two 16-byte loads; 4 x the memory) for the frames that shade every sample: same modes,
-  // same 40 % rule (all replicas together); OVR_HIP_QUAD=0 leaves it out (measurements)
-  static const bool want_quad = !(getenv("OVR_HIP_QUAD") && atoi(getenv("OVR_HIP_QUAD")) == 0);
-  if (want_quad && r->layouts.current != 0 && replica_voxel_type(vt, LAYOUT_QUAD) >= 0) {
-    VolumeDesc tq = vd;
-    volume_layout(replica_voxel_type(vt, LAYOUT_QUAD), vd.nx, vd.ny, vd.nz, tq);
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const double built = (double)(r->volume_bytes - bytes); // the thin replicas, already allocated
-    if (layout_offsets_fit(tq) && (r->layouts.current == 2 || (double)tq.bytes + built <= 0.4 * ((double)free_b + built))) {
-      hipError_t e = hipMalloc(&r->d_replica[LAYOUT_QUAD], (size_t)tq.bytes + 64);
-      if (e == hipSuccess) e = hipMemset(r->d_replica[LAYOUT_QUAD], 0, (size_t)tq.bytes + 64);
-      if (e == hipSuccess) {
+    static const bool want_quad = !(getenv("OVR_HIP_QUAD") && atoi(getenv("OVR_HIP_QUAD")) == 0);
+    if (want_quad && r->layouts.current != 0 && replica_voxel_type(vt, LAYOUT_QUAD) >= 0) {
+      const VolumeDesc tq = plan(LAYOUT_QUAD);
+      if (layout_offsets_fit(tq) && (r->layouts.current == 2 || (double)tq.bytes + planned <= 0.4 * (double)free_b)) {
         r->vd_replica[LAYOUT_QUAD] = tq;
-        r->vd_replica[LAYOUT_QUAD].data = r->d_replica[LAYOUT_QUAD];
-        r->volume_bytes += (size_t)tq.bytes;
-      }
-      else {
-        (void)hipGetLastError();
-        if (r->d_replica[LAYOUT_QUAD]) (void)hipFree(r->d_replica[LAYOUT_QUAD]);
-        r->d_replica[LAYOUT_QUAD] = nullptr;
-        if (r->layouts.current == 2) return fail(OVR_HIP_EDEVICE, std::string("[hip] volume replicas requested (layouts mode 2) but the quad replica's allocation failed: ") + hipGetErrorString(e));
+        r->replica_state[LAYOUT_QUAD] = 1;
       }
     }
   }
-  (void)n_layouts;
-  for (int k = 0; k < kLayouts; ++k) { // the layouts' per-axis offset tables, staged into LDS by every march / shade workgroup
-    if (!r->d_replica[k]) continue;
-    HIP_TRY(hipMalloc(&r->d_axis[k], axis_table_bytes(r->vd_replica[k])));
-    HIP_TRY(launch_axis_tables(r->vd_replica[k], r->d_axis[k], st_));
-  }
+  HIP_TRY(hipMalloc(&r->d_axis[0], axis_table_bytes(r->vd_replica[0]))); // the layout's per-axis offset tables, staged into LDS by every march / shade workgroup
+  HIP_TRY(launch_axis_tables(r->vd_replica[0], r->d_axis[0], st_));
   vd = r->vd_replica[0];
   auto relayout_all = [&](const void* src, int z0, int nzc) -> hipError_t {
-    for (int k = 0; k < kLayouts; ++k)
-      if (r->d_replica[k])
-        if (hipError_t e = launch_relayout(src, value_type, r->d_replica[k], r->vd_replica[k], z0, nzc, st_)) return e;
-    return hipSuccess;
+    return launch_relayout(src, value_type, r->d_replica[0], r->vd_replica[0], z0, nzc, st_);
   };
 
   const size_t in_es = value_type_size(value_type);
   const size_t slice_bytes = (size_t)vd.nx * vd.ny * in_es;
   hipStream_t st = r->own_stream[0];
+  int src_device = r->device; // a device array may live on another GPU (a device group's followers): staged through peer copies
   if (mem_kind == OVR_HIP_MEM_DEVICE) {
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, data) == hipSuccess) src_device = attr.device;
+    else (void)hipGetLastError();
+  }
+  if (mem_kind == OVR_HIP_MEM_DEVICE && src_device == r->device) {
     // chunk over z only to keep grid.z within limits
     for (int z0 = 0; z0 < vd.nz; z0 += 32768) {
       const int nzc = std::min(32768, vd.nz - z0);
@@ -1200,7 +1555,9 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
     HIP_TRY(hipMalloc(&d_stage, slab * slice_bytes));
     for (int z0 = 0; z0 < vd.nz; z0 += (int)slab) {
       const int nzc = (int)std::min<size_t>(slab, (size_t)(vd.nz - z0));
-      hipError_t e = hipMemcpyAsync(d_stage, (const char*)data + (size_t)z0 * slice_bytes, (size_t)nzc * slice_bytes, hipMemcpyHostToDevice, st);
+      hipError_t e = mem_kind == OVR_HIP_MEM_DEVICE
+                         ? hipMemcpyPeerAsync(d_stage, r->device, (const char*)data + (size_t)z0 * slice_bytes, src_device, (size_t)nzc * slice_bytes, st)
+                         : hipMemcpyAsync(d_stage, (const char*)data + (size_t)z0 * slice_bytes, (size_t)nzc * slice_bytes, hipMemcpyHostToDevice, st);
       if (e == hipSuccess) e = relayout_all(d_stage, z0, nzc);
       if (e == hipSuccess) e = hipStreamSynchronize(st);
       if (e != hipSuccess) { (void)hipFree(d_stage); return fail(OVR_HIP_EDEVICE, std::string("[hip] volume upload failed: ") + hipGetErrorString(e)); }
@@ -1208,6 +1565,20 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
     HIP_TRY(hipFree(d_stage));
   }
   r->vd = vd;
+  if (r->layouts.current == 2) { // all planned replicas now, before the call returns
+    for (int k = 1; k < kLayouts; ++k) {
+      if (r->replica_state[k] != 1) continue;
+      std::string err;
+      (void)start_replica_build(r, k, &err);
+      if (r->replica_state[k] != 2) {
+        for (int j = 1; j < kLayouts; ++j) drop_replica(r, j);
+        return fail(OVR_HIP_EDEVICE, std::string("[hip] volume replicas requested (layouts mode 2) but their allocation failed: ") + err);
+      }
+    }
+    HIP_TRY(hipStreamSynchronize(r->build_stream));
+    for (int k = 1; k < kLayouts; ++k)
+      if (r->replica_state[k] == 2) r->replica_state[k] = 3;
+  }
   r->value_type = value_type;
   std::memcpy(r->origin, grid_origin, sizeof(r->origin));
   std::memcpy(r->spacing, grid_spacing, sizeof(r->spacing));
@@ -1230,6 +1601,7 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
   r->fb_reset = true;
   r->tune_state = 0;
   r->pool_roomy = false; // a pooled frame of THIS volume has to prove the pool (ovr_hip_pack_tiles packs early only then)
+  GROUP_FORWARD(r, ovr_hip_set_volume(m, data, mem_kind, value_type, dims, grid_origin, grid_spacing)); // replicated on every device of a group
   return 0;
 }
 
@@ -1250,8 +1622,8 @@ int ovr_hip_set_grid_convention(ovr_hip_renderer* r, int c)
 {
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
   if (c != OVR_HIP_GRID_CELL_CENTRED && c != OVR_HIP_GRID_VERTEX_CENTRED) return fail(OVR_HIP_EINVAL, "[hip] unknown grid convention");
-  std::lock_guard<std::mutex> lk(r->mtx);
-  r->grid_convention.set(c);
+  { std::lock_guard<std::mutex> lk(r->mtx); r->grid_convention.set(c); }
+  GROUP_FORWARD(r, ovr_hip_set_grid_convention(m, c));
   return 0;
 }
 
@@ -1261,26 +1633,32 @@ int ovr_hip_set_transfer_function(ovr_hip_renderer* r, const float* colors, int3
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
   if (n_colors < 0 || n_alphas < 0 || (n_colors > 0 && !colors) || (n_alphas > 0 && !alphas))
     return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_transfer_function: bad arguments");
-  std::lock_guard<std::mutex> lk(r->mtx);
-  TfnP t;
-  t.colors.assign(colors, colors + (size_t)n_colors * 3);
-  t.alphas.assign(alphas, alphas + (size_t)n_alphas * 2);
-  t.lo = lo;
-  t.hi = hi;
-  r->tfn.set(t);
+  {
+    std::lock_guard<std::mutex> lk(r->mtx);
+    TfnP t;
+    t.colors.assign(colors, colors + (size_t)n_colors * 3);
+    t.alphas.assign(alphas, alphas + (size_t)n_alphas * 2);
+    t.lo = lo;
+    t.hi = hi;
+    r->tfn.set(t);
+  }
+  GROUP_FORWARD(r, ovr_hip_set_transfer_function(m, colors, n_colors, alphas, n_alphas, lo, hi));
   return 0;
 }
 
 int ovr_hip_set_camera(ovr_hip_renderer* r, const float from[3], const float at[3], const float up[3], float fovy)
 {
   if (!r || !from || !at || !up) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_camera: null argument");
-  std::lock_guard<std::mutex> lk(r->mtx);
-  CameraP c;
-  std::memcpy(c.from, from, sizeof(c.from));
-  std::memcpy(c.at, at, sizeof(c.at));
-  std::memcpy(c.up, up, sizeof(c.up));
-  c.fovy = fovy;
-  r->camera.set(c);
+  {
+    std::lock_guard<std::mutex> lk(r->mtx);
+    CameraP c;
+    std::memcpy(c.from, from, sizeof(c.from));
+    std::memcpy(c.at, at, sizeof(c.at));
+    std::memcpy(c.up, up, sizeof(c.up));
+    c.fovy = fovy;
+    r->camera.set(c);
+  }
+  GROUP_FORWARD(r, ovr_hip_set_camera(m, from, at, up, fovy));
   return 0;
 }
 
@@ -1288,9 +1666,8 @@ int ovr_hip_set_fbsize(ovr_hip_renderer* r, int32_t w, int32_t h)
 {
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
   if (w < 0 || h < 0) return fail(OVR_HIP_EINVAL, "[hip] negative framebuffer size");
-  std::lock_guard<std::mutex> lk(r->mtx);
-  Size2 s; s.w = w; s.h = h;
-  r->fbsize.set(s);
+  { std::lock_guard<std::mutex> lk(r->mtx); Size2 s; s.w = w; s.h = h; r->fbsize.set(s); }
+  GROUP_FORWARD(r, ovr_hip_set_fbsize(m, w, h));
   return 0;
 }
 
@@ -1299,8 +1676,8 @@ int ovr_hip_set_fbsize(ovr_hip_renderer* r, int32_t w, int32_t h)
   {                                                                                                                    \
     if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");                                                        \
     if (!(check)) return fail(OVR_HIP_EINVAL, msg);                                                                    \
-    std::lock_guard<std::mutex> lk(r->mtx);                                                                            \
-    r->field.set(v);                                                                                                   \
+    { std::lock_guard<std::mutex> lk(r->mtx); r->field.set(v); }                                                       \
+    GROUP_FORWARD(r, name(m, v));                                                                                      \
     return 0;                                                                                                          \
   }
 OVR_SIMPLE_SETTER(ovr_hip_set_sample_per_pixel, spp, int32_t, v > 0, "'sample_per_pixel' should always be positive")
@@ -1318,9 +1695,8 @@ OVR_SIMPLE_SETTER(ovr_hip_set_pixel_jitter, jitter, int32_t, v == 0 || v == 1, "
 int ovr_hip_set_focus(ovr_hip_renderer* r, float cx, float cy, float scale, float base_noise)
 {
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
-  std::lock_guard<std::mutex> lk(r->mtx);
-  FocusP f; f.cx = cx; f.cy = cy; f.scale = scale; f.base_noise = base_noise;
-  r->focus.set(f);
+  { std::lock_guard<std::mutex> lk(r->mtx); FocusP f; f.cx = cx; f.cy = cy; f.scale = scale; f.base_noise = base_noise; r->focus.set(f); }
+  GROUP_FORWARD(r, ovr_hip_set_focus(m, cx, cy, scale, base_noise));
   return 0;
 }
 
@@ -1342,6 +1718,7 @@ int ovr_hip_set_noise_tile(ovr_hip_renderer* r, const float* tile, int32_t xy)
   HIP_TRY(hipMemcpy(r->d_noise, tr.data(), bytes, hipMemcpyHostToDevice));
   r->noise_xy = xy;
   r->fb_reset = true;
+  GROUP_FORWARD(r, ovr_hip_set_noise_tile(m, tile, xy));
   return 0;
 }
 
@@ -1349,6 +1726,16 @@ int ovr_hip_set_image_shard(ovr_hip_renderer* r, int32_t rank, int32_t world, in
 {
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
   if (world < 1 || rank < 0 || rank >= world || tw < 1 || th < 1) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_image_shard: bad arguments");
+  if (r->members.size() > 1) { // a device group shards the image among its members itself: only the tile size is the caller's
+    if (world != 1) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_image_shard: a device group cannot be one rank of a larger shard (use world = 1 to set its tile size)");
+    for (size_t i = 0; i < r->members.size(); ++i) {
+      ovr_hip_renderer* m = r->members[i];
+      std::lock_guard<std::mutex> lk(m->mtx);
+      ShardP s; s.rank = (int)i; s.world = (int)r->members.size(); s.tw = tw; s.th = th;
+      m->shard.set(s);
+    }
+    return 0;
+  }
   std::lock_guard<std::mutex> lk(r->mtx);
   ShardP s; s.rank = rank; s.world = world; s.tw = tw; s.th = th;
   r->shard.set(s);
@@ -1360,6 +1747,7 @@ int ovr_hip_commit(ovr_hip_renderer* r)
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
   if (int e = set_device(r)) return e;
   if (int e = finish_frame(r)) return e;
+  GROUP_FORWARD(r, ovr_hip_commit(m));
   std::lock_guard<std::mutex> lk(r->mtx);
   const bool reset_pending = r->fb_reset; // (without accumulation the flag is never consumed)
   r->fb_reset = false;
@@ -1399,8 +1787,11 @@ int ovr_hip_commit(ovr_hip_renderer* r)
   if (r->shading.update()) r->fb_reset = true;
   if (r->jitter.update()) r->fb_reset = true;
   (void)r->lds_staging.update(); // same frame either way
-  (void)r->layout_choice.update(); // every layout gives the same frame: no accumulation reset
-  (void)r->pipeline.update(); // both pipelines produce the same frame: no accumulation reset
+  // every layout and both pipelines give the same frame: no accumulation reset - but what was measured under the old setting is void
+  // (a probe must not override a layout forced meanwhile; forced -> automatic has to measure again)
+  bool tune_void = false;
+  { const int before = r->layout_choice.current; if (r->layout_choice.update() && r->layout_choice.current != before) tune_void = true; }
+  { const int before = r->pipeline.current; if (r->pipeline.update() && r->pipeline.current != before) tune_void = true; }
   if (r->skipping.update()) { r->skip_active = true; r->skip_backoff = 32; } // skipping does not change the frame either
   if (r->shard.update()) {
     r->sched_list_dirty = true;
@@ -1413,6 +1804,7 @@ int ovr_hip_commit(ovr_hip_renderer* r)
     if (keep) r->tune_recheck = 12; // only the camera moved: the measured layout / pipeline stay (see tune_recheck)
     else { r->tune_state = 0; r->tune_recheck = 0; } // ... and so are the fastest layout and pipeline
   }
+  if (tune_void) { r->tune_state = 0; r->tune_recheck = 0; }
   r->fb_reset = other_changed || only_camera_so_far || reset_pending;
   return 0;
 }
@@ -1422,6 +1814,7 @@ int ovr_hip_render_async(ovr_hip_renderer* r)
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
   if (int e = set_device(r)) return e;
   if (int e = finish_frame(r)) return e;
+  GROUP_FORWARD(r, ovr_hip_render_async(m)); // every device starts its tiles; the gather happens when the frame is resolved (group_finish)
   return enqueue_frame(r);
 }
 
@@ -1555,6 +1948,7 @@ int ovr_hip_swap(ovr_hip_renderer* r)
   if (int e = finish_frame(r)) return e;
   HIP_TRY(hipStreamSynchronize(r->stream())); // device_impl.cpp:105
   r->cur = (r->cur + 1) % 2;                  // safe_swap, optix7_common.h:366-370
+  GROUP_FORWARD(r, ovr_hip_swap(m));
   return 0;
 }
 
@@ -1598,6 +1992,7 @@ int ovr_hip_owned_tiles(const ovr_hip_renderer* r, int32_t rank, int32_t* n_tile
 int ovr_hip_pack_tiles(ovr_hip_renderer* r, float* dst, size_t dst_bytes)
 {
   if (!r || !dst) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_pack_tiles: null argument");
+  if (r->members.size() > 1) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_pack_tiles: a device group gathers its tiles itself");
   if (int e = set_device(r)) return e;
   // A frame of the pooled pipeline may still have to be rendered again (request-pool overflow: nothing was written to the
   // framebuffer and only the host can grow the pool).  Until the pool has proven roomy for this configuration (the last frame

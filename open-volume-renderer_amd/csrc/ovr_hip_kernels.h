@@ -185,6 +185,9 @@ inline bool layout_offsets_fit(const VolumeDesc& vd)
 }
 hipError_t launch_relayout(const void* src_linear, int ovr_value_type, void* dst, const VolumeDesc& vd, int z0, int nz_chunk,
                            hipStream_t stream);
+// a replica (vd: one of the _T / _TT / _Q layouts, dst = its storage) built from the volume's resident GENERAL layout: the replicas are
+// permutations of its voxels, and building them from it needs no second copy of the caller's data - they can be built later, in the background
+hipError_t launch_rebrick(const VolumeDesc& general, void* dst, const VolumeDesc& vd, hipStream_t stream);
 // per-axis offset tables of a layout: bytes of the device buffer, and the kernel that fills it ([z: nz + 1 x u64][a: na x u32]
 // [b: nb + 1 x u32]) and points vd.axis_z / vd.axis_ab into it
 size_t axis_table_bytes(const VolumeDesc& vd);
@@ -221,12 +224,12 @@ hipError_t launch_minmax_reduce(const float* minmax, unsigned long long cells, f
 // occupancy grids (one byte per 4^3 macrocells / per macrocell, both dilated by one macrocell) for the march's per-ray skip intervals
 hipError_t launch_macrocell_coarse(const float* majorant, int nx, int ny, int nz, unsigned char* out_coarse, unsigned char* out_fine, hipStream_t stream);
 
-// tile pack/unpack for the RCCL gather payload
+// tile pack/unpack for the gather payload (RCCL between processes, peer copies / RCCL inside a device group); channels = 4 (RGBA layer) or 3 (gradient layer)
 hipError_t launch_pack_tiles(const float* frame, float* dst, int width, int height, int tile_w, int tile_h, int rank, int world,
-                             hipStream_t stream);
-// rank >= 0: scatter that rank's payload; rank < 0: scatter all ranks' payloads, rank r's at src + r * rank_stride_floats
+                             hipStream_t stream, int channels = 4);
+// rank >= 0: scatter that rank's payload; rank < 0: scatter all ranks' payloads except skip_rank's, rank r's at src + r * rank_stride_floats
 hipError_t launch_unpack_tiles(const float* src, float* frame, int width, int height, int tile_w, int tile_h, int rank, int world,
-                               size_t rank_stride_floats, hipStream_t stream);
+                               size_t rank_stride_floats, hipStream_t stream, int channels = 4, int skip_rank = -1);
 // image_to_rgba8 (imageio.cpp:146-181): RGBA32F frame -> packed RGBA8, optionally flipped vertically
 hipError_t launch_rgba8(const float* rgba, uint32_t* out, int width, int height, int flip, hipStream_t stream);
 // RGBA32F frame -> RGBA half (4 x uint16 per pixel) with the float -> half rule of the reference's EXR writer

@@ -353,10 +353,28 @@ template <> struct Conv<int, float> { // array.h:78-90
   static __device__ __forceinline__ float cv(int v) { const float n = (float)v / (float)0x7fffffff; return n < -1.f ? -1.f : n; }
 };
 
-template <typename TI, typename TO, int VT>
-__global__ __launch_bounds__(256) void relayout_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int nx, int ny, int bricks_a, unsigned int macro_y,
+// where a relayout kernel reads voxel (x, y, z) from: the caller's linear array (x fastest; slices [z0, z0 + nz_chunk) of it), or the
+// resident GENERAL layout of the same volume (replicas built in the background, round 4: every replica is a permutation of the general layout's voxels)
+template <typename TI> struct SrcLinear {
+  typedef TI value_type;
+  const TI* p; int nx, ny, z0;
+  __device__ __forceinline__ TI get(size_t x, size_t y, unsigned z) const { return p[x + (size_t)nx * (y + (size_t)ny * (size_t)(z - (unsigned)z0))]; }
+};
+template <int VTB> struct SrcBricked {
+  typedef typename Vox<VTB>::T value_type;
+  const value_type* p; unsigned int macro_y; unsigned long long macro_z;
+  __device__ __forceinline__ value_type get(size_t x, size_t y, unsigned z) const
+  {
+    typedef BrickMap<VTB> M;
+    return p[(unsigned long long)(M::X((unsigned)x + 1u) + M::Y((unsigned)y, macro_y)) + M::Zlo(z) + (unsigned long long)(z >> 5) * macro_z];
+  }
+};
+
+template <typename SRC, typename TO, int VT>
+__global__ __launch_bounds__(256) void relayout_kernel(const SRC src, TO* __restrict__ dst, int nx, int ny, int bricks_a, unsigned int macro_y,
                                                       unsigned long long macro_z, int z0, int nz_chunk)
 {
+  typedef typename SRC::value_type TI;
   // layout axes (a, b, z): a = pair axis = x (y in a transposed replica), b = the other one
   // grid: x = ceil(bricks_a * SX / 256) over STORED a positions, y = nb, z = nz_chunk ; src holds slices [z0, z0 + nz_chunk)
   typedef BrickMap<VT> M;
@@ -370,7 +388,7 @@ __global__ __launch_bounds__(256) void relayout_kernel(const TI* __restrict__ sr
   const unsigned as = (unsigned)min(max((int)a - 1, 0), (TR ? ny : nx) - 1);
   const unsigned z = (unsigned)(z0 + zl);
   const size_t x = TR ? (size_t)b : (size_t)as, y = TR ? (size_t)as : (size_t)b;
-  const TI v = src[x + (size_t)nx * (y + (size_t)ny * (size_t)zl)];
+  const TI v = src.get(x, y, z);
   const unsigned m = M::div_mbx(br), bm = br - m * Vox<VT>::mbx;
   const unsigned long long off = (unsigned long long)(ar + bm * M::BV + m * M::MV) + M::Y((unsigned)b, macro_y) + M::Zlo(z) + (unsigned long long)(z >> 5) * macro_z;
   dst[off] = Conv<TI, TO>::cv(v);
@@ -378,10 +396,11 @@ __global__ __launch_bounds__(256) void relayout_kernel(const TI* __restrict__ sr
 
 // quad replicas: one thread per cell writes the cell's 2 x 2 (x, y) voxels of its z slice as one 4-vector, neighbours beyond the
 // grid replaced by the last voxel (clamp-to-edge addressing)
-template <typename TI, int VT>
-__global__ __launch_bounds__(256) void relayout_quad_kernel(const TI* __restrict__ src, typename Vox<VT>::T* __restrict__ dst, int nx, int ny, unsigned int macro_y,
+template <typename SRC, int VT>
+__global__ __launch_bounds__(256) void relayout_quad_kernel(const SRC src, typename Vox<VT>::T* __restrict__ dst, int nx, int ny, unsigned int macro_y,
                                                            unsigned long long macro_z, int z0, int nz_chunk)
 {
+  typedef typename SRC::value_type TI;
   typedef BrickMap<VT> M;
   typedef typename Vox<VT>::T TO;
   typedef typename Vox<VT>::Q Q;
@@ -390,33 +409,42 @@ __global__ __launch_bounds__(256) void relayout_quad_kernel(const TI* __restrict
   if (u > nx || zl >= nz_chunk) return;
   const int x = max(u - 1, 0), y = max(v - 1, 0);
   const int x1 = min(u, nx - 1), y1 = min(v, ny - 1);
-  const TI* sl = src + (size_t)nx * (size_t)ny * (size_t)zl;
-  Q q;
-  q.x = Conv<TI, TO>::cv(sl[x + (size_t)nx * y]); q.y = Conv<TI, TO>::cv(sl[x1 + (size_t)nx * y]);
-  q.z = Conv<TI, TO>::cv(sl[x + (size_t)nx * y1]); q.w = Conv<TI, TO>::cv(sl[x1 + (size_t)nx * y1]);
   const unsigned z = (unsigned)(z0 + zl);
+  Q q;
+  q.x = Conv<TI, TO>::cv(src.get((size_t)x, (size_t)y, z)); q.y = Conv<TI, TO>::cv(src.get((size_t)x1, (size_t)y, z));
+  q.z = Conv<TI, TO>::cv(src.get((size_t)x, (size_t)y1, z)); q.w = Conv<TI, TO>::cv(src.get((size_t)x1, (size_t)y1, z));
   const unsigned long long off = (unsigned long long)(M::X((unsigned)u) + M::Y((unsigned)v, macro_y)) + M::Zlo(z) + (unsigned long long)(z >> 5) * macro_z;
   *reinterpret_cast<Q*>(dst + off) = q;
+}
+template <typename SRC, int VT>
+static hipError_t relayout_quad_s(const SRC& src, void* dst, const VolumeDesc& vd, int z0, int nzc, hipStream_t stream)
+{
+  dim3 grid((unsigned)((vd.nx + 1 + 255) / 256), (unsigned)(vd.ny + 1), (unsigned)nzc);
+  hipLaunchKernelGGL((relayout_quad_kernel<SRC, VT>), grid, dim3(256), 0, stream, src, (typename Vox<VT>::T*)dst, vd.nx, vd.ny, vd.macro_elems * (unsigned)vd.macros_x,
+                     (unsigned long long)vd.macro_elems * (unsigned long long)vd.macros_x * (unsigned long long)vd.macros_y, z0, nzc);
+  return hipGetLastError();
 }
 template <typename TI, int VT>
 static hipError_t relayout_quad_t(const void* src, void* dst, const VolumeDesc& vd, int z0, int nzc, hipStream_t stream)
 {
-  dim3 grid((unsigned)((vd.nx + 1 + 255) / 256), (unsigned)(vd.ny + 1), (unsigned)nzc);
-  hipLaunchKernelGGL((relayout_quad_kernel<TI, VT>), grid, dim3(256), 0, stream, (const TI*)src, (typename Vox<VT>::T*)dst, vd.nx, vd.ny, vd.macro_elems * (unsigned)vd.macros_x,
-                     (unsigned long long)vd.macro_elems * (unsigned long long)vd.macros_x * (unsigned long long)vd.macros_y, z0, nzc);
-  return hipGetLastError();
+  return relayout_quad_s<SrcLinear<TI>, VT>(SrcLinear<TI>{ (const TI*)src, vd.nx, vd.ny, z0 }, dst, vd, z0, nzc, stream);
 }
 
-template <typename TI, typename TO, int VT>
-static hipError_t relayout_t(const void* src, void* dst, const VolumeDesc& vd, int z0, int nzc, hipStream_t stream)
+template <typename SRC, typename TO, int VT>
+static hipError_t relayout_s(const SRC& src, void* dst, const VolumeDesc& vd, int z0, int nzc, hipStream_t stream)
 {
   typedef BrickMap<VT> M;
   const int bricks_a = vd.macros_x * Vox<VT>::mbx;
   const int nb = Vox<VT>::kTransposed ? vd.nx : vd.ny;
   dim3 grid((unsigned)((bricks_a * M::SX + 255) / 256), (unsigned)nb, (unsigned)nzc);
-  hipLaunchKernelGGL((relayout_kernel<TI, TO, VT>), grid, dim3(256), 0, stream, (const TI*)src, (TO*)dst, vd.nx, vd.ny, bricks_a,
+  hipLaunchKernelGGL((relayout_kernel<SRC, TO, VT>), grid, dim3(256), 0, stream, src, (TO*)dst, vd.nx, vd.ny, bricks_a,
                      vd.macro_elems * (unsigned)vd.macros_x, (unsigned long long)vd.macro_elems * (unsigned long long)vd.macros_x * (unsigned long long)vd.macros_y, z0, nzc);
   return hipGetLastError();
+}
+template <typename TI, typename TO, int VT>
+static hipError_t relayout_t(const void* src, void* dst, const VolumeDesc& vd, int z0, int nzc, hipStream_t stream)
+{
+  return relayout_s<SrcLinear<TI>, TO, VT>(SrcLinear<TI>{ (const TI*)src, vd.nx, vd.ny, z0 }, dst, vd, z0, nzc, stream);
 }
 
 // layout constants the host needs to size the allocation (vd.type, nx, ny, nz and the macro-block geometry of that layout)
@@ -486,6 +514,37 @@ hipError_t launch_relayout(const void* src, int vt, void* dst, const VolumeDesc&
   case 500: return relayout_f32<double>(src, dst, vd, z0, nzc, stream);
   default: return hipErrorInvalidValue;
   }
+}
+
+// a replica from the resident general layout (the caller's array is gone by then: ovr_hip_set_volume does not keep it)
+template <int VTB>
+static hipError_t rebrick_b(const VolumeDesc& g, void* dst, const VolumeDesc& vd, int z0, int nzc, hipStream_t stream)
+{
+  typedef typename Vox<VTB>::T T;
+  const SrcBricked<VTB> src{ (const T*)g.data, g.macro_elems * (unsigned)g.macros_x, (unsigned long long)g.macro_elems * (unsigned long long)g.macros_x * (unsigned long long)g.macros_y };
+  constexpr int T1 = VTB == VOX_F32 ? VOX_F32_T : VOX_U16_T, T2 = VTB == VOX_F32 ? VOX_F32_TT : VOX_U16_TT;
+  constexpr int TQ = VTB == VOX_F32 ? VOX_F32_Q : VTB == VOX_U16 ? VOX_U16_Q : VOX_U8_Q;
+  if (vd.type == TQ) return relayout_quad_s<SrcBricked<VTB>, TQ>(src, dst, vd, z0, nzc, stream);
+  if constexpr (VTB != VOX_U8) {
+    if (vd.type == T1) return relayout_s<SrcBricked<VTB>, T, T1>(src, dst, vd, z0, nzc, stream);
+    if (vd.type == T2) return relayout_s<SrcBricked<VTB>, T, T2>(src, dst, vd, z0, nzc, stream);
+  }
+  return hipErrorInvalidValue;
+}
+hipError_t launch_rebrick(const VolumeDesc& general, void* dst, const VolumeDesc& vd, hipStream_t stream)
+{
+  for (int z0 = 0; z0 < vd.nz; z0 += 32768) { // grid.z limit
+    const int nzc = std::min(32768, vd.nz - z0);
+    hipError_t e;
+    switch (general.type) {
+    case VOX_F32: e = rebrick_b<VOX_F32>(general, dst, vd, z0, nzc, stream); break;
+    case VOX_U16: e = rebrick_b<VOX_U16>(general, dst, vd, z0, nzc, stream); break;
+    case VOX_U8: e = rebrick_b<VOX_U8>(general, dst, vd, z0, nzc, stream); break;
+    default: e = hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 // per-axis offset tables of a layout (VolumeDesc::axis_ab / axis_z), once per volume
@@ -918,36 +977,43 @@ __host__ __device__ inline int tile_slot(int tiles_x, int tx, int ty, int rank, 
 }
 
 // one thread per frame pixel.  PACK: frame -> this rank's payload (pixels of foreign tiles exit).  !PACK: payload -> frame;
-// rank >= 0 scatters that rank's payload, rank < 0 scatters ALL ranks' payloads, laid out `rank_stride` float4 apart
-template <bool PACK>
-__global__ __launch_bounds__(256) void tiles_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int width, int height,
-                                                   int tw, int th, int rank, int world, size_t rank_stride)
+// rank >= 0 scatters that rank's payload, rank < 0 scatters ALL ranks' payloads, laid out `rank_stride` pixels apart, except
+// `skip_rank`'s (the in-process device group: the gathering device rendered its own tiles in place).  C = floats per pixel: 4 = the
+// RGBA layer, 3 = the gradient layer (device_impl.cpp:271-281 maps both)
+template <bool PACK, int C>
+__global__ __launch_bounds__(256) void tiles_kernel(const float* __restrict__ src, float* __restrict__ dst, int width, int height,
+                                                   int tw, int th, int rank, int world, size_t rank_stride, int skip_rank)
 {
   const int ix = blockIdx.x * 64 + (threadIdx.x & 63), iy = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (ix >= width || iy >= height) return;
   const int tx = ix / tw, ty = iy / th;
   const int owner = (tx + ty) % world;
-  if (rank >= 0 && owner != rank) return;
+  if (rank >= 0 ? owner != rank : owner == skip_rank) return;
   const int tiles_x = (width + tw - 1) / tw;
   const int slot = tile_slot(tiles_x, tx, ty, owner, world);
   const size_t pi = (size_t)slot * tw * th + (size_t)(iy - ty * th) * tw + (size_t)(ix - tx * tw) + (rank < 0 ? (size_t)owner * rank_stride : 0);
   const size_t fi = (size_t)iy * width + ix;
-  if (PACK) dst[pi] = src[fi];
-  else dst[fi] = src[pi];
+  const size_t si = PACK ? fi : pi, di = PACK ? pi : fi;
+  if (C == 4) reinterpret_cast<float4*>(dst)[di] = reinterpret_cast<const float4*>(src)[si];
+  else {
+#pragma unroll
+    for (int c = 0; c < C; ++c) dst[di * C + c] = src[si * C + c];
+  }
 }
 
-hipError_t launch_pack_tiles(const float* frame, float* dst, int width, int height, int tw, int th, int rank, int world, hipStream_t stream)
+hipError_t launch_pack_tiles(const float* frame, float* dst, int width, int height, int tw, int th, int rank, int world, hipStream_t stream, int channels)
 {
   dim3 grid((unsigned)((width + 63) / 64), (unsigned)((height + 3) / 4));
-  hipLaunchKernelGGL((tiles_kernel<true>), grid, dim3(256), 0, stream, (const float4*)frame, (float4*)dst, width, height, tw, th, rank, world, (size_t)0);
+  if (channels == 3) hipLaunchKernelGGL((tiles_kernel<true, 3>), grid, dim3(256), 0, stream, frame, dst, width, height, tw, th, rank, world, (size_t)0, -1);
+  else hipLaunchKernelGGL((tiles_kernel<true, 4>), grid, dim3(256), 0, stream, frame, dst, width, height, tw, th, rank, world, (size_t)0, -1);
   return hipGetLastError();
 }
 hipError_t launch_unpack_tiles(const float* src, float* frame, int width, int height, int tw, int th, int rank, int world, size_t rank_stride_floats,
-                               hipStream_t stream)
+                               hipStream_t stream, int channels, int skip_rank)
 {
   dim3 grid((unsigned)((width + 63) / 64), (unsigned)((height + 3) / 4));
-  hipLaunchKernelGGL((tiles_kernel<false>), grid, dim3(256), 0, stream, (const float4*)src, (float4*)frame, width, height, tw, th, rank, world,
-                     rank_stride_floats / 4);
+  if (channels == 3) hipLaunchKernelGGL((tiles_kernel<false, 3>), grid, dim3(256), 0, stream, src, frame, width, height, tw, th, rank, world, rank_stride_floats / 3, skip_rank);
+  else hipLaunchKernelGGL((tiles_kernel<false, 4>), grid, dim3(256), 0, stream, src, frame, width, height, tw, th, rank, world, rank_stride_floats / 4, skip_rank);
   return hipGetLastError();
 }
 

@@ -98,10 +98,17 @@ def _f3(v):
 class DeviceHIP:
     """The "hip" device.  Method-for-method mirror of ovr::MainRenderer + DeviceOptix7."""
 
-    def __init__(self, device_id: int = 0):
+    def __init__(self, device_id: int = 0, devices=None):
+        """devices: several HIP device ordinals -> one in-process device group behind this object (ovr_hip_create_group: image tiles
+        sharded over the devices, gathered on devices[0]); the reference's device knows one GPU (device_impl.cpp:371-372)"""
         self._lib = L.load()
         self._h = C.c_void_p()
-        L.check(self._lib.ovr_hip_create(C.byref(self._h), int(device_id)))
+        if devices is not None and len(devices) > 0:
+            ids = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            L.check(self._lib.ovr_hip_create_group(C.byref(self._h), ids, len(devices)))
+            device_id = int(devices[0])
+        else:
+            L.check(self._lib.ovr_hip_create(C.byref(self._h), int(device_id)))
         self.device_id = int(device_id)
         self.current_scene: Optional[Scene] = None
         self.variance = float("inf")          # renderer.h:287
@@ -385,6 +392,17 @@ class DeviceHIP:
         L.check(self._lib.ovr_hip_get_stats(self._h, C.byref(s)))
         return s
 
+    def group_info(self):
+        """(devices, gather: 0 none / 1 peer copies / 2 RCCL, host milliseconds of the last frame's gather tail)"""
+        n, kind, ms = C.c_int32(), C.c_int32(), C.c_double()
+        L.check(self._lib.ovr_hip_group_info(self._h, C.byref(n), C.byref(kind), C.byref(ms)))
+        return n.value, kind.value, ms.value
+
+    def member_stats(self, member):
+        s = L.Stats()
+        L.check(self._lib.ovr_hip_get_member_stats(self._h, int(member), C.byref(s)))
+        return s
+
     # ---- stand-alone pieces for known-answer tests ----------------------------------------------------------------
     def sparse_mask(self, frame_index):
         import torch
@@ -403,9 +421,9 @@ class DeviceHIP:
         return out.cpu().numpy(), st.cpu().numpy().view(np.uint32)
 
 
-def create_renderer(name: str, device_id: int = 0):
+def create_renderer(name: str, device_id: int = 0, devices=None):
     """create_renderer(name) (reference ovr/renderer.cpp:42-61).  Only "hip" exists here; anything else raises the
-    same way the reference's factory does for an unknown device."""
+    same way the reference's factory does for an unknown device.  devices = [ordinals]: an in-process device group."""
     if name == "hip":
-        return DeviceHIP(device_id)
+        return DeviceHIP(device_id, devices)
     raise RuntimeError(f"OVR ERROR: Could not find device_{name} (only the 'hip' device is built)")

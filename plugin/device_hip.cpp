@@ -71,10 +71,26 @@ public:
   void init(int argc, const char** argv) override
   {
     if (h) throw std::runtime_error("[hip] device already initialized!");
+    // One GPU (`--hip-device N`, default 0: the reference hard-codes device 0, device_impl.cpp:371-372) or several behind this one
+    // MainRenderer: `--hip-devices 0,1,2,...` or OVR_HIP_DEVICES=0,1,2,... (the unmodified apps pass no such flag: the environment
+    // variable is their switch).  The group shards the image plane into tiles over the listed devices and gathers them on the first
+    // (ovr_hip_create_group); everything below is the same for both.
+    std::string list = std::getenv("OVR_HIP_DEVICES") ? std::getenv("OVR_HIP_DEVICES") : "";
     int device_id = 0;
-    for (int i = 1; i + 1 < argc; ++i)
+    for (int i = 1; i + 1 < argc; ++i) {
       if (std::string(argv[i]) == "--hip-device") device_id = std::stoi(argv[i + 1]);
-    check(ovr_hip_create(&h, device_id));
+      if (std::string(argv[i]) == "--hip-devices") list = argv[i + 1];
+    }
+    std::vector<int32_t> devices;
+    for (size_t at = 0; at < list.size();) {
+      const size_t comma = list.find(',', at);
+      const std::string tok = list.substr(at, comma == std::string::npos ? std::string::npos : comma - at);
+      if (!tok.empty()) devices.push_back((int32_t)std::stoi(tok));
+      if (comma == std::string::npos) break;
+      at = comma + 1;
+    }
+    if (devices.empty()) check(ovr_hip_create(&h, device_id));
+    else check(ovr_hip_create_group(&h, devices.data(), (int32_t)devices.size()));
     const auto& v = ovr::parse_single_volume_scene(current_scene, ovr::scene::Volume::STRUCTURED_REGULAR_VOLUME).structured_regular;
     const int32_t dims[3] = { v.data->dims.x, v.data->dims.y, v.data->dims.z };
     const float origin[3] = { v.grid_origin.x, v.grid_origin.y, v.grid_origin.z };

@@ -28,8 +28,8 @@ def test_library_exports_every_declared_symbol(ovr):
 
 
 def test_stats_struct_layout_matches_header(ovr):
-    # 5 x u64, 2 x f64, 2 x i32, 3 x f64, 3 x u64, 2 x i32, 3 x u64, 2 x i32 (ABI v6: skipping_kernels; v7: tuning)
-    assert C.sizeof(ovr._lib.Stats) == 5 * 8 + 2 * 8 + 2 * 4 + 3 * 8 + 3 * 8 + 2 * 4 + 3 * 8 + 2 * 4
+    # 5 x u64, 2 x f64, 2 x i32, 3 x f64, 3 x u64, 2 x i32, 3 x u64, 3 x i32 + padding (ABI v6: skipping_kernels; v7: tuning; v8: replicas_building)
+    assert C.sizeof(ovr._lib.Stats) == 5 * 8 + 2 * 8 + 2 * 4 + 3 * 8 + 3 * 8 + 2 * 4 + 3 * 8 + 4 * 4
     # the same fields, in the same order, as the header's struct
     import re
     hdr = open(os.path.join(ROOT, "include", "ovr_hip.h")).read()
@@ -86,6 +86,13 @@ def test_addressing_mode_selection(ovr):
     assert mode((64, 64, 64), 100, layout=3) == 0       # ... but a quad replica, like 16-bit and float volumes
     assert mode((2048, 2048, 2048), 200, layout=3) == 2 # C4's would be 64 GiB
     assert mode((64, 64, 64), 201, layout=3) < 0        # signed types: general layout only
+    # (round 4) the taps add the in-plane offsets X + Y in 32 bits: a layout whose z layer of macro blocks holds more than 2^32
+    # elements would alias cells silently - a slab-shaped 8192 x 8192 x 64 u8 volume's quad replica (17 GB, inside the 40 % rule) did; such a
+    # layout is not built, and the query says so
+    assert mode((8192, 8192, 64), 100, layout=0) >= 0
+    assert mode((8192, 8192, 64), 100, layout=3) < 0 and b"2^32" in lib.ovr_hip_last_error()
+    assert mode((4095, 8190, 64), 100, layout=3) >= 0      # 128 x 256 macro blocks of 2^17 elements: exactly 2^32
+    assert mode((20000, 20000, 8), 100, layout=0) < 0   # ... and the general layout beyond ~16 k x 16 k is refused by ovr_hip_set_volume
 
 
 def test_no_cpu_fallback(ovr):

@@ -336,16 +336,35 @@ def test_layouts_are_bit_identical(ovr, oracle, hip_renderer_factory, dtype, cam
     ren.close()
 
 
+def _render_until_layout(ovr, ren, layout, limit=500):
+    """replicas are built in the background (round 4): frames read the general layout until the one the rule asks for is resident -
+    every frame on the way is the same frame bit for bit"""
+    import time
+    ren.render()
+    first = hip_frame(ovr, ren)
+    seen = [ren.stats().layout]
+    for _ in range(limit):
+        st = ren.stats()
+        if st.layout == layout and st.replicas_building == 0:
+            break
+        time.sleep(0.002)
+        ren.render()
+        seen.append(ren.stats().layout)
+        rgba, grad = hip_frame(ovr, ren)
+        assert np.array_equal(rgba, first[0]) and np.array_equal(grad, first[1])
+    return seen
+
+
 def test_layout_follows_the_camera(ovr, oracle, hip_renderer_factory):
-    """within ~18 degrees of a volume axis the frame reads a thin replica (pair axis off that axis); types without replicas and
-    renderers told not to build them stay on the general layout"""
+    """within ~18 degrees of a volume axis the frame reads a thin replica (pair axis off that axis) - once it has been built in the background;
+    types without replicas and renderers told not to build them stay on the general layout"""
     dims = (40, 40, 40)
     expect = {"x": 2, "y": 1, "z": 2, "oblique": 0}   # along z either thin replica serves: the one wide in the drift direction (x here)
     for cam, layout in expect.items():
         case = _layout_case(ovr, oracle, np.float32, dims, cam, shading=1, size=(48, 32))
         ren = hip_setup(ovr, hip_renderer_factory(), case)
-        ren.render()
-        assert ren.stats().layout == layout, cam
+        seen = _render_until_layout(ovr, ren, layout)
+        assert ren.stats().layout == layout and set(seen) <= {0, layout}, (cam, seen)
         ren.close()
     case = _layout_case(ovr, oracle, np.uint8, dims, "z", shading=1, size=(48, 32))
     ren = hip_setup(ovr, hip_renderer_factory(), case)
@@ -361,8 +380,16 @@ def test_layout_follows_the_camera(ovr, oracle, hip_renderer_factory):
     assert ren.stats().layout == 0
     ren.close()
     ren = hip_setup(ovr, hip_renderer_factory(), case)
-    assert ren.volume_info().resident_bytes > 3 * general_only
-    # anisotropic spacing: the choice is made in object space (a view along world z is still along the volume's z)
+    assert ren.volume_info().resident_bytes == general_only   # (round 4) nothing but the general layout until a frame asks for a replica
+    _render_until_layout(ovr, ren, 2)
+    assert ren.stats().layout == 2 and 2 * general_only < ren.volume_info().resident_bytes < 3 * general_only   # + the one thin replica
+    ren.close()
+    ren = hip_renderer_factory()
+    ren.set_volume_layouts(2)                                    # mode 2: every replica resident when ovr_hip_set_volume returns
+    hip_setup(ovr, ren, case)
+    assert ren.volume_info().resident_bytes > 6 * general_only
+    ren.render()
+    assert ren.stats().layout == 2 and ren.stats().replicas_building == 0
     ren.close()
 
 

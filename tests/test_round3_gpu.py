@@ -52,11 +52,19 @@ def test_measured_choice_keeps_the_frames(ovr, oracle, hip_renderer_factory, rat
     compare(oracle, seq[-1][0], o_rgba, name=f"tuned rate {rate}")
     # a camera that moves keeps the measured decision (an interactive session never rests long enough to be measured again) ...
     won = (seq[-1][2], seq[-1][3])
-    ren.set_camera(ovr.Camera(*ovr.synth.make_camera("front", 40), 60.0))
+    eye, at, up = case["cam"]
+    ren.set_camera(ovr.Camera(tuple(c * 1.05 for c in eye), at, up, 60.0))   # still an oblique view: the layout rule says what it said
     ren.commit()
     ren.render()
     st = ren.stats()
     assert st.tuning == 2 and (st.layout, st.pipeline) == won
+    # (round 4) ... but a measured LAYOUT only while the layout rule still says what it said when the measurement was made: along an
+    # axis the rule asks for a thin replica, and general / quad were never measured against that - the rule's layout, the measured pipeline
+    ren.set_camera(ovr.Camera(*ovr.synth.make_camera("front", 40), 60.0))
+    ren.commit()
+    ren.render()
+    st = ren.stats()
+    assert st.layout in (1, 2) and st.pipeline == won[1] and st.tuning in (0, 2), (st.layout, st.pipeline, st.tuning)
     later = []
     for _ in range(16):     # ... and measures again once the configuration has rested for a dozen frames
         ren.render()
