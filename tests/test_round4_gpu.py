@@ -251,3 +251,58 @@ def test_renderbatch_on_a_device_group(tmp_path, ovr):
     from PIL import Image
     import io
     assert (np.asarray(Image.open(io.BytesIO(pngs["group"])).convert("RGBA"))[..., 3] > 0).mean() > 0.05
+
+
+# ---- the interactive app's two threads through the plugin ------------------------------------------------------------------
+
+def test_two_thread_renderapp_contract_through_the_plugin(tmp_path, ovr, hip_renderer_factory):
+    """oracle/_ref/plugin_probe --stress (oracle/plugin_probe.cpp, built against the reference's headers): a setter thread calls set_camera /
+    set_transfer_function / set_focus at random moments while the render thread runs renderapp's loop - commit, mapframe, swap, render
+    (apps/main_app.cpp:233-278) - and a reader thread checksums the mapped buffer during the following render().  10 000 iterations: every
+    mapped frame is the frame of exactly ONE of the 12 states (never a mixture, no torn rectangle from the cropped mapframe copy), the
+    published buffer does not change under the reader, and the 12 reference frames are what the Python host renders for the same inputs."""
+    import subprocess
+    probe = os.path.join(ROOT, "oracle", "_ref", "plugin_probe")
+    plugin = os.path.join(ROOT, "plugin", "libdevice_hip.so")
+    if not (os.path.exists(probe) and os.path.exists(plugin)):
+        pytest.skip("oracle/_ref/plugin_probe or plugin/libdevice_hip.so missing (built by __graft_entry__.build() where the reference tree is present)")
+    n, W, H = 48, 160, 104
+    vol = ovr.synth.make_volume(n, np.float32)
+    colors, alphas, vr = ovr.synth.make_tfn("bumps", 256)
+    cam = ovr.synth.make_camera("oblique", n)
+    scene_path = ovr.vidi3d.write_scene(str(tmp_path), "synthetic", vol, ovr.synth._RAINBOW, alphas[1::2].copy(), (0.0, 1.0), cam, fovy=45.0, sample_distance=1.0)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.dirname(plugin), os.path.join(ROOT, "open-volume-renderer_amd"), env.get("LD_LIBRARY_PATH", "")])
+    out = subprocess.run([probe, "--stress", "10000", scene_path, str(W), str(H), str(tmp_path / "stress")], env=env, cwd=str(tmp_path), capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    import re
+    line = [l for l in out.stdout.splitlines() if l.startswith("stress:")][-1]
+    rep = {k: int(v) for k, v in re.findall(r"(\w+) (\d+)", line)}
+    assert rep["iterations"] == rep["frames_checked"] == 10000 and rep["not_a_reference_frame"] == 0 and rep["torn"] == 0, line
+    assert rep["distinct_frames_seen"] >= 8 and rep["reader_checks"] > 1000 and rep["setter_calls"] > 1000, line
+    # the probe's reference frames against the Python host (same C ABI, the same inputs read back from the probe's dump)
+    raw = np.fromfile(str(tmp_path / "stress_states.bin"), dtype=np.uint8)
+    K, M, nc, na, w, h = np.frombuffer(raw[:24].tobytes(), dtype=np.int32)
+    f = np.frombuffer(raw[24:].tobytes(), dtype=np.float32)
+    cams = f[:K * 9].reshape(K, 3, 3); f = f[K * 9:]
+    tf_colors = f[:nc * 3].copy(); f = f[nc * 3:]
+    tf_alphas = f[:M * na * 2].reshape(M, na * 2).copy(); f = f[M * na * 2:]
+    tf_range = tuple(float(x) for x in f[:2]); f = f[2:]
+    frames = f.reshape(K * M, h, w, 4)
+    scene, camera = ovr.vidi3d.scene_from_file(scene_path)
+    ren = hip_renderer_factory()
+    ren.set_fbsize((int(w), int(h)))
+    ren.set_frame_accumulation(False)
+    ren.set_volume_sampling_rate(1.0)
+    ren.init(scene, camera)
+    ren.set_empty_space_skipping(True)   # the plugin's default
+    for k in range(K):
+        for m in range(M):
+            ren.set_camera(tuple(cams[k, 0]), tuple(cams[k, 1]), tuple(cams[k, 2]))
+            ren.set_transfer_function(tf_colors, tf_alphas[m], tf_range)
+            ren.commit()
+            ren.render()
+            assert np.array_equal(hip_frame(ovr, ren)[0], frames[k * M + m]), (k, m)
+    assert len({fr.tobytes() for fr in frames}) == K * M   # the states really differ
+    ren.close()
