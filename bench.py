@@ -806,7 +806,11 @@ def worker(args, world):
                 extra["c3_shard_of_8"] = run_extra_leg(["--shard-of", "8", "--steps", "20", "--warmup", "5"], 300)
                 extra["c3_device_group_rehearsal"] = run_extra_leg(["--devices", "0,0", "--steps", "10", "--warmup", "5"], 300)
             else:
-                extra["c3_device_group"] = run_extra_leg(["--devices", ",".join(str(i) for i in range(world)), "--steps", str(args.steps), "--warmup", str(args.warmup)], 420)
+                devs = ",".join(str(i) for i in range(world))
+                extra["c3_device_group"] = run_extra_leg(["--devices", devs, "--steps", str(args.steps), "--warmup", str(args.warmup)], 420)
+                os.environ["OVR_HIP_GATHER"] = "copy"   # the same group with peer-to-peer copies instead of RCCL send / recv
+                extra["c3_device_group_peer_copies"] = run_extra_leg(["--devices", devs, "--steps", str(args.steps), "--warmup", str(args.warmup)], 420)
+                del os.environ["OVR_HIP_GATHER"]
             out["extra"] = extra
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -1188,10 +1188,15 @@ int group_ship(ovr_hip_renderer* L, ovr_hip_renderer* m)
       if (rc == 0) rc = N.Recv(L->d_gather[c] + (size_t)m->group_rank * L->group_stride[c], m->payload_floats[c], kNcclFloat, m->group_rank, L->rccl_comm, L->comm_stream);
     }
     const int rc2 = N.GroupEnd();
-    if (rc != 0 || rc2 != 0) return fail(OVR_HIP_EDEVICE, std::string("[hip] RCCL send / recv of a group member's tiles failed: ") + (N.GetErrorString ? N.GetErrorString(rc != 0 ? rc : rc2) : "?"));
-    HIP_TRY(hipEventRecord(m->ev_shipped, L->comm_stream)); // the receive side: ordered after every earlier member's receive on that stream
-    (void)n;
-    return 0;
+    if (rc == 0 && rc2 == 0) {
+      HIP_TRY(hipEventRecord(m->ev_shipped, L->comm_stream)); // the receive side: ordered after every earlier member's receive on that stream
+      (void)n;
+      return 0;
+    }
+    // RCCL refused the pair: this group goes on with peer copies (same bytes, same destination), and says so once
+    fprintf(stderr, "[hip] RCCL send / recv of a group member's tiles failed (%s): falling back to peer copies\n", N.GetErrorString ? N.GetErrorString(rc != 0 ? rc : rc2) : "?");
+    L->gather_kind = 1;
+    HIP_TRY(hipSetDevice(m->device));
   }
   for (int c = 0; c < 2; ++c) {
     if (c == 1 && !L->group_grad) break;

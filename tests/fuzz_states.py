@@ -21,6 +21,11 @@ LONG = __import__('os').environ.get('OVR_FUZZ_LONG') == '1'
 # collective on its own stream, the scatter one call later - and the gathered frame must equal the device frame
 GATHER = __import__('os').environ.get('OVR_FUZZ_GATHER') == '1'
 NONFINITE = __import__('os').environ.get('OVR_FUZZ_NONFINITE') == '1'   # float volumes with a few NaN / Inf voxels
+# (round 4) OVR_FUZZ_GROUP=N: the renderer is an in-process device group of N members on device 0 (ovr_hip_create_group: tiles dealt over the
+# members, gathered on the leader) - every frame must still be the oracle's WHOLE frame; the shard transition becomes a tile-size change.
+# OVR_FUZZ_LAZY=1: the default layouts mode - replicas are built in the background when a frame first asks for one - instead of all at upload
+GROUP = int(__import__('os').environ.get('OVR_FUZZ_GROUP', '0'))
+LAZY = __import__('os').environ.get('OVR_FUZZ_LAZY') == '1'
 if GATHER:
     import torch
     import torch.distributed as dist
@@ -43,8 +48,9 @@ def episode(ep):
         v = case["vol"]
         idx = rng.integers(0, v.size, 6)
         v.reshape(-1)[idx] = np.array([np.nan, np.inf, -np.inf, np.nan, 3.0e38, -3.0e38], np.float32)
-    ren = ovr.create_renderer("hip")
-    ren.set_volume_layouts(2)
+    ren = ovr.create_renderer("hip", devices=[0] * GROUP) if GROUP > 1 else ovr.create_renderer("hip")
+    if not LAZY:
+        ren.set_volume_layouts(2)
     hip_setup(ovr, ren, case, accumulate=True, pipeline=0)
     ren.set_noise_tile(noise)
     gat = [None]
@@ -159,6 +165,9 @@ def episode(ep):
                 ren.set_sparse_sampling(sparse); log.append(f"sparse {sparse} {focus}")
             elif op == 9 and GATHER:
                 log.append("render only (no shard changes under the gather)")
+            elif op == 9 and GROUP > 1:
+                tw, th = int(rng.choice([4, 8, 16, 24])), int(rng.choice([4, 8, 16]))
+                ren.set_image_shard(0, 1, tw, th); log.append(f"group tile size {tw}x{th}")
             elif op == 9:
                 shard = None if rng.integers(2) else (int(rng.integers(0, 2)), 2, int(rng.choice([8, 16])), int(rng.choice([8, 16])))
                 ren.set_image_shard(*(shard or (0, 1, 16, 16))); log.append(f"shard {shard}")
