@@ -7,10 +7,10 @@ export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py "$@" --no-cpu-baseline --no-views --no-skip-leg > $out/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py "$@" --no-cpu-baseline --no-views --no-skip-leg --no-extras > $out/stats.log 2>&1
 for set in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS" "TA_BUSY_sum TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TD_TD_BUSY_sum"; do
   n=$(echo $set | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc_$n -- python3 bench.py "$@" --no-cpu-baseline --no-views --no-skip-leg > $out/pmc_$n.log 2>&1 || echo "pmc set failed: $set" >> $out/errors.log
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc_$n -- python3 bench.py "$@" --no-cpu-baseline --no-views --no-skip-leg --no-extras > $out/pmc_$n.log 2>&1 || echo "pmc set failed: $set" >> $out/errors.log
 done
 python3 - <<PY
 import csv, glob, os, collections
