@@ -455,10 +455,16 @@ def worker(args, world):
             flag = torch.tensor([1 if mine else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             return bool(flag.item())
-        extra = 0
-        while extra < 16 and step.count > 0 and unsettled():
+        extra, t_settle = 0, time.perf_counter()
+        while extra < 64 and step.count > 0 and time.perf_counter() - t_settle < 3.0 and unsettled():
             step()
             extra += 1
+            if ren.stats().replicas_building > 0:
+                time.sleep(0.002)   # a replica is being re-bricked on the side stream: let it have the memory system for a moment
+        if extra:
+            for _ in range(warmup):   # the first frames on a replica that has just become resident page it in: warm-up again
+                step()
+                extra += 1
         timed_leg.extra_warmup = extra
         if dist is not None:
             dist.barrier()
@@ -564,6 +570,19 @@ def worker(args, world):
         ren.commit()
         for _ in range(args.warmup):
             ren.render()
+        # (with most samples skipped the frame is shade-heavy: the renderer measures its alternatives, the quad replica is built for it -
+        # warm-up, like in timed_leg; the frame count of the accumulation is made up to the plain leg's below)
+        n_settle, t_settle = 0, time.perf_counter()
+        while n_settle < 64 and time.perf_counter() - t_settle < 3.0 and (ren.stats().tuning == 1 or ren.stats().replicas_building > 0):
+            ren.render()
+            n_settle += 1
+            if ren.stats().replicas_building > 0:
+                time.sleep(0.002)
+        if n_settle:
+            set_cam()
+            ren.commit()
+            for _ in range(args.warmup):
+                ren.render()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
@@ -574,7 +593,9 @@ def worker(args, world):
         st1 = ren.stats()
         skip_leg = {"fps": args.steps / dt1, "ms_per_step": dt1 / args.steps * 1e3, "frames_bit_identical": bool(torch.equal(plain, fb.rgba.data())),
                     "samples_fetched_per_frame": int(st1.samples), "samples_skipped_per_frame": int(st1.skipped_samples),
-                    "shadow_samples_skipped_per_frame": int(st1.skipped_shadow_samples)}
+                    "shadow_samples_skipped_per_frame": int(st1.skipped_shadow_samples),
+                    "layout": ["general", "thin", "thin transposed", "quad"][st1.layout], "pipeline": "pooled" if st1.pipeline == 2 else "in place",
+                    "tuning": ["rules", "probing", "measured choice"][st1.tuning], "phase_ms_last_frame": {"march": st1.march_ms, "shade": st1.shade_ms, "composite": st1.composite_ms}}
         ren.set_empty_space_skipping(False)
         ren.commit()
 
@@ -606,6 +627,8 @@ def worker(args, world):
                 "kernel": dom, "bound": kern[dom]["bound"] if dom else None, "frac": kern[dom]["frac"] if dom else None, "unit": kern[dom]["unit"] if dom else None,
                 "utilisation": kern[dom].get("utilisation") if dom else None, "traffic": kern[dom]["traffic"] if dom else None,
                 "kernel_fracs": {k: v["frac"] for k, v in kern.items()}, "kernel_bounds": {k: v["bound"] for k, v in kern.items()},
+                "layout": ["general", "thin", "thin transposed", "quad"][leg["last"].layout], "pipeline": "pooled" if leg["last"].pipeline == 2 else "in place",
+                "extra_warmup": timed_leg.extra_warmup if leg is not main_leg else main_extra_warmup,
                 "pipeline_frac": abytes / (leg["kernel_ms"] / vsteps * 1e-3) / 1e9 / HBM_PEAK_GBS if leg["kernel_ms"] > 0 else None}
         ren.set_transfer_function(colors, alphas, vr)
         set_cam()

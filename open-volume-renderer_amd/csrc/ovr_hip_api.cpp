@@ -19,7 +19,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -112,7 +114,7 @@ struct ovr_hip_renderer {
 
   // volume: d_volume / vd = the general layout (always resident); replica[1..2] = the thin layouts, [3] = the quad layout (ovr_hip_kernels.h), if built
   void* d_volume = nullptr;
-  size_t volume_bytes = 0; // all resident replicas
+  std::atomic<size_t> volume_bytes{ 0 }; // all resident replicas (a builder thread adds its replica's)
   VolumeDesc vd{};
   void* d_replica[kLayouts] = {};  // [3] = the quad replica (f32 volumes)
   void* d_axis[kLayouts] = {}; // per layout: its per-axis offset tables (VolumeDesc::axis_ab / axis_z)
@@ -122,8 +124,12 @@ struct ovr_hip_renderer {
   // build_stream the first time the layout rule, the tuner or a forced choice asks for it.  Every layout gives the same frame bit for bit,
   // so frames keep rendering from the general layout until the build has finished (a forced choice and the tuner's probes wait for it on the
   // device).  C3: 40 GB and four relayout passes at every ovr_hip_set_volume became 5.9 GB and one.
-  //   0 = no such replica, 1 = planned (vd_replica[k] is its geometry, nothing allocated), 2 = being built (build_ev[k] pending), 3 = resident
-  int replica_state[kLayouts] = {};
+  //   0 = no such replica, 1 = planned (vd_replica[k] is its geometry, nothing allocated), 4 = a builder thread is allocating it and
+  //   enqueueing its construction (hipMalloc of C3's 8.8 GB thin replica takes 0.25 s of HOST time: not on the render thread),
+  //   2 = being built on the device (build_ev[k] pending), 3 = resident.  The builder publishes vd_replica[k] / d_replica[k] / d_axis[k]
+  //   before it stores 2 (release); the render thread reads them only after it has seen 2 or 3 (acquire).
+  std::atomic<int> replica_state[kLayouts] = {};
+  std::thread builder[kLayouts];
   hipStream_t build_stream = nullptr;
   hipEvent_t build_ev[kLayouts] = {};
   Queued<int> layouts;      // ovr_hip_set_volume_layouts: which replicas the next ovr_hip_set_volume plans (2: builds at once)
@@ -637,58 +643,82 @@ int build_schedule_list(ovr_hip_renderer* r)
 }
 
 // ---- replicas built in the background (see replica_state)
+void join_builders(ovr_hip_renderer* r)
+{
+  for (int k = 0; k < kLayouts; ++k)
+    if (r->builder[k].joinable()) r->builder[k].join();
+}
+
 void drop_replica(ovr_hip_renderer* r, int k)
 {
-  if (r->d_replica[k] && k != LAYOUT_GENERAL) { (void)hipFree(r->d_replica[k]); r->volume_bytes -= (size_t)r->vd_replica[k].bytes; }
-  if (r->d_axis[k] && k != LAYOUT_GENERAL) (void)hipFree(r->d_axis[k]);
-  if (k != LAYOUT_GENERAL) { r->d_replica[k] = nullptr; r->d_axis[k] = nullptr; }
+  if (k == LAYOUT_GENERAL) return;
+  if (r->builder[k].joinable()) r->builder[k].join();
+  if (r->d_replica[k]) { (void)hipFree(r->d_replica[k]); r->volume_bytes -= (size_t)r->vd_replica[k].bytes; }
+  if (r->d_axis[k]) (void)hipFree(r->d_axis[k]);
+  r->d_replica[k] = nullptr; r->d_axis[k] = nullptr;
   r->replica_state[k] = 0;
 }
 
-// allocate replica k and enqueue its construction from the general layout on build_stream; on an allocation failure the replica is
-// given up (an optimisation: the general layout renders the same frames) and `err` says why
-int start_replica_build(ovr_hip_renderer* r, int k, std::string* err)
+// allocate replica k and enqueue its construction from the general layout on build_stream (host work: on the calling thread); on an
+// allocation failure the replica is given up (an optimisation: the general layout renders the same frames) and `err` says why.
+// Expects replica_state[k] == 4 (claimed); leaves 2 (enqueued) or 0 (given up).
+void build_replica_host(ovr_hip_renderer* r, int k, std::string* err)
 {
-  if (r->replica_state[k] != 1) return 0;
-  VolumeDesc& t = r->vd_replica[k];
-  hipError_t e = hipMalloc(&r->d_replica[k], (size_t)t.bytes + 64); // + slack: the pair load of the very last element
-  if (e == hipSuccess) e = hipMalloc(&r->d_axis[k], axis_table_bytes(t));
+  (void)hipSetDevice(r->device);
+  VolumeDesc t = r->vd_replica[k];
+  void *d_data = nullptr, *d_tab = nullptr;
+  hipError_t e = hipMalloc(&d_data, (size_t)t.bytes + 64); // + slack: the pair load of the very last element
+  if (e == hipSuccess) e = hipMalloc(&d_tab, axis_table_bytes(t));
   if (e == hipSuccess) {
-    t.data = r->d_replica[k];
-    r->volume_bytes += (size_t)t.bytes;
-    e = hipMemsetAsync(r->d_replica[k], 0, (size_t)t.bytes + 64, r->build_stream); // padding voxels are never sampled, but must be finite
+    t.data = d_data;
+    e = hipMemsetAsync(d_data, 0, (size_t)t.bytes + 64, r->build_stream); // padding voxels are never sampled, but must be finite
   }
-  if (e == hipSuccess) e = launch_axis_tables(t, r->d_axis[k], r->build_stream);
+  if (e == hipSuccess) e = launch_axis_tables(t, d_tab, r->build_stream);
   if (e == hipSuccess) {
     VolumeDesc g = r->vd_replica[LAYOUT_GENERAL];
     g.data = r->d_volume;
-    e = launch_rebrick(g, r->d_replica[k], t, r->build_stream);
+    e = launch_rebrick(g, d_data, t, r->build_stream);
   }
   if (e == hipSuccess) e = hipEventRecord(r->build_ev[k], r->build_stream);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     (void)hipStreamSynchronize(r->build_stream);
     if (err) *err = hipGetErrorString(e);
-    if (r->d_replica[k] && t.data) r->volume_bytes -= (size_t)t.bytes;
-    if (r->d_replica[k]) (void)hipFree(r->d_replica[k]);
-    if (r->d_axis[k]) (void)hipFree(r->d_axis[k]);
-    r->d_replica[k] = nullptr; r->d_axis[k] = nullptr; t.data = nullptr;
-    r->replica_state[k] = 0;
-    return 0;
+    if (d_data) (void)hipFree(d_data);
+    if (d_tab) (void)hipFree(d_tab);
+    r->replica_state[k].store(0, std::memory_order_release);
+    return;
   }
-  r->replica_state[k] = 2;
+  r->vd_replica[k] = t;
+  r->d_replica[k] = d_data;
+  r->d_axis[k] = d_tab;
+  r->volume_bytes += (size_t)t.bytes;
+  r->replica_state[k].store(2, std::memory_order_release);
+}
+
+// a planned replica is wanted: in the background (a builder thread does the host work; frames go on from the general layout) or at once
+int start_replica_build(ovr_hip_renderer* r, int k, std::string* err, bool background = true)
+{
+  int planned = 1;
+  if (!r->replica_state[k].compare_exchange_strong(planned, 4)) return 0; // not planned, or already on its way
+  if (r->builder[k].joinable()) r->builder[k].join();
+  static const bool threads = !(getenv("OVR_HIP_BUILD_THREAD") && atoi(getenv("OVR_HIP_BUILD_THREAD")) == 0); // measurements: 0 = host work on the caller
+  if (background && threads) r->builder[k] = std::thread(build_replica_host, r, k, nullptr);
+  else build_replica_host(r, k, err);
   return 0;
 }
 
 // the layout a frame on stream `st` reads when it asks for `choice`: the replica if it is resident; if it is still being built, the replica
-// when the frame may wait for it on the device (forced choice, tuner), else the general layout (same frame bit for bit)
+// when the frame may wait for it (forced choice), else the general layout (same frame bit for bit)
 int resolve_layout(ovr_hip_renderer* r, int choice, bool may_wait, hipStream_t st)
 {
-  if (choice <= LAYOUT_GENERAL || choice >= kLayouts || r->replica_state[choice] == 0) return LAYOUT_GENERAL;
-  if (r->replica_state[choice] == 1) (void)start_replica_build(r, choice, nullptr);
-  if (r->replica_state[choice] == 2 && hipEventQuery(r->build_ev[choice]) == hipSuccess) r->replica_state[choice] = 3;
-  if (r->replica_state[choice] == 3) return choice;
-  if (r->replica_state[choice] == 2 && may_wait && hipStreamWaitEvent(st, r->build_ev[choice], 0) == hipSuccess) return choice;
+  if (choice <= LAYOUT_GENERAL || choice >= kLayouts || r->replica_state[choice].load(std::memory_order_acquire) == 0) return LAYOUT_GENERAL;
+  if (r->replica_state[choice] == 1) (void)start_replica_build(r, choice, nullptr, !may_wait);
+  if (r->replica_state[choice] == 4 && may_wait && r->builder[choice].joinable()) r->builder[choice].join(); // the host part of the build
+  int state = r->replica_state[choice].load(std::memory_order_acquire);
+  if (state == 2 && hipEventQuery(r->build_ev[choice]) == hipSuccess) { r->replica_state[choice] = 3; state = 3; }
+  if (state == 3) return choice;
+  if (state == 2 && may_wait && hipStreamWaitEvent(st, r->build_ev[choice], 0) == hipSuccess) return choice;
   (void)hipGetLastError();
   return LAYOUT_GENERAL;
 }
@@ -783,16 +813,31 @@ int enqueue_frame(ovr_hip_renderer* r)
       }
       else if (r->tune_state == 1) {
         const auto& c = r->tune_cand[r->tune_cur];
-        if (tune_l && c.layout >= 0) { choice = c.layout; may_wait = true; } // (a forced layout is never overridden by a probe)
-        r->tune_pipeline = c.pipeline;
-        r->tune_frame = r->tune_cur;
+        // Nothing is probed while ANY replica is being built in the background: the frame runs the rules' choice and counts for nothing.
+        // Waiting for the candidate's own replica on the device would stall an interactive frame for the length of the build (24 ms for
+        // C3's 17 GB quad replica), and a candidate timed beside a build is timed wrong - the build has the memory system: the rules'
+        // candidate measured 4.7 instead of 1.2 ms that way and lost to the quad replica it beats (profiles/r04_notes.md section 4)
+        if (tune_l && c.layout > LAYOUT_GENERAL && r->replica_state[c.layout] == 1) (void)start_replica_build(r, c.layout, nullptr);
+        bool ready = true;
+        for (int k = 1; k < kLayouts; ++k) {
+          int state = r->replica_state[k].load(std::memory_order_acquire);
+          if (state == 2 && hipEventQuery(r->build_ev[k]) == hipSuccess) { r->replica_state[k] = 3; state = 3; }
+          if (state == 2 || state == 4) ready = false;
+        }
+        (void)hipGetLastError();
+        if (ready) {
+          if (tune_l && c.layout >= 0) choice = c.layout; // (a forced layout is never overridden by a probe)
+          r->tune_pipeline = c.pipeline;
+          r->tune_frame = r->tune_cur;
+        }
+        else r->tune_pipeline = r->tune_cand[0].pipeline; // the pipeline the rules' frame ran (tune_cand[0] was filled in by its finish)
       }
       else if (r->tune_layout >= 0 && tune_l) {
         // a measured layout outlives camera moves only while the layout rule still says what it said when the measurement was made:
         // the thin replicas are view-dependent (an axis view's winner loses 30-60 % at an oblique angle), and general / quad were
         // measured against THAT rule's choice.  The measured pipeline stays (the regime decides it, not the view).
         if (rule_choice != r->tune_rule_choice) r->tune_layout = -1;
-        else { choice = r->tune_layout; may_wait = true; }
+        else choice = r->tune_layout; // (probed, hence resident)
       }
     }
     choice = resolve_layout(r, choice, may_wait, st);
@@ -975,8 +1020,9 @@ int finish_frame_one(ovr_hip_renderer* r)
   r->stats.skipping_kernels = r->frame_used_skip ? 1 : 0;
   r->stats.replicas_building = 0;
   for (int k = 1; k < kLayouts; ++k) {
-    if (r->replica_state[k] == 2 && hipEventQuery(r->build_ev[k]) == hipSuccess) r->replica_state[k] = 3;
-    if (r->replica_state[k] == 2) r->stats.replicas_building++;
+    int state = r->replica_state[k].load(std::memory_order_acquire);
+    if (state == 2 && hipEventQuery(r->build_ev[k]) == hipSuccess) { r->replica_state[k] = 3; state = 3; }
+    if (state == 2 || state == 4) r->stats.replicas_building++;
   }
   (void)hipGetLastError(); // hipErrorNotReady of the query is not an error
   r->stats.tuning = r->tune_frame >= 0 ? 1 : (r->tune_on && r->tune_state == 2 && (r->tune_layout >= 0 || r->tune_pipeline != 0)) ? 2 : 0;
@@ -1293,7 +1339,12 @@ int ovr_hip_create(ovr_hip_renderer** out, int device_id)
     HIP_TRY(hipStreamCreate(&r->own_stream[0]));
     HIP_TRY(hipStreamCreate(&r->own_stream[1]));
     for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&r->ev[i]));
-    HIP_TRY(hipStreamCreate(&r->build_stream));
+    {
+      // replicas are built at the highest stream priority: the sooner a replica is resident, the sooner the frames that asked for it get faster
+      int lo = 0, hi = 0;
+      if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+      HIP_TRY(hipStreamCreateWithPriority(&r->build_stream, hipStreamNonBlocking, hi));
+    }
     for (int k = 0; k < kLayouts; ++k) HIP_TRY(hipEventCreateWithFlags(&r->build_ev[k], hipEventDisableTiming));
     HIP_TRY(hipMalloc((void**)&r->d_counters, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc((void**)&r->d_sparse_count, sizeof(unsigned long long)));
@@ -1403,6 +1454,7 @@ void ovr_hip_destroy(ovr_hip_renderer* r)
   if (!r) return;
   for (size_t i = 1; i < r->members.size(); ++i) ovr_hip_destroy(r->members[i]); // a group leader takes its followers with it
   r->members.clear();
+  join_builders(r);
   (void)hipSetDevice(r->device);
   (void)hipDeviceSynchronize();
   if (r->rccl_comm && rccl_api().ok) (void)rccl_api().CommDestroy(r->rccl_comm);
@@ -1479,7 +1531,8 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
   if (!layout_offsets_fit(vd))
     return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_volume: one z layer of the volume exceeds 2^32 stored voxels (x * y too large for the 32-bit in-plane offsets)");
 
-  HIP_TRY(hipStreamSynchronize(r->build_stream)); // (covered by the device synchronisation above; kept explicit: a build reads the old general layout)
+  join_builders(r);                               // a builder thread may still be enqueueing a replica of the OLD volume
+  HIP_TRY(hipStreamSynchronize(r->build_stream)); // ... which reads the old general layout
   for (int k = 0; k < kLayouts; ++k) {
     if (r->d_replica[k]) HIP_TRY(hipFree(r->d_replica[k]));
     r->d_replica[k] = nullptr;
@@ -1574,7 +1627,7 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
     for (int k = 1; k < kLayouts; ++k) {
       if (r->replica_state[k] != 1) continue;
       std::string err;
-      (void)start_replica_build(r, k, &err);
+      (void)start_replica_build(r, k, &err, false);
       if (r->replica_state[k] != 2) {
         for (int j = 1; j < kLayouts; ++j) drop_replica(r, j);
         return fail(OVR_HIP_EDEVICE, std::string("[hip] volume replicas requested (layouts mode 2) but their allocation failed: ") + err);
@@ -1837,9 +1890,14 @@ int ovr_hip_render(ovr_hip_renderer* r)
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
   const auto t0 = std::chrono::high_resolution_clock::now(); // optix7/device.cpp:37-42
   if (int e = ovr_hip_render_async(r)) return e;
+  const auto tm = std::chrono::high_resolution_clock::now();
   if (int e = finish_frame(r)) return e;
   const auto t1 = std::chrono::high_resolution_clock::now();
   const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  static const bool slow_trace = getenv("OVR_HIP_SLOW_FRAMES") != nullptr; // diagnostic: where a frame that took > 20 ms of host time spent it
+  if (slow_trace && ms > 20.0)
+    fprintf(stderr, "[hip] slow frame %d: enqueue %.2f ms, wait + finish %.2f ms (kernels %.2f ms)\n", r->frame_index, std::chrono::duration<double, std::milli>(tm - t0).count(),
+            std::chrono::duration<double, std::milli>(t1 - tm).count(), r->stats.kernel_ms);
   r->stats.render_ms = ms;
   r->render_time_ms += ms;
   return 0;

@@ -82,6 +82,16 @@ def test_pipelined_gather_rebuilds_the_accumulated_frame(tmp_path, ovr, world):
         ren.mapframe(fb)
         frames.append(np.array(fb.rgba.data(), copy=True).reshape(SIZE[1], SIZE[0], 4))
     ren.close()
-    assert np.array_equal(got, frames[-1])
+    def which(frame):
+        """per 16x16 tile: the index of the accumulated frame its pixels equal (-1: none) - what a failure prints"""
+        out = {}
+        for ty in range(0, SIZE[1], TILE):
+            for tx in range(0, SIZE[0], TILE):
+                sl = (slice(ty, ty + TILE), slice(tx, tx + TILE))
+                m = [k for k in range(FRAMES) if np.array_equal(frame[sl], frames[k][sl])]
+                key = (m[-1] if m else -1, ((tx // TILE) + (ty // TILE)) % world)
+                out[key] = out.get(key, 0) + 1
+        return out   # {(frame index, owning rank): tiles}
+    assert np.array_equal(got, frames[-1]), which(got)
     # after run() number FRAMES - 1 (index FRAMES - 2) and the renderer's sync, the scattered frame is the one before it
-    assert np.array_equal(prev, frames[FRAMES - 3])
+    assert np.array_equal(prev, frames[FRAMES - 3]), which(prev)
