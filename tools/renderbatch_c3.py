@@ -49,6 +49,17 @@ try:
         fps = [l for l in out.stdout.splitlines() if l.startswith("fps =")]
         print(f"[renderbatch_c3] {n}^3 {dtype} at {fbsize}, empty-space skipping {'on (plugin default)' if skip == '1' else 'off'}: the reference app's own line: "
               f"{fps[-1] if fps else 'no fps line'}  (whole run incl. volume load {time.perf_counter() - t1:.1f} s)", flush=True)
+    # (round 4) the same unmodified app on a device group: OVR_HIP_DEVICES makes the plugin create one (ovr_hip_create_group); argv[4] = the list
+    # (default 0,0: two members on one card - the path, not the speed; on an 8-GPU node: 0,1,2,3,4,5,6,7)
+    devices = sys.argv[4] if len(sys.argv) > 4 else "0,0"
+    env["OVR_HIP_SKIP_EMPTY"] = "0"
+    out = subprocess.run([renderbatch, "--scene", scene, "--num-frames", "1", "--device", "hip", "--fbsize", fbsize, "--exp", os.path.join(d, "outg")],
+                         env=dict(env, OVR_HIP_DEVICES=devices), cwd=d, capture_output=True, text=True, timeout=900)
+    fps = [l for l in out.stdout.splitlines() if l.startswith("fps =")]
+    g = open(os.path.join(d, "outg000000.png"), "rb").read() if os.path.exists(os.path.join(d, "outg000000.png")) else None
+    one = open(os.path.join(d, "out0000000.png"), "rb").read() if os.path.exists(os.path.join(d, "out0000000.png")) else None
+    print(f"[renderbatch_c3] OVR_HIP_DEVICES={devices} (device group behind the unmodified app): {fps[-1] if fps else out.stderr[-500:]}; PNG "
+          f"{'byte-identical to the one-device run' if g is not None and g == one else 'DIFFERS / missing'}", flush=True)
     # renderapp's render-thread order (commit -> mapframe -> swap -> render: every frame crosses PCIe) through the same plugin
     probe = os.path.join(ROOT, "oracle", "_ref", "plugin_probe")
     w_, h_ = fbsize.split(",")
