@@ -306,3 +306,36 @@ def test_two_thread_renderapp_contract_through_the_plugin(tmp_path, ovr, hip_ren
             assert np.array_equal(hip_frame(ovr, ren)[0], frames[k * M + m]), (k, m)
     assert len({fr.tobytes() for fr in frames}) == K * M   # the states really differ
     ren.close()
+
+
+def test_device_group_api_edges(ovr, hip_renderer_factory):
+    """argument checks of ovr_hip_create_group and what a group refuses: one device is an ordinary renderer; RCCL cannot serve a device listed
+    twice (it is asked for explicitly here - the default falls back to peer copies); a group has one stream per device and gathers its tiles itself"""
+    import torch
+    lib = ovr._lib.load()
+    one = ovr.create_renderer("hip", devices=[0])
+    assert one.group_info()[:2] == (1, 0)
+    one.close()
+    h = C.c_void_p()
+    assert lib.ovr_hip_create_group(C.byref(h), None, 2) < 0 and b"device ordinals" in lib.ovr_hip_last_error()
+    ids = (C.c_int32 * 2)(0, 99)
+    assert lib.ovr_hip_create_group(C.byref(h), ids, 2) < 0 and not h.value   # an invalid member: nothing half-built is handed out
+    for bad, msg in (("rccl", "distinct devices"), ("smoke-signals", "OVR_HIP_GATHER")):
+        os.environ["OVR_HIP_GATHER"] = bad
+        try:
+            with pytest.raises(RuntimeError, match=msg):
+                ovr.create_renderer("hip", devices=[0, 0])
+        finally:
+            del os.environ["OVR_HIP_GATHER"]
+    g = ovr.create_renderer("hip", devices=[0, 0])
+    try:
+        assert g.group_info()[:2] == (2, 1)
+        with pytest.raises(RuntimeError, match="one stream per device"):
+            g.set_stream(torch.cuda.Stream().cuda_stream)
+        g.set_stream(None)
+        buf = torch.zeros(1024, dtype=torch.float32, device="cuda")
+        assert lib.ovr_hip_pack_tiles(g._h, C.c_void_p(buf.data_ptr()), buf.numel() * 4) < 0 and b"gathers its tiles itself" in lib.ovr_hip_last_error()
+        st = ovr._lib.Stats()
+        assert lib.ovr_hip_get_member_stats(g._h, 2, C.byref(st)) < 0
+    finally:
+        g.close()
