@@ -820,6 +820,10 @@ def worker(args, world):
         default_cmd = (args.config == "c3" and not (args.camera or args.tf or args.dtype or args.n or args.rate or args.skip_empty or args.sparse_sampling
                                                     or args.shard_of or args.devices or args.lds_staging) and args.shading is None and args.layout == -1 and args.pipeline == 0
                        and args.fovy == 60.0 and os.environ.get("OVR_BENCH_FORCE_GATHER") != "1" and os.environ.get("OVR_BENCH_ONE_GPU") != "1")
+        # rehearsal switches (one-GPU box): OVR_BENCH_FORCE_EXTRAS=1 runs the extra legs although this is not the default command (e.g. two gloo
+        # ranks on one card), OVR_BENCH_EXTRA_DEVICES=0,0 replaces the N > 1 leg's device list (the box has one GPU)
+        if os.environ.get("OVR_BENCH_FORCE_EXTRAS") == "1":
+            default_cmd = True
         if default_cmd and not args.no_extras:
             torch.cuda.empty_cache()
             extra = {}
@@ -829,7 +833,7 @@ def worker(args, world):
                 extra["c3_shard_of_8"] = run_extra_leg(["--shard-of", "8", "--steps", "20", "--warmup", "5"], 300)
                 extra["c3_device_group_rehearsal"] = run_extra_leg(["--devices", "0,0", "--steps", "10", "--warmup", "5"], 300)
             else:
-                devs = ",".join(str(i) for i in range(world))
+                devs = os.environ.get("OVR_BENCH_EXTRA_DEVICES") or ",".join(str(i) for i in range(world))
                 extra["c3_device_group"] = run_extra_leg(["--devices", devs, "--steps", str(args.steps), "--warmup", str(args.warmup)], 420)
                 os.environ["OVR_HIP_GATHER"] = "copy"   # the same group with peer-to-peer copies instead of RCCL send / recv
                 extra["c3_device_group_peer_copies"] = run_extra_leg(["--devices", devs, "--steps", str(args.steps), "--warmup", str(args.warmup)], 420)
