@@ -112,6 +112,9 @@ int ovr_hip_create_group(ovr_hip_renderer** out, const int32_t* device_ids, int3
 /* n_devices (1 for an ordinary renderer), how the tiles travel (0 = no group, 1 = peer copies, 2 = RCCL), and the host time the last frame
  * spent after its slowest member had finished (waiting for the shipments + the scatter), milliseconds; any pointer may be NULL */
 int ovr_hip_group_info(const ovr_hip_renderer* r, int32_t* n_devices, int32_t* gather_kind, double* gather_ms);
+/* diagnostic: the RCCL entry points a device group uses (ncclCommInitAll, ncclGroupStart / End, ncclSend, ncclRecv on a stream), exercised on
+ * ONE device - a communicator of one rank sends 256 KiB to itself.  0 = they work; OVR_HIP_ESTATE = librccl.so is not loadable (groups use peer copies) */
+int ovr_hip_rccl_selftest(int device_id);
 /* the counters of ONE member's last frame (member 0 = the leader's own tiles) */
 int ovr_hip_get_member_stats(const ovr_hip_renderer* r, int32_t member, ovr_hip_stats* out);
 

@@ -75,6 +75,7 @@ SYMBOLS = {
     "ovr_hip_create_group": (C.c_int, [C.POINTER(_H), C.POINTER(C.c_int32), C.c_int32]),
     "ovr_hip_group_info": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "ovr_hip_get_member_stats": (C.c_int, [_H, C.c_int32, C.POINTER(Stats)]),
+    "ovr_hip_rccl_selftest": (C.c_int, [C.c_int]),
     "ovr_hip_set_stream": (C.c_int, [_H, C.c_void_p]),
     "ovr_hip_set_volume": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), _F3, _F3]),
     "ovr_hip_set_grid_convention": (C.c_int, [_H, C.c_int]),

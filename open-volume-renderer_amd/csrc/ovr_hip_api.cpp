@@ -259,7 +259,10 @@ struct ovr_hip_renderer {
   int group_rank = 0;
   int gather_kind = 0;                    // leader: 0 = no group, 1 = peer copies, 2 = RCCL send / recv
   hipStream_t comm_stream = nullptr;      // every member: where its payload travels (the render stream goes on with the next frame)
-  hipEvent_t ev_packed = nullptr, ev_shipped = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_shipped = nullptr; // on the member's own device: its tiles are packed / have left on its comm_stream (peer copies)
+  hipEvent_t ev_received = nullptr;       // follower, created on the LEADER's device: its tiles have arrived on the leader's comm_stream (RCCL) - an
+                                          // event is recorded on a stream of its own device only
+  bool shipped_by_rccl = false;           // which of the two events the leader's scatter waits for
   float* d_payload[2] = { nullptr, nullptr };  // follower: its packed tiles, [0] RGBA, [1] gradient layer
   float* d_gather[2] = { nullptr, nullptr };   // leader: every member's payload, group_stride[] floats apart
   size_t payload_floats[2] = { 0, 0 }, group_stride[2] = { 0, 0 };
@@ -1217,7 +1220,7 @@ int group_ship(ovr_hip_renderer* L, ovr_hip_renderer* m)
   const int W = L->fbsize.current.w, H = L->fbsize.current.h;
   const ShardP& s = m->shard.current;
   HIP_TRY(hipSetDevice(m->device));
-  if (m->payload_floats[0] == 0) { HIP_TRY(hipEventRecord(m->ev_shipped, m->comm_stream)); return 0; }
+  if (m->payload_floats[0] == 0) { HIP_TRY(hipEventRecord(m->ev_shipped, m->comm_stream)); m->shipped_by_rccl = false; return 0; }
   // ovr_hip_pack_tiles resolves a frame whose request pool is not yet known to be roomy before it packs (a pool overflow renders the frame again)
   if (int e = ovr_hip_pack_tiles(m, m->d_payload[0], m->payload_floats[0] * sizeof(float))) return e;
   if (L->group_grad) HIP_TRY(launch_pack_tiles(m->d_grad[m->cur], m->d_payload[1], W, H, s.tw, s.th, s.rank, s.world, m->stream(), 3));
@@ -1230,12 +1233,16 @@ int group_ship(ovr_hip_renderer* L, ovr_hip_renderer* m)
     int rc = N.GroupStart();
     for (int c = 0; c < 2 && rc == 0; ++c) {
       if (c == 1 && !L->group_grad) break;
+      (void)hipSetDevice(m->device);
       rc = N.Send(m->d_payload[c], m->payload_floats[c], kNcclFloat, 0, m->rccl_comm, m->comm_stream);
+      (void)hipSetDevice(L->device);
       if (rc == 0) rc = N.Recv(L->d_gather[c] + (size_t)m->group_rank * L->group_stride[c], m->payload_floats[c], kNcclFloat, m->group_rank, L->rccl_comm, L->comm_stream);
     }
     const int rc2 = N.GroupEnd();
     if (rc == 0 && rc2 == 0) {
-      HIP_TRY(hipEventRecord(m->ev_shipped, L->comm_stream)); // the receive side: ordered after every earlier member's receive on that stream
+      HIP_TRY(hipSetDevice(L->device));
+      HIP_TRY(hipEventRecord(m->ev_received, L->comm_stream)); // the receive side: ordered after every earlier member's receive on that stream
+      m->shipped_by_rccl = true;
       (void)n;
       return 0;
     }
@@ -1251,6 +1258,7 @@ int group_ship(ovr_hip_renderer* L, ovr_hip_renderer* m)
     else HIP_TRY(hipMemcpyPeerAsync(dst, L->device, m->d_payload[c], m->device, m->payload_floats[c] * sizeof(float), m->comm_stream));
   }
   HIP_TRY(hipEventRecord(m->ev_shipped, m->comm_stream));
+  m->shipped_by_rccl = false;
   return 0;
 }
 
@@ -1279,7 +1287,7 @@ int group_finish(ovr_hip_renderer* L)
   // 3. the leader scatters the payloads into the framebuffer set the frame rendered into
   HIP_TRY(hipSetDevice(L->device));
   hipStream_t st = L->stream();
-  for (int i = 1; i < n; ++i) HIP_TRY(hipStreamWaitEvent(st, L->members[i]->ev_shipped, 0));
+  for (int i = 1; i < n; ++i) HIP_TRY(hipStreamWaitEvent(st, L->members[i]->shipped_by_rccl ? L->members[i]->ev_received : L->members[i]->ev_shipped, 0));
   const ShardP& s = L->shard.current;
   if (W > 0 && H > 0 && L->d_gather[0]) {
     HIP_TRY(launch_unpack_tiles(L->d_gather[0], L->d_rgba[L->frame_set], W, H, s.tw, s.th, -1, n, L->group_stride[0], st, 4, 0));
@@ -1398,6 +1406,11 @@ int ovr_hip_create_group(ovr_hip_renderer** out, const int32_t* device_ids, int3
       HIP_TRY(hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking));
       HIP_TRY(hipEventCreateWithFlags(&m->ev_packed, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&m->ev_shipped, hipEventDisableTiming));
+      if (i > 0) {
+        HIP_TRY(hipSetDevice(L->device));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_received, hipEventDisableTiming));
+        HIP_TRY(hipSetDevice(m->device));
+      }
       ShardP s; s.rank = i; s.world = n_devices; s.tw = tw; s.th = th;
       m->shard.current = m->shard.queued = s;
       m->sched_list_dirty = true;
@@ -1428,6 +1441,49 @@ int ovr_hip_create_group(ovr_hip_renderer** out, const int32_t* device_ids, int3
   if (int e = build()) { const std::string msg = g_last_error; ovr_hip_destroy(L); g_last_error = msg; return e; }
   *out = L;
   return 0;
+}
+
+// The RCCL entry points a device group uses, exercised on ONE device: a communicator of one rank (ncclCommInitAll), a send to itself matched by
+// a receive inside one ncclGroupStart / End on a stream, the payload compared.  A device group's own RCCL branch needs distinct devices; this
+// pins what can be pinned on one card - the library resolves, the prototypes and the data-type constant are right, the calls run on a stream.
+int ovr_hip_rccl_selftest(int device_id)
+{
+  const RcclApi& N = rccl_api();
+  if (!N.ok) return fail(OVR_HIP_ESTATE, "[hip] librccl.so could not be loaded (a device group then gathers with peer copies)");
+  HIP_TRY(hipSetDevice(device_id));
+  void* comm = nullptr;
+  const int dev = device_id;
+  int rc = N.CommInitAll(&comm, 1, &dev);
+  if (rc != 0) return fail(OVR_HIP_EDEVICE, std::string("[hip] ncclCommInitAll(1 device) failed: ") + (N.GetErrorString ? N.GetErrorString(rc) : "?"));
+  const size_t n = 1 << 16;
+  float *src = nullptr, *dst = nullptr;
+  hipStream_t st = nullptr;
+  std::vector<float> h(n), back(n, -1.f);
+  for (size_t i = 0; i < n; ++i) h[i] = (float)i * 0.25f;
+  auto run = [&]() -> int {
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void**)&src, n * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&dst, n * sizeof(float)));
+    HIP_TRY(hipMemcpy(src, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dst, 0, n * sizeof(float)));
+    int a = N.GroupStart();
+    if (a == 0) a = N.Send(src, n, kNcclFloat, 0, comm, st);
+    if (a == 0) a = N.Recv(dst, n, kNcclFloat, 0, comm, st);
+    const int b = N.GroupEnd();
+    if (a != 0 || b != 0) return fail(OVR_HIP_EDEVICE, std::string("[hip] RCCL self send / recv failed: ") + (N.GetErrorString ? N.GetErrorString(a != 0 ? a : b) : "?"));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(back.data(), dst, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (std::memcmp(back.data(), h.data(), n * sizeof(float)) != 0) return fail(OVR_HIP_EDEVICE, "[hip] RCCL self send / recv delivered other bytes than were sent");
+    return 0;
+  };
+  const int e = run();
+  const std::string msg = g_last_error;
+  if (src) (void)hipFree(src);
+  if (dst) (void)hipFree(dst);
+  if (st) (void)hipStreamDestroy(st);
+  (void)N.CommDestroy(comm);
+  g_last_error = msg;
+  return e;
 }
 
 int ovr_hip_group_info(const ovr_hip_renderer* r, int32_t* n_devices, int32_t* gather_kind, double* gather_ms)
@@ -1465,6 +1521,7 @@ void ovr_hip_destroy(ovr_hip_renderer* r)
   if (r->comm_stream) (void)hipStreamDestroy(r->comm_stream);
   if (r->ev_packed) (void)hipEventDestroy(r->ev_packed);
   if (r->ev_shipped) (void)hipEventDestroy(r->ev_shipped);
+  if (r->ev_received) (void)hipEventDestroy(r->ev_received);
   (void)free_framebuffers(r);
   for (int k = 0; k < kLayouts; ++k) {
     if (r->d_replica[k]) (void)hipFree(r->d_replica[k]);

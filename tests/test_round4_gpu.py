@@ -339,3 +339,11 @@ def test_device_group_api_edges(ovr, hip_renderer_factory):
         assert lib.ovr_hip_get_member_stats(g._h, 2, C.byref(st)) < 0
     finally:
         g.close()
+
+
+def test_rccl_entry_points_on_one_device(ovr):
+    """the RCCL calls of a device group's gather - resolved from librccl.so at run time - on one device: a one-rank communicator sends 256 KiB to
+    itself inside ncclGroupStart / End on a stream and gets the same bytes back (the group's own RCCL branch needs distinct devices)"""
+    lib = ovr._lib.load()
+    rc = lib.ovr_hip_rccl_selftest(0)
+    assert rc == 0, lib.ovr_hip_last_error()
