@@ -706,8 +706,12 @@ int start_replica_build(ovr_hip_renderer* r, int k, std::string* err, bool backg
   if (!r->replica_state[k].compare_exchange_strong(planned, 4)) return 0; // not planned, or already on its way
   if (r->builder[k].joinable()) r->builder[k].join();
   static const bool threads = !(getenv("OVR_HIP_BUILD_THREAD") && atoi(getenv("OVR_HIP_BUILD_THREAD")) == 0); // measurements: 0 = host work on the caller
-  if (background && threads) r->builder[k] = std::thread(build_replica_host, r, k, nullptr);
-  else build_replica_host(r, k, err);
+  bool started = false;
+  if (background && threads) {
+    try { r->builder[k] = std::thread(build_replica_host, r, k, nullptr); started = true; }
+    catch (const std::exception&) { started = false; } // no thread to be had: the caller does the host work
+  }
+  if (!started) build_replica_host(r, k, err);
   return 0;
 }
 

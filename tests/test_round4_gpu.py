@@ -255,7 +255,8 @@ def test_renderbatch_on_a_device_group(tmp_path, ovr):
 
 # ---- the interactive app's two threads through the plugin ------------------------------------------------------------------
 
-def test_two_thread_renderapp_contract_through_the_plugin(tmp_path, ovr, hip_renderer_factory):
+@pytest.mark.parametrize("devices,iterations", [(None, 10000), ("0,0,0", 3000)])
+def test_two_thread_renderapp_contract_through_the_plugin(tmp_path, ovr, hip_renderer_factory, devices, iterations):
     """oracle/_ref/plugin_probe --stress (oracle/plugin_probe.cpp, built against the reference's headers): a setter thread calls set_camera /
     set_transfer_function / set_focus at random moments while the render thread runs renderapp's loop - commit, mapframe, swap, render
     (apps/main_app.cpp:233-278) - and a reader thread checksums the mapped buffer during the following render().  10 000 iterations: every
@@ -273,14 +274,17 @@ def test_two_thread_renderapp_contract_through_the_plugin(tmp_path, ovr, hip_ren
     scene_path = ovr.vidi3d.write_scene(str(tmp_path), "synthetic", vol, ovr.synth._RAINBOW, alphas[1::2].copy(), (0.0, 1.0), cam, fovy=45.0, sample_distance=1.0)
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.dirname(plugin), os.path.join(ROOT, "open-volume-renderer_amd"), env.get("LD_LIBRARY_PATH", "")])
-    out = subprocess.run([probe, "--stress", "10000", scene_path, str(W), str(H), str(tmp_path / "stress")], env=env, cwd=str(tmp_path), capture_output=True,
+    env.pop("OVR_HIP_DEVICES", None)
+    if devices:   # the same contract with a device group behind the MainRenderer: setters forwarded to every member from the GUI thread, a gather per frame
+        env["OVR_HIP_DEVICES"] = devices
+    out = subprocess.run([probe, "--stress", str(iterations), scene_path, str(W), str(H), str(tmp_path / "stress")], env=env, cwd=str(tmp_path), capture_output=True,
                          text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     import re
     line = [l for l in out.stdout.splitlines() if l.startswith("stress:")][-1]
     rep = {k: int(v) for k, v in re.findall(r"(\w+) (\d+)", line)}
-    assert rep["iterations"] == rep["frames_checked"] == 10000 and rep["not_a_reference_frame"] == 0 and rep["torn"] == 0, line
-    assert rep["distinct_frames_seen"] >= 8 and rep["reader_checks"] > 1000 and rep["setter_calls"] > 1000, line
+    assert rep["iterations"] == rep["frames_checked"] == iterations and rep["not_a_reference_frame"] == 0 and rep["torn"] == 0, line
+    assert rep["distinct_frames_seen"] >= 8 and rep["reader_checks"] > iterations // 10 and rep["setter_calls"] > iterations // 10, line
     # the probe's reference frames against the Python host (same C ABI, the same inputs read back from the probe's dump)
     raw = np.fromfile(str(tmp_path / "stress_states.bin"), dtype=np.uint8)
     K, M, nc, na, w, h = np.frombuffer(raw[:24].tobytes(), dtype=np.int32)
