@@ -58,6 +58,9 @@ def _worker(rank, world, port, out_path):
             ren.sync()
             if rank == 0 and i == FRAMES - 2:
                 snaps.append(g.frame.clone())   # run() number i scatters frame i - 1: this snapshot must be frame FRAMES - 3
+                # (the clone is a kernel on torch's default stream, which the gatherer's non-blocking streams do not wait for: without this
+                # synchronisation the NEXT run()'s scatter could overtake it on a busy card - seen twice in ~20 full-suite runs, always with 4 ranks)
+                torch.cuda.synchronize()
         g.flush()
         ren.sync()
         torch.cuda.synchronize()
