@@ -236,6 +236,14 @@ struct ovr_hip_renderer {
   unsigned int* d_sched = nullptr;     // sorted on the device whenever the camera or the volume's box changes
   unsigned int n_sched = 0;
   bool sched_list_dirty = true, sched_dirty = true;
+  // Blocks none of whose rays meets the volume's box are not launched (round 4; launch_schedule's `exact` classification puts them last in the
+  // list): n_work = the entries that get a march / composite workgroup, empty_pixels = the active pixels of the others (they count as rays and
+  // rendered pixels like before).  Their pixels are zeroed by launch_clear_blocks - once per framebuffer set after anything changed (clear_gen),
+  // and on the first frame of an accumulation (the accumulation buffer's turn).
+  unsigned int* d_sched_info = nullptr;
+  unsigned int n_work = 0, empty_pixels = 0, frame_empty_pixels = 0;
+  unsigned int clear_gen = 1, set_clear_gen[2] = { 0, 0 };
+  bool sched_exact = false;
 
   // request pool of the pooled shading pipeline
   PoolDesc pool{};
@@ -306,6 +314,7 @@ int free_framebuffers(ovr_hip_renderer* r)
   r->d_sched_src = r->d_sched = nullptr;
   r->n_sched = 0;
   r->sched_list_dirty = r->sched_dirty = true;
+  r->clear_gen++;
   if (r->pool.tile_first) HIP_TRY(hipFree(r->pool.tile_first));
   if (r->pool.tile_count) HIP_TRY(hipFree(r->pool.tile_count));
   if (r->pool.pix_state) HIP_TRY(hipFree(r->pool.pix_state));
@@ -899,17 +908,42 @@ int enqueue_frame(ovr_hip_renderer* r)
   P.sparse_hint_pixels = 0;
   P.schedule = nullptr;
   P.n_schedule = 0;
+  P.n_blocks_owned = 0;
+  r->frame_empty_pixels = 0;
   if (!sparse) {
     if (r->sched_list_dirty)
       if (int e = build_schedule_list(r)) return e;
-    if (r->sched_dirty) {
-      HIP_TRY(launch_schedule(P, r->d_sched_src, r->n_sched, r->d_sched, r->d_sched + r->n_sched, st));
-      r->sched_dirty = false;
-    }
-    P.schedule = r->d_sched;
     static const bool unsorted = getenv("OVR_HIP_SCHED_SORT") && atoi(getenv("OVR_HIP_SCHED_SORT")) == 0; // experiment: image (supertile) order
-    if (unsorted) P.schedule = r->d_sched_src;
-    P.n_schedule = r->n_sched;
+    static const bool skip_blocks = !(getenv("OVR_HIP_EMPTY_BLOCKS") && atoi(getenv("OVR_HIP_EMPTY_BLOCKS")) == 0); // 0: launch every block (measurements)
+    // a pixel's ray is known to the schedule kernels when it has one sample and no jitter: blocks without a hit are found exactly
+    const bool exact = skip_blocks && !unsorted && P.spp == 1 && P.jitter_mode == 0;
+    if (r->sched_dirty || exact != r->sched_exact) {
+      if (!r->d_sched_info) HIP_TRY(hipMalloc((void**)&r->d_sched_info, 2 * sizeof(unsigned int)));
+      HIP_TRY(launch_schedule(P, r->d_sched_src, r->n_sched, r->d_sched, r->d_sched + r->n_sched, exact ? 1 : 0, r->d_sched_info, st));
+      r->n_work = r->n_sched;
+      r->empty_pixels = 0;
+      if (exact && r->n_sched > 0) { // how many entries need a workgroup: 8 bytes back from the device, once per camera / volume / size change
+        unsigned int info[2] = { 0u, 0u };
+        HIP_TRY(hipMemcpyAsync(info, r->d_sched_info, sizeof(info), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        r->n_work = std::min(info[0], r->n_sched);
+        r->empty_pixels = info[1];
+      }
+      r->sched_dirty = false;
+      r->sched_exact = exact;
+      r->clear_gen++;
+    }
+    P.schedule = unsorted ? r->d_sched_src : r->d_sched;
+    P.n_schedule = r->n_work;
+    P.n_blocks_owned = r->n_sched;
+    r->frame_empty_pixels = r->empty_pixels;
+    if (r->n_work < r->n_sched) {
+      const bool first_accumulated = accumulate && r->frame_index == 1;
+      if (r->set_clear_gen[r->cur] != r->clear_gen || first_accumulated) {
+        HIP_TRY(launch_clear_blocks(P, r->d_sched + r->n_work, r->n_sched - r->n_work, first_accumulated ? 1 : 0, st));
+        r->set_clear_gen[r->cur] = r->clear_gen;
+      }
+    }
   }
   if (sparse) { // createSparseSamples, device_impl.cpp:304-342
     if (!r->d_noise) return fail(OVR_HIP_ESTATE, "[hip] sparse sampling enabled but no noise tile was set (ovr_hip_set_noise_tile)");
@@ -1000,11 +1034,11 @@ int finish_frame_one(ovr_hip_renderer* r)
   r->stats.march_ms = m1;
   r->stats.shade_ms = m2;
   r->stats.composite_ms = m3;
-  r->stats.rays = r->h_counters[0];
+  r->stats.rays = r->h_counters[0] + r->frame_empty_pixels;   // (blocks without a hit are not launched: their pixels' rays missed)
   r->stats.samples = r->h_counters[1];
   r->stats.shaded_samples = r->h_counters[2];
   r->stats.shadow_samples = r->h_counters[3];
-  r->stats.active_pixels = r->h_counters[4];
+  r->stats.active_pixels = r->h_counters[4] + r->frame_empty_pixels;
   r->stats.skipped_samples = r->h_counters[5];
   r->stats.skipped_shadow_samples = r->h_counters[6];
   // The reference's box test switches a slab off for a ray whose direction component on that axis is below FLT_MIN (shaders_common.h:162-172,
@@ -1550,6 +1584,7 @@ void ovr_hip_destroy(ovr_hip_renderer* r)
   if (r->pool.shade_counters) (void)hipFree(r->pool.shade_counters);
   if (r->h_ctrl) (void)hipHostFree(r->h_ctrl);
   if (r->d_block_counters) (void)hipFree(r->d_block_counters);
+  if (r->d_sched_info) (void)hipFree(r->d_sched_info);
   if (r->d_trace) (void)hipFree(r->d_trace);
   for (int i = 0; i < 2; ++i)
     if (r->own_stream[i]) (void)hipStreamDestroy(r->own_stream[i]);
@@ -1899,12 +1934,12 @@ int ovr_hip_commit(ovr_hip_renderer* r)
     r->fb_reset = true;
   }
   if (r->focus.update()) r->fb_reset = true;      // :155-168
-  if (r->spp.update()) r->fb_reset = true;        // :170-173
+  if (r->spp.update()) { r->fb_reset = true; r->sched_dirty = true; }        // :170-173 (one sample per pixel: the schedule knows every ray)
   if (r->sparse.update()) r->fb_reset = true;     // :180-183
   if (r->accumulate.update()) r->fb_reset = true; // :185-188
   if (r->rate.update()) r->fb_reset = true;       // :190-196
   if (r->shading.update()) r->fb_reset = true;
-  if (r->jitter.update()) r->fb_reset = true;
+  if (r->jitter.update()) { r->fb_reset = true; r->sched_dirty = true; }
   (void)r->lds_staging.update(); // same frame either way
   // every layout and both pipelines give the same frame: no accumulation reset - but what was measured under the old setting is void
   // (a probe must not override a layout forced meanwhile; forced -> automatic has to measure again)
@@ -1918,6 +1953,7 @@ int ovr_hip_commit(ovr_hip_renderer* r)
   }
   const bool other_changed = r->fb_reset;
   if (other_changed || only_camera_so_far) {
+    r->clear_gen++;        // ... and so is what the pixels of the blocks that are not launched hold
     r->pool_roomy = false; // something changed: the next frame's request count is unknown
     const bool keep = r->tune_on && !other_changed && r->tune_state == 2 && (r->tune_layout >= 0 || r->tune_pipeline != 0);
     if (keep) r->tune_recheck = 12; // only the camera moved: the measured layout / pipeline stay (see tune_recheck)

@@ -577,6 +577,22 @@ __device__ __forceinline__ f3 to_object(const MarchConsts& mc, f3 p)
   return mk3(fmaf(p.x, mc.inv_scale.x, mc.wto_p.x), fmaf(p.y, mc.inv_scale.y, mc.wto_p.y), fmaf(p.z, mc.inv_scale.z, mc.wto_p.z));
 }
 
+// Does the ray of pixel (ix, iy) - one sample per pixel, no jitter - meet the volume's box?  The expressions are the march's own
+// (raymarch_kernel: screen position, ray direction, object-space ray, box test), so the answer is the march's answer bit for bit, the
+// ignored-slab quirk of the reference's box test included.  launch_schedule uses it to find the 8x8 blocks NONE of whose rays hits.
+__device__ __forceinline__ bool pixel_ray_hits_box(const RayMarchParams& P, const MarchConsts& mc, int ix, int iy)
+{
+  const float rsx = 1.f / (float)P.width, rsy = 1.f / (float)P.height;
+  const float sx = ((float)ix + .5f) * rsx, sy = ((float)iy + .5f) * rsy;
+  const float ux = sx - 0.5f, uy = sy - 0.5f;
+  const f3 cdir = ld3(P.cam_dir), chor = ld3(P.cam_hor), cver = ld3(P.cam_ver);
+  const f3 dir = normalize3_exact(mk3(cdir.x + ux * chor.x + uy * cver.x, cdir.y + ux * chor.y + uy * cver.y, cdir.z + ux * chor.z + uy * cver.z));
+  const f3 od = mk3(dir.x * mc.inv_scale.x, dir.y * mc.inv_scale.y, dir.z * mc.inv_scale.z);
+  const f3 oo = to_object(mc, ld3(P.cam_pos));
+  float t0 = 0.f, t1 = FLT_MAX;
+  return intersect_unit_box(t0, t1, oo, od);
+}
+
 // Empty-space skipping, per ray: the t interval outside of which every sample lies in a macrocell with majorant 0.
 // skip_walk: one lane walks the ray's [ta, tb] through an occupancy grid (3-D DDA; accel/dda.h is the reference's walker for
 // its path tracer) and widens [first, last] by the entry / exit of every set entry it crosses.  FINE = false: the coarse grid
@@ -1943,7 +1959,9 @@ inline bool use_deep_rounds(const RayMarchParams& p)
   // sparse (foveated) frames: the kept rays are few and concentrated where the rays are long - the same floor (round 3: march 1.12 ->
   // 1.01 ms at the app's default focus); the host passes the previous frame's pixel count, the list's length is only known on the device
   if (p.sparse_xy) return p.world == 1 && p.sparse_hint_pixels > 0 && p.sparse_hint_pixels <= 64ull * OVR_DEEP_MAX_BLOCKS;
-  return p.world > 1 && p.n_schedule <= (unsigned int)OVR_DEEP_MAX_BLOCKS;
+  // (the threshold was measured on the number of blocks a shard OWNS, launched or not: n_blocks_owned - n_schedule may be smaller since
+  // round 4, when blocks none of whose rays hits the box are no longer launched)
+  return p.world > 1 && p.n_blocks_owned <= (unsigned int)OVR_DEEP_MAX_BLOCKS;
 }
 
 template <int VT, int SHADE, int AM, bool SKIP>

@@ -169,29 +169,53 @@ __device__ __forceinline__ unsigned int schedule_class(const RayMarchParams& P, 
 //                            blocks supertile by supertile, 4x4 blocks = 32x32 pixels, so blocks that run at the same time are
 //                            compact squares of the image and share their bricks in L2 / Infinity Cache)
 // (Mapping the 16 blocks of a supertile to ONE XCD - workgroup s runs on XCD s % 8 - was measured slower: C3 march 1.63 vs 1.57 ms.)
-__global__ __launch_bounds__(1024) void schedule_hist_kernel(const RayMarchParams P, const unsigned int* __restrict__ src, unsigned int n,
-                                                             unsigned int* __restrict__ hist)
+//   schedule_classify_kernel one WAVE per block: its length class (five probe rays) and - `exact` - whether ANY of its 64 pixel rays meets the box
+//                            (pixel_ray_hits_box: the march's own test); cls[i] = class | active pixels << 8, class 0 <=> (exact) no ray hits
+__global__ __launch_bounds__(256) void schedule_classify_kernel(const RayMarchParams P, const unsigned int* __restrict__ src, unsigned int n, int exact,
+                                                               unsigned int* __restrict__ cls)
 {
-  __shared__ unsigned int count[kSchedClasses];
   VolConsts vc;
   MarchConsts mc;
   setup_consts(P, vc, mc);
-  if (threadIdx.x < kSchedClasses) count[threadIdx.x] = 0u;
-  __syncthreads();
-  const unsigned int i = blockIdx.x * 1024u + threadIdx.x;
-  if (i < n) atomicAdd(&count[schedule_class(P, mc, src[i])], 1u);
-  __syncthreads();
-  if (threadIdx.x < kSchedClasses) hist[blockIdx.x * kSchedClasses + threadIdx.x] = count[threadIdx.x];
+  const unsigned int i = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (i >= n) return; // wave-uniform
+  const int lane = threadIdx.x & 63;
+  const unsigned int e = src[i];
+  const int ix = (int)(e & 0xffffu) * 8 + (lane & 7), iy = (int)(e >> 16) * 8 + (lane >> 3);
+  bool active = ix < P.width && iy < P.height;
+  if (P.world > 1 && active) active = ((ix / P.tile_w + iy / P.tile_h) % P.world) == P.rank; // assign_pixel_quad's ownership test
+  const bool hit = exact && active && pixel_ray_hits_box(P, mc, ix, iy);
+  const unsigned long long any = __ballot(hit), act = __ballot(active);
+  if (lane == 0) {
+    unsigned int c = schedule_class(P, mc, e);
+    if (exact) c = any != 0ull ? max(c, 1u) : 0u;
+    cls[i] = c | ((unsigned int)__popcll(act) << 8);
+  }
 }
 
-__global__ __launch_bounds__(1024) void schedule_scatter_kernel(const RayMarchParams P, const unsigned int* __restrict__ src, unsigned int n,
-                                                                const unsigned int* __restrict__ hist, unsigned int* __restrict__ dst)
+__global__ __launch_bounds__(1024) void schedule_hist_kernel(const unsigned int* __restrict__ cls, unsigned int n, unsigned int* __restrict__ hist, unsigned int* __restrict__ info)
+{
+  __shared__ unsigned int count[kSchedClasses];
+  __shared__ unsigned int empty_pixels;
+  if (threadIdx.x < kSchedClasses) count[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) empty_pixels = 0u;
+  __syncthreads();
+  const unsigned int i = blockIdx.x * 1024u + threadIdx.x;
+  if (i < n) {
+    const unsigned int c = cls[i];
+    atomicAdd(&count[c & 0xffu], 1u);
+    if ((c & 0xffu) == 0u) atomicAdd(&empty_pixels, c >> 8);
+  }
+  __syncthreads();
+  if (threadIdx.x < kSchedClasses) hist[blockIdx.x * kSchedClasses + threadIdx.x] = count[threadIdx.x];
+  if (threadIdx.x == 0 && info && empty_pixels) atomicAdd(&info[1], empty_pixels); // active pixels of the class-0 blocks (one atomic per workgroup)
+}
+
+__global__ __launch_bounds__(1024) void schedule_scatter_kernel(const unsigned int* __restrict__ src, const unsigned int* __restrict__ cls_in, unsigned int n,
+                                                                const unsigned int* __restrict__ hist, unsigned int* __restrict__ dst, unsigned int* __restrict__ info)
 {
   __shared__ unsigned int base[kSchedClasses], total[kSchedClasses];
   __shared__ unsigned int wave_count[16][kSchedClasses];
-  VolConsts vc;
-  MarchConsts mc;
-  setup_consts(P, vc, mc);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // per class: blocks in the workgroups before this one, and in all of them
   if (threadIdx.x < kSchedClasses) {
@@ -209,11 +233,12 @@ __global__ __launch_bounds__(1024) void schedule_scatter_kernel(const RayMarchPa
   if (threadIdx.x == 0) { // descending classes: the longest rays first
     unsigned int at = 0u;
     for (int c = kSchedClasses - 1; c >= 0; --c) { const unsigned int t = total[c]; base[c] += at; at += t; }
+    if (info && blockIdx.x == 0) info[0] = n - total[0]; // the blocks that need a workgroup: everything before class 0
   }
   const unsigned int i = blockIdx.x * 1024u + threadIdx.x;
   const bool valid = i < n;
   const unsigned int e = valid ? src[i] : 0u;
-  const unsigned int cls = valid ? schedule_class(P, mc, e) : 0u;
+  const unsigned int cls = valid ? (cls_in[i] & 0xffu) : 0u;
   // rank among the lanes of this wave with the same class (lower lanes first), wave totals to LDS
   unsigned int rank = 0u;
   unsigned long long todo = __ballot(valid);
@@ -235,14 +260,46 @@ __global__ __launch_bounds__(1024) void schedule_scatter_kernel(const RayMarchPa
   if (valid) dst[wave_count[wave][cls] + rank] = e;
 }
 
-size_t schedule_workspace_elems(unsigned int n) { return (size_t)((n + 1023u) / 1024u) * kSchedClasses; }
+size_t schedule_workspace_elems(unsigned int n) { return (size_t)((n + 1023u) / 1024u) * kSchedClasses + (size_t)n; } // histograms + one class word per block
 
-hipError_t launch_schedule(const RayMarchParams& p, const unsigned int* src, unsigned int n, unsigned int* dst, unsigned int* workspace, hipStream_t stream)
+hipError_t launch_schedule(const RayMarchParams& p, const unsigned int* src, unsigned int n, unsigned int* dst, unsigned int* workspace, int exact, unsigned int* info,
+                           hipStream_t stream)
 {
+  if (info) {
+    const hipError_t e = hipMemsetAsync(info, 0, 2 * sizeof(unsigned int), stream);
+    if (e != hipSuccess) return e;
+  }
   if (n == 0) return hipSuccess;
   const dim3 grid((n + 1023u) / 1024u);
-  hipLaunchKernelGGL(schedule_hist_kernel, grid, dim3(1024), 0, stream, p, src, n, workspace);
-  hipLaunchKernelGGL(schedule_scatter_kernel, grid, dim3(1024), 0, stream, p, src, n, workspace, dst);
+  unsigned int* hist = workspace;
+  unsigned int* cls = workspace + (size_t)grid.x * kSchedClasses;
+  hipLaunchKernelGGL(schedule_classify_kernel, dim3((n + 3u) / 4u), dim3(256), 0, stream, p, src, n, exact, cls);
+  hipLaunchKernelGGL(schedule_hist_kernel, grid, dim3(1024), 0, stream, cls, n, hist, info);
+  hipLaunchKernelGGL(schedule_scatter_kernel, grid, dim3(1024), 0, stream, src, cls, n, hist, dst, info);
+  return hipGetLastError();
+}
+
+// the pixels of blocks that are not launched (no ray of theirs meets the box): what the march's miss writes - 0 in every layer
+// (shaders_raymarching.cu:237-253 + the accumulation of :389-409: accum += 0, rgba = accum / frame_index = 0)
+__global__ __launch_bounds__(256) void clear_blocks_kernel(const RayMarchParams P, const unsigned int* __restrict__ blocks, unsigned int n, int clear_accum)
+{
+  const unsigned int i = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  const unsigned int e = blocks[i];
+  const int ix = (int)(e & 0xffffu) * 8 + (lane & 7), iy = (int)(e >> 16) * 8 + (lane >> 3);
+  bool active = ix < P.width && iy < P.height;
+  if (P.world > 1 && active) active = ((ix / P.tile_w + iy / P.tile_h) % P.world) == P.rank;
+  if (!active) return;
+  const size_t pi = (size_t)ix + (size_t)iy * (size_t)P.width;
+  reinterpret_cast<float4*>(P.rgba)[pi] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (P.grad) { float* g = P.grad + 3 * pi; g[0] = 0.f; g[1] = 0.f; g[2] = 0.f; }
+  if (clear_accum && P.accum) reinterpret_cast<float4*>(P.accum)[pi] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+hipError_t launch_clear_blocks(const RayMarchParams& p, const unsigned int* blocks, unsigned int n, int clear_accum, hipStream_t stream)
+{
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(clear_blocks_kernel, dim3((n + 3u) / 4u), dim3(256), 0, stream, p, blocks, n, clear_accum);
   return hipGetLastError();
 }
 

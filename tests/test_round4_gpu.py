@@ -351,3 +351,56 @@ def test_rccl_entry_points_on_one_device(ovr):
     lib = ovr._lib.load()
     rc = lib.ovr_hip_rccl_selftest(0)
     assert rc == 0, lib.ovr_hip_last_error()
+
+
+# ---- blocks without a hit are not launched ------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("cam", ["oblique", "front", "x-axis-odd", "far", "away", "inside"])
+def test_blocks_without_a_hit_are_not_launched(ovr, oracle, hip_renderer_factory, cam):
+    """8x8-pixel blocks none of whose rays meets the volume's box get no march / composite workgroup (the schedule kernels test all 64 rays of a block
+    with the march's own expressions, so also the reference's ignored-slab quirk is answered as the march answers it) - their pixels are cleared
+    instead.  Frames (both layers), and every counter incl. rays and rendered pixels, equal the renderer that launches every block
+    (OVR_HIP_EMPTY_BLOCKS=0) bit for bit - through accumulation, a camera move, swaps, an image shard - and the oracle's."""
+    size = (121, 75) if cam == "x-axis-odd" else (136, 88)      # odd sizes: an axis-aligned camera's centre column has a ray with d.x == 0
+    case = make_case(ovr, oracle, n=32, tf="bumps", cam="oblique", size=size, shading=2)
+    c = np.array([16.0, 16.0, 16.0])
+    if cam == "x-axis-odd":
+        case["cam"] = (tuple(c + np.array([0.0, 90.0, 0.0]) + np.array([0.0, 0.0, 0.0])), tuple(c), (0.0, 0.0, 1.0))   # looking down -y: d.x == 0 in the centre column
+    elif cam == "far":
+        case["cam"] = (tuple(c + np.array([300.0, 210.0, 170.0])), tuple(c), (0.0, 0.0, 1.0))                          # a few blocks only
+    elif cam == "away":
+        case["cam"] = (tuple(c + np.array([60.0, 0.0, 0.0])), tuple(c + np.array([120.0, 5.0, 0.0])), (0.0, 0.0, 1.0))   # the volume is behind the camera: nothing to launch
+    elif cam != "oblique":
+        case["cam"] = make_case(ovr, oracle, n=32, cam=cam, size=size)["cam"]
+
+    def run(ren):
+        out = []
+        hip_setup(ovr, ren, case, accumulate=True)
+        for step in range(3):
+            ren.render()
+        st = ren.stats(); out.append((hip_frame(ovr, ren), (st.rays, st.samples, st.shaded_samples, st.shadow_samples, st.active_pixels)))
+        eye = tuple(np.array(case["cam"][0]) * 1.0 + np.array([3.0, -2.0, 1.5]))
+        ren.set_camera(ovr.Camera(eye, case["cam"][1], case["cam"][2], case["fovy"])); ren.commit()
+        ren.render(); ren.swap(); ren.render()
+        st = ren.stats(); out.append((hip_frame(ovr, ren), (st.rays, st.samples, st.shaded_samples, st.shadow_samples, st.active_pixels)))
+        ren.set_frame_accumulation(False); ren.set_camera(ovr.Camera(*case["cam"], case["fovy"])); ren.commit()     # back: blocks lit by the moved camera go dark again
+        ren.render(); ren.swap(); ren.render()
+        st = ren.stats(); out.append((hip_frame(ovr, ren), (st.rays, st.samples, st.shaded_samples, st.shadow_samples, st.active_pixels)))
+        ren.set_image_shard(1, 3, 16, 8); ren.commit(); ren.render()
+        st = ren.stats(); out.append((hip_frame(ovr, ren), (st.rays, st.samples, st.shaded_samples, st.shadow_samples, st.active_pixels)))
+        return out
+
+    os.environ["OVR_HIP_EMPTY_BLOCKS"] = "0"
+    try:
+        want = run(hip_renderer_factory())
+    finally:
+        del os.environ["OVR_HIP_EMPTY_BLOCKS"]
+    got = run(hip_renderer_factory())
+    for k, (((rgba, grad), cnt), ((rgba1, grad1), cnt1)) in enumerate(zip(got, want)):
+        assert np.array_equal(rgba, rgba1) and np.array_equal(grad, grad1), (cam, k)
+        assert cnt == cnt1, (cam, k, cnt, cnt1)
+    ref, _, ocnt = oracle_scene(oracle, case).render()
+    compare(oracle, got[2][0][0], ref, name=f"unaccumulated frame, camera {cam}")
+    assert got[2][1][1] == ocnt.samples and got[2][1][0] == size[0] * size[1]
+    if cam == "away":
+        assert got[0][1][1] == 0 and not got[0][0][0].any()
