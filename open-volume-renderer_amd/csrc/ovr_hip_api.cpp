@@ -242,8 +242,9 @@ struct ovr_hip_renderer {
   // and on the first frame of an accumulation (the accumulation buffer's turn).
   unsigned int* d_sched_info = nullptr;
   unsigned int n_work = 0, empty_pixels = 0, frame_empty_pixels = 0;
+  unsigned long long frame_empty_rays = 0;
   unsigned int clear_gen = 1, set_clear_gen[2] = { 0, 0 };
-  bool sched_exact = false;
+  int sched_exact = 0;
 
   // request pool of the pooled shading pipeline
   PoolDesc pool{};
@@ -910,16 +911,18 @@ int enqueue_frame(ovr_hip_renderer* r)
   P.n_schedule = 0;
   P.n_blocks_owned = 0;
   r->frame_empty_pixels = 0;
+  r->frame_empty_rays = 0;
   if (!sparse) {
     if (r->sched_list_dirty)
       if (int e = build_schedule_list(r)) return e;
     static const bool unsorted = getenv("OVR_HIP_SCHED_SORT") && atoi(getenv("OVR_HIP_SCHED_SORT")) == 0; // experiment: image (supertile) order
     static const bool skip_blocks = !(getenv("OVR_HIP_EMPTY_BLOCKS") && atoi(getenv("OVR_HIP_EMPTY_BLOCKS")) == 0); // 0: launch every block (measurements)
-    // a pixel's ray is known to the schedule kernels when it has one sample and no jitter: blocks without a hit are found exactly
-    const bool exact = skip_blocks && !unsorted && P.spp == 1 && P.jitter_mode == 0;
+    // a pixel's ray is known to the schedule kernels when it has one sample and no jitter: blocks without a hit are found exactly (1); with
+    // several samples or jitter its rays lie within half a pixel of the centre: blocks whose widened cone misses the box are found (2)
+    const int exact = (!skip_blocks || unsorted) ? 0 : (P.spp == 1 && P.jitter_mode == 0) ? 1 : 2;
     if (r->sched_dirty || exact != r->sched_exact) {
       if (!r->d_sched_info) HIP_TRY(hipMalloc((void**)&r->d_sched_info, 2 * sizeof(unsigned int)));
-      HIP_TRY(launch_schedule(P, r->d_sched_src, r->n_sched, r->d_sched, r->d_sched + r->n_sched, exact ? 1 : 0, r->d_sched_info, st));
+      HIP_TRY(launch_schedule(P, r->d_sched_src, r->n_sched, r->d_sched, r->d_sched + r->n_sched, exact, r->d_sched_info, st));
       r->n_work = r->n_sched;
       r->empty_pixels = 0;
       if (exact && r->n_sched > 0) { // how many entries need a workgroup: 8 bytes back from the device, once per camera / volume / size change
@@ -937,6 +940,7 @@ int enqueue_frame(ovr_hip_renderer* r)
     P.n_schedule = r->n_work;
     P.n_blocks_owned = r->n_sched;
     r->frame_empty_pixels = r->empty_pixels;
+    r->frame_empty_rays = (unsigned long long)r->empty_pixels * (unsigned long long)std::max(P.spp, 1); // every sample of a pixel is a ray
     if (r->n_work < r->n_sched) {
       const bool first_accumulated = accumulate && r->frame_index == 1;
       if (r->set_clear_gen[r->cur] != r->clear_gen || first_accumulated) {
@@ -1034,7 +1038,7 @@ int finish_frame_one(ovr_hip_renderer* r)
   r->stats.march_ms = m1;
   r->stats.shade_ms = m2;
   r->stats.composite_ms = m3;
-  r->stats.rays = r->h_counters[0] + r->frame_empty_pixels;   // (blocks without a hit are not launched: their pixels' rays missed)
+  r->stats.rays = r->h_counters[0] + r->frame_empty_rays;   // (blocks without a hit are not launched: their pixels' rays missed)
   r->stats.samples = r->h_counters[1];
   r->stats.shaded_samples = r->h_counters[2];
   r->stats.shadow_samples = r->h_counters[3];

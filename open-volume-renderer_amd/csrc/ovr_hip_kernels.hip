@@ -184,11 +184,50 @@ __global__ __launch_bounds__(256) void schedule_classify_kernel(const RayMarchPa
   const int ix = (int)(e & 0xffffu) * 8 + (lane & 7), iy = (int)(e >> 16) * 8 + (lane >> 3);
   bool active = ix < P.width && iy < P.height;
   if (P.world > 1 && active) active = ((ix / P.tile_w + iy / P.tile_h) % P.world) == P.rank; // assign_pixel_quad's ownership test
-  const bool hit = exact && active && pixel_ray_hits_box(P, mc, ix, iy);
+  const bool hit = exact == 1 && active && pixel_ray_hits_box(P, mc, ix, iy);
   const unsigned long long any = __ballot(hit), act = __ballot(active);
+  // exact == 2 (several samples per pixel, or jittered ones: a pixel's rays are only known to lie within half a pixel of its centre): the block
+  // is surely empty if the cone of ALL rays through the block widened by 1.5 pixels lies beyond one of its own four side planes from the whole
+  // box (frustum culling: 4 planes x 8 box corners, one pair per lane, object space), and no ray in it can have a direction component near 0
+  // (the reference's box test ignores the slab of such a component, shaders_common.h:162-172: a ray could then "hit" from outside the silhouette)
+  bool culled = false;
+  if (exact == 2) {
+    const float x0 = ((float)((int)(e & 0xffffu) * 8) - 1.5f) / (float)P.width - 0.5f, x1 = ((float)((int)(e & 0xffffu) * 8 + 8) + 1.5f) / (float)P.width - 0.5f;
+    const float y0 = ((float)((int)(e >> 16) * 8) - 1.5f) / (float)P.height - 0.5f, y1 = ((float)((int)(e >> 16) * 8 + 8) + 1.5f) / (float)P.height - 0.5f;
+    const f3 cd = ld3(P.cam_dir), ch = ld3(P.cam_hor), cv = ld3(P.cam_ver);
+    auto ray = [&](int k) { // corner k of the widened block, counter-clockwise; object-space direction (not normalised)
+      const float ux = (k == 1 || k == 2) ? x1 : x0, uy = (k >= 2) ? y1 : y0;
+      return mk3((cd.x + ux * ch.x + uy * cv.x) * mc.inv_scale.x, (cd.y + ux * ch.y + uy * cv.y) * mc.inv_scale.y, (cd.z + ux * ch.z + uy * cv.z) * mc.inv_scale.z);
+    };
+    const f3 oo = to_object(mc, ld3(P.cam_pos));
+    const int pl = (lane >> 3) & 3, cn = lane & 7;
+    const f3 a = ray(pl), b = ray((pl + 1) & 3), in = ray((pl + 2) & 3);
+    const f3 nrm = mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+    const float side = dot3(nrm, in);                                          // the sign of the cone's inside
+    const f3 v = mk3((float)(cn & 1) - oo.x, (float)((cn >> 1) & 1) - oo.y, (float)(cn >> 2) - oo.z);
+    const float d = dot3(nrm, v) * (side >= 0.f ? 1.f : -1.f);
+    const float scale = sqrtf(dot3(nrm, nrm) * dot3(v, v));
+    const bool outside = lane < 32 && fabsf(side) > 0.f && d < -1e-4f * scale;   // this corner lies beyond this plane, with a margin far above the rounding of the products
+    const unsigned int bits = (unsigned int)__ballot(outside);
+    bool beyond = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) beyond = beyond || ((bits >> (8 * k)) & 0xffu) == 0xffu;
+    // direction components over the widened block: linear in (ux, uy), so the extremes are at the corners
+    bool sign_safe = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float c00 = k == 0 ? ray(0).x : k == 1 ? ray(0).y : ray(0).z, c10 = k == 0 ? ray(1).x : k == 1 ? ray(1).y : ray(1).z;
+      const float c11 = k == 0 ? ray(2).x : k == 1 ? ray(2).y : ray(2).z, c01 = k == 0 ? ray(3).x : k == 1 ? ray(3).y : ray(3).z;
+      const float lo = fminf(fminf(c00, c10), fminf(c11, c01)), hi = fmaxf(fmaxf(c00, c10), fmaxf(c11, c01));
+      const float len = sqrtf(dot3(ray(0), ray(0)));
+      sign_safe = sign_safe && (lo > 1e-6f * len || hi < -1e-6f * len);
+    }
+    culled = beyond && sign_safe;
+  }
   if (lane == 0) {
     unsigned int c = schedule_class(P, mc, e);
-    if (exact) c = any != 0ull ? max(c, 1u) : 0u;
+    if (exact == 1) c = any != 0ull ? max(c, 1u) : 0u;
+    if (exact == 2) c = culled ? 0u : max(c, 1u);
     cls[i] = c | ((unsigned int)__popcll(act) << 8);
   }
 }
