@@ -13,7 +13,7 @@ for part in $parts; do
     bash tools/prof.sh r04_c3_dense --config c3 --tf dense $S
     bash tools/prof.sh r04_c3_front_dense --config c3 --camera front --tf dense $S ;;
   b)
-    bash tools/prof.sh r04_c3_rate4 --config c3 --rate 4 --steps 4 --warmup 2
+    bash tools/prof.sh r04_c3_rate4 --config c3 --rate 4 --steps 12 --warmup 3
     bash tools/prof.sh r04_c3_fovy45 --config c3 --fovy 45 $S
     bash tools/prof.sh r04_c3_sparse --config c3 --sparse-sampling $S
     bash tools/prof.sh r04_c3_gradient --config c3 --shading 1 $S ;;
