@@ -213,7 +213,9 @@ int ovr_hip_commit(ovr_hip_renderer* r);
 /* replaces DeviceOptix7::render (optix7/device.cpp:35-43, device_impl.cpp:199-269): one frame, blocking until the
  * frame is complete on the device; adds the elapsed milliseconds to the value ovr_hip_render_time_ms() returns. */
 int ovr_hip_render(ovr_hip_renderer* r);
-/* non-blocking variant: enqueues the frame on the renderer's stream and returns (for hipEvent timing / graphs) */
+/* non-blocking variant: enqueues the frame on the renderer's stream and returns (for hipEvent timing / graphs).  (Round 4: the first frame after
+ * a camera / volume / size change reads 8 bytes back from the device before it launches - how many 8x8-pixel blocks have a ray that meets the
+ * volume's box; the others get no workgroup, their pixels are cleared - a stream synchronisation of ~20 us.) */
 int ovr_hip_render_async(ovr_hip_renderer* r);
 /* waits for the frame enqueued by render_async and for everything else enqueued on the renderer's stream
  * (ovr_hip_pack_tiles / ovr_hip_unpack_tiles launches included) */
