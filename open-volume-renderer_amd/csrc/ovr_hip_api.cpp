@@ -264,6 +264,10 @@ struct ovr_hip_renderer {
   // group_size (ovr_hip_set_image_shard semantics, volume replicated) and the leader - members[0], the handle the caller holds - gathers the
   // followers' tiles into its own framebuffer at the end of every frame.  A follower is an ordinary renderer whose `leader` is set.
   std::vector<ovr_hip_renderer*> members; // leader only: every member, itself first
+  // A setter on a group queues its value on every member; ovr_hip_commit applies the queued values member by member.  Both hold this mutex of the
+  // leader, so a commit on the render thread never falls between the members of one setter call on the GUI thread (a frame whose tiles come from
+  // two cameras); the reference's TransactionalValue gives the same guarantee per value (vidi_transactional_value.h:75-103)
+  std::mutex group_mtx;
   ovr_hip_renderer* leader = nullptr;     // follower only
   int group_rank = 0;
   int gather_kind = 0;                    // leader: 0 = no group, 1 = peer copies, 2 = RCCL send / recv
@@ -1214,6 +1218,12 @@ const RcclApi& rccl_api()
 }
 constexpr int kNcclFloat = 7; // ncclFloat32, rccl.h
 
+// (see ovr_hip_renderer::group_mtx; followers are only ever called with their leader's lock held)
+struct GroupLock {
+  std::unique_lock<std::mutex> lk;
+  explicit GroupLock(ovr_hip_renderer* r) { if (r && !r->leader && r->members.size() > 1) lk = std::unique_lock<std::mutex>(r->group_mtx); }
+};
+
 #define GROUP_FORWARD(r, call)                                                                                          \
   do {                                                                                                                  \
     for (size_t i_ = 1; i_ < (r)->members.size(); ++i_) {                                                               \
@@ -1780,6 +1790,7 @@ int ovr_hip_set_grid_convention(ovr_hip_renderer* r, int c)
 {
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
   if (c != OVR_HIP_GRID_CELL_CENTRED && c != OVR_HIP_GRID_VERTEX_CENTRED) return fail(OVR_HIP_EINVAL, "[hip] unknown grid convention");
+  GroupLock gl(r);
   { std::lock_guard<std::mutex> lk(r->mtx); r->grid_convention.set(c); }
   GROUP_FORWARD(r, ovr_hip_set_grid_convention(m, c));
   return 0;
@@ -1791,6 +1802,7 @@ int ovr_hip_set_transfer_function(ovr_hip_renderer* r, const float* colors, int3
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
   if (n_colors < 0 || n_alphas < 0 || (n_colors > 0 && !colors) || (n_alphas > 0 && !alphas))
     return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_transfer_function: bad arguments");
+  GroupLock gl(r);
   {
     std::lock_guard<std::mutex> lk(r->mtx);
     TfnP t;
@@ -1807,6 +1819,7 @@ int ovr_hip_set_transfer_function(ovr_hip_renderer* r, const float* colors, int3
 int ovr_hip_set_camera(ovr_hip_renderer* r, const float from[3], const float at[3], const float up[3], float fovy)
 {
   if (!r || !from || !at || !up) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_camera: null argument");
+  GroupLock gl(r);
   {
     std::lock_guard<std::mutex> lk(r->mtx);
     CameraP c;
@@ -1824,6 +1837,7 @@ int ovr_hip_set_fbsize(ovr_hip_renderer* r, int32_t w, int32_t h)
 {
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
   if (w < 0 || h < 0) return fail(OVR_HIP_EINVAL, "[hip] negative framebuffer size");
+  GroupLock gl(r);
   { std::lock_guard<std::mutex> lk(r->mtx); Size2 s; s.w = w; s.h = h; r->fbsize.set(s); }
   GROUP_FORWARD(r, ovr_hip_set_fbsize(m, w, h));
   return 0;
@@ -1834,6 +1848,7 @@ int ovr_hip_set_fbsize(ovr_hip_renderer* r, int32_t w, int32_t h)
   {                                                                                                                    \
     if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");                                                        \
     if (!(check)) return fail(OVR_HIP_EINVAL, msg);                                                                    \
+    GroupLock gl(r);                                                                                                   \
     { std::lock_guard<std::mutex> lk(r->mtx); r->field.set(v); }                                                       \
     GROUP_FORWARD(r, name(m, v));                                                                                      \
     return 0;                                                                                                          \
@@ -1853,6 +1868,7 @@ OVR_SIMPLE_SETTER(ovr_hip_set_pixel_jitter, jitter, int32_t, v == 0 || v == 1, "
 int ovr_hip_set_focus(ovr_hip_renderer* r, float cx, float cy, float scale, float base_noise)
 {
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
+  GroupLock gl(r);
   { std::lock_guard<std::mutex> lk(r->mtx); FocusP f; f.cx = cx; f.cy = cy; f.scale = scale; f.base_noise = base_noise; r->focus.set(f); }
   GROUP_FORWARD(r, ovr_hip_set_focus(m, cx, cy, scale, base_noise));
   return 0;
@@ -1884,6 +1900,7 @@ int ovr_hip_set_image_shard(ovr_hip_renderer* r, int32_t rank, int32_t world, in
 {
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
   if (world < 1 || rank < 0 || rank >= world || tw < 1 || th < 1) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_image_shard: bad arguments");
+  GroupLock gl(r);
   if (r->members.size() > 1) { // a device group shards the image among its members itself: only the tile size is the caller's
     if (world != 1) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_image_shard: a device group cannot be one rank of a larger shard (use world = 1 to set its tile size)");
     for (size_t i = 0; i < r->members.size(); ++i) {
@@ -1905,6 +1922,7 @@ int ovr_hip_commit(ovr_hip_renderer* r)
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
   if (int e = set_device(r)) return e;
   if (int e = finish_frame(r)) return e;
+  GroupLock gl(r); // every member applies the same queued values: no setter call of another thread is split between them
   GROUP_FORWARD(r, ovr_hip_commit(m));
   std::lock_guard<std::mutex> lk(r->mtx);
   const bool reset_pending = r->fb_reset; // (without accumulation the flag is never consumed)

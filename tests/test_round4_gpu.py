@@ -412,3 +412,43 @@ def test_blocks_without_a_hit_are_not_launched(ovr, oracle, hip_renderer_factory
         assert got[2][1][1] == ocnt.samples
     if cam == "away":
         assert got[0][1][1] == 0 and not got[0][0][0].any()
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]])
+def test_setters_from_another_thread_never_tear_a_frame(ovr, oracle, hip_renderer_factory, devices):
+    """include/ovr_hip.h: "setters may be called from any thread".  A thread hammers set_camera (four cameras) on the handle while this one loops
+    commit -> render -> mapframe: every frame is the frame of exactly one camera - on a device group too, where a setter queues its value on every
+    member and a commit must not fall between them (ovr_hip_renderer::group_mtx)."""
+    import threading
+    case = make_case(ovr, oracle, n=32, tf="bumps", cam="oblique", size=(120, 72), shading=1)
+    cams = [tuple(np.array(case["cam"][0]) * (1.0 + 0.12 * k)) for k in range(4)]
+    ren = ovr.create_renderer("hip", devices=devices) if devices else hip_renderer_factory()
+    try:
+        hip_setup(ovr, ren, case)
+        refs = []
+        for eye in cams:
+            ren.set_camera(ovr.Camera(eye, case["cam"][1], case["cam"][2], case["fovy"])); ren.commit(); ren.render()
+            refs.append(hip_frame(ovr, ren)[0].tobytes())
+        assert len(set(refs)) == 4
+        stop = threading.Event()
+
+        def hammer():
+            rng = np.random.default_rng(5)
+            while not stop.is_set():
+                ren.set_camera(ovr.Camera(cams[int(rng.integers(4))], case["cam"][1], case["cam"][2], case["fovy"]))
+
+        th = threading.Thread(target=hammer)
+        th.start()
+        seen = set()
+        try:
+            for _ in range(600):
+                ren.commit(); ren.render()
+                f = hip_frame(ovr, ren)[0].tobytes()
+                assert f in refs, "a frame that belongs to no single camera"
+                seen.add(refs.index(f))
+        finally:
+            stop.set(); th.join()
+        assert len(seen) >= 3
+    finally:
+        if devices:
+            ren.close()
