@@ -2,7 +2,7 @@
  *
  * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  Every entry point
  * replaces one member of the reference's device interface; `file:line` citations are relative to the
- * reference tree (VIDILabs/open-volume-renderer).  The reference-side binding (a ~160-line
+ * reference tree (VIDILabs/open-volume-renderer).  The reference-side binding (a ~180-line
  * `DeviceHIP : ovr::MainRenderer` compiled against the reference's own headers and exported as
  * `ovr_create_renderer__hip`, the symbol ovr/renderer.cpp:55-58 looks up) lives in plugin/device_hip.cpp
  * and is described in INTEGRATION.md.
