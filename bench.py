@@ -456,16 +456,18 @@ def worker(args, world):
         # ... and so do the frames rendered from the general layout while the replica the camera asks for is still being built in the
         # background (ovr_hip_stats.replicas_building).  N > 1: every rank probes / builds on its own - the ranks agree on one more step
         # while ANY of them is still at it (those frames used to land in the timed steps of the multi-GPU line)
-        def unsettled():
+        def unsettled(expired):
+            # (every rank makes the same number of these calls: the loop below ends on the REDUCED flag and on counters all ranks share - a
+            # rank whose own patience has run out keeps answering "settled" instead of leaving the collective)
             st = ren.stats()
-            mine = st.tuning == 1 or st.replicas_building > 0
+            mine = (st.tuning == 1 or st.replicas_building > 0) and not expired
             if dist is None:
                 return mine
             flag = torch.tensor([1 if mine else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             return bool(flag.item())
         extra, t_settle = 0, time.perf_counter()
-        while extra < 64 and step.count > 0 and time.perf_counter() - t_settle < 3.0 and unsettled():
+        while extra < 64 and step.count > 0 and unsettled(time.perf_counter() - t_settle > 3.0):
             step()
             extra += 1
             if ren.stats().replicas_building > 0:
