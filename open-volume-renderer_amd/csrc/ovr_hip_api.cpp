@@ -688,7 +688,9 @@ void build_replica_host(ovr_hip_renderer* r, int k, std::string* err)
   if (e == hipSuccess) e = hipMalloc(&d_tab, axis_table_bytes(t));
   if (e == hipSuccess) {
     t.data = d_data;
-    e = hipMemsetAsync(d_data, 0, (size_t)t.bytes + 64, r->build_stream); // padding voxels are never sampled, but must be finite
+    // padding voxels are never sampled, but must be finite: the build writes them itself (launch_relayout), only the slack is set here
+    if (getenv("OVR_HIP_POISON_ALLOC") && atoi(getenv("OVR_HIP_POISON_ALLOC")) != 0) e = hipMemsetAsync(d_data, 0xff, (size_t)t.bytes, r->build_stream);
+    if (e == hipSuccess) e = hipMemsetAsync((char*)d_data + (size_t)t.bytes, 0, 64, r->build_stream);
   }
   if (e == hipSuccess) e = launch_axis_tables(t, d_tab, r->build_stream);
   if (e == hipSuccess) {
@@ -1408,7 +1410,7 @@ int ovr_hip_create(ovr_hip_renderer** out, int device_id)
     for (int k = 0; k < kLayouts; ++k) HIP_TRY(hipEventCreateWithFlags(&r->build_ev[k], hipEventDisableTiming));
     HIP_TRY(hipMalloc((void**)&r->d_counters, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc((void**)&r->d_sparse_count, sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc((void**)&r->d_data_range, 2 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&r->d_data_range, minmax_reduce_floats() * sizeof(float)));
     HIP_TRY(hipHostMalloc((void**)&r->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
     return 0;
   };
@@ -1654,7 +1656,9 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
   r->d_volume = nullptr;
   r->have_volume = false; // until the new one is completely resident: a failure below must not leave a half-built volume renderable
   HIP_TRY(hipMalloc(&r->d_replica[0], bytes + 64)); // + slack: the pair load of the very last element
-  HIP_TRY(hipMemset(r->d_replica[0], 0, bytes + 64));  // padding voxels are never sampled, but must be finite
+  // (tests: OVR_HIP_POISON_ALLOC=1 fills a fresh layout with 0xff bytes - NaN / the type's extreme - first: a padding element the build left out would show)
+  if (getenv("OVR_HIP_POISON_ALLOC") && atoi(getenv("OVR_HIP_POISON_ALLOC")) != 0) HIP_TRY(hipMemsetAsync(r->d_replica[0], 0xff, bytes, st_));
+  HIP_TRY(hipMemsetAsync((char*)r->d_replica[0] + bytes, 0, 64, st_)); // the slack; the relayout launches write every element of the layout itself, padding included
   r->d_volume = r->d_replica[0];
   r->volume_bytes = bytes;
   vd.data = r->d_volume;

@@ -191,6 +191,9 @@ inline bool layout_offsets_fit(const VolumeDesc& vd)
 {
   return (unsigned long long)vd.macro_elems * (unsigned long long)vd.macros_x * (unsigned long long)vd.macros_y <= 0x100000000ull;
 }
+// slices [z0, z0 + nz_chunk) of the caller's linear array into the layout vd describes.  The launches for all slices together write EVERY element
+// of the allocation (padding rows, cells and layers as zeros - never sampled, but they have to be finite -, by the launch of the last slices), so
+// dst needs no memset
 hipError_t launch_relayout(const void* src_linear, int ovr_value_type, void* dst, const VolumeDesc& vd, int z0, int nz_chunk,
                            hipStream_t stream);
 // a replica (vd: one of the _T / _TT / _Q layouts, dst = its storage) built from the volume's resident GENERAL layout: the replicas are
@@ -226,7 +229,9 @@ hipError_t launch_macrocell_majorants(const float* minmax, unsigned int count, c
                                       hipStream_t stream);
 
 // global (min, max) of the macrocell value ranges = the volume's data range as the device's voxel read returns it
-// (compute_scalar_range + cuda_scalar_range, array.cpp:27-66,92-108); out = 2 floats on the device
+// (compute_scalar_range + cuda_scalar_range, array.cpp:27-66,92-108); out = minmax_reduce_floats() floats on the device: the result in
+// out[0 .. 1], behind it the partial ranges of the first of the two launches
+size_t minmax_reduce_floats();
 hipError_t launch_minmax_reduce(const float* minmax, unsigned long long cells, float* out, hipStream_t stream);
 
 // occupancy grids (one byte per 4^3 macrocells / per macrocell, both dilated by one macrocell) for the march's per-ray skip intervals

@@ -453,11 +453,13 @@ template <> struct Conv<int, float> { // array.h:78-90
 // resident GENERAL layout of the same volume (replicas built in the background, round 4: every replica is a permutation of the general layout's voxels)
 template <typename TI> struct SrcLinear {
   typedef TI value_type;
+  static constexpr bool kLinear = true;
   const TI* p; int nx, ny, z0;
   __device__ __forceinline__ TI get(size_t x, size_t y, unsigned z) const { return p[x + (size_t)nx * (y + (size_t)ny * (size_t)(z - (unsigned)z0))]; }
 };
 template <int VTB> struct SrcBricked {
   typedef typename Vox<VTB>::T value_type;
+  static constexpr bool kLinear = false;
   const value_type* p; unsigned int macro_y; unsigned long long macro_z;
   __device__ __forceinline__ value_type get(size_t x, size_t y, unsigned z) const
   {
@@ -466,58 +468,129 @@ template <int VTB> struct SrcBricked {
   }
 };
 
+// One thread per brick ROW (the SX stored voxels of one (y, z) line of a brick: 8 or 16 bytes), rows taken in the order the layout stores them:
+// a workgroup owns the 32 y x 2^bz z slab of one macro row and sweeps it along the pair axis, macro block by macro block - inside a macro block
+// that slab is ONE contiguous piece of the layout ((32 >> by) * mbx bricks, 10 KiB for f32), so consecutive lanes store consecutive vectors and
+// every 128-byte line leaves the workgroup complete.  (Until round 4 a thread was one stored voxel and a workgroup one source row: a 16-byte
+// piece of every line per workgroup, the rest of the line from 7 other workgroups on other XCDs - 8.8 ms for C3's 10 GB, 0.14 of the HBM peak.)
+// The source rows of the slab (64 for f32) are read in step along x: each line of the caller's array is fetched once and used up within the workgroup.
+template <typename TI, int N> struct __attribute__((packed, aligned(sizeof(TI)))) RowIn { TI v[N]; };
+template <typename TO, int N> struct alignas(sizeof(TO) * N) RowOut { TO v[N]; };
+
 template <typename SRC, typename TO, int VT>
-__global__ __launch_bounds__(256) void relayout_kernel(const SRC src, TO* __restrict__ dst, int nx, int ny, int bricks_a, unsigned int macro_y,
-                                                      unsigned long long macro_z, int z0, int nz_chunk)
+__global__ __launch_bounds__(256) void relayout_kernel(const SRC src, TO* __restrict__ dst, int nx, int ny, int macros_a, unsigned int macro_y,
+                                                      unsigned long long macro_z, int z0, int nz_chunk, int nz)
 {
   typedef typename SRC::value_type TI;
   // layout axes (a, b, z): a = pair axis = x (y in a transposed replica), b = the other one
-  // grid: x = ceil(bricks_a * SX / 256) over STORED a positions, y = nb, z = nz_chunk ; src holds slices [z0, z0 + nz_chunk)
+  // grid: x = macro rows along b, y = z layers (2^bz slices each) that meet [z0, z0 + nz_chunk) - and, in the launch of the volume's last
+  // slices, the padding layers up to the end of the allocation ; src holds slices [z0, z0 + nz_chunk)
   typedef BrickMap<VT> M;
-  constexpr bool TR = Vox<VT>::kTransposed;
-  const unsigned sa = blockIdx.x * 256 + threadIdx.x;
-  const int b = blockIdx.y, zl = blockIdx.z;
-  if (sa >= (unsigned)bricks_a * M::SX || zl >= nz_chunk) return;
-  const unsigned br = sa / M::SX, ar = sa - br * M::SX;  // brick and position inside its row (ar == cx is the apron)
-  const unsigned a = br * Vox<VT>::cx + ar;              // stored position = voxel index + 1 (BrickMap::X)
-  // clamp addressing baked into the data: position 0 is a copy of voxel 0, positions beyond the grid replicate the last voxel
-  const unsigned as = (unsigned)min(max((int)a - 1, 0), (TR ? ny : nx) - 1);
-  const unsigned z = (unsigned)(z0 + zl);
-  const size_t x = TR ? (size_t)b : (size_t)as, y = TR ? (size_t)as : (size_t)b;
-  const TI v = src.get(x, y, z);
-  const unsigned m = M::div_mbx(br), bm = br - m * Vox<VT>::mbx;
-  const unsigned long long off = (unsigned long long)(ar + bm * M::BV + m * M::MV) + M::Y((unsigned)b, macro_y) + M::Zlo(z) + (unsigned long long)(z >> 5) * macro_z;
-  dst[off] = Conv<TI, TO>::cv(v);
+  typedef Vox<VT> V;
+  constexpr bool TR = V::kTransposed;
+  constexpr unsigned SX = M::SX, RB = 1u << (V::by + V::bz);   // stored voxels per row, rows per brick
+  constexpr unsigned ROWS = M::sbz / SX;                        // rows of the slab inside one macro block
+  constexpr unsigned LZ = 32u >> V::bz;                         // z layers per macro block
+  static_assert(ROWS * SX == M::sbz && ROWS == (32u >> V::by) * V::mbx * RB, "the slab is the layout's z-layer stride");
+  const int na = TR ? ny : nx, nb = TR ? nx : ny;
+  const unsigned my = blockIdx.x, layer = ((unsigned)z0 >> V::bz) + blockIdx.y;
+  const unsigned long long slab = (unsigned long long)my * macro_y + (unsigned long long)(layer & (LZ - 1u)) * M::sbz + (unsigned long long)(layer / LZ) * macro_z;
+  const unsigned total = (unsigned)macros_a * ROWS;
+  for (unsigned g = threadIdx.x; g < total; g += 256u) {
+    const unsigned mx = g / ROWS, i = g - mx * ROWS;
+    const unsigned rr = i & (RB - 1u), bi = i / RB;
+    const unsigned ybk = bi / V::mbx, bm = bi - ybk * V::mbx;
+    const unsigned b = my * 32u + (ybk << V::by) + (rr & ((1u << V::by) - 1u));
+    const unsigned z = (layer << V::bz) + (rr >> V::by);
+    RowOut<TO, SX>* const row = reinterpret_cast<RowOut<TO, SX>*>(dst + slab + (unsigned long long)mx * M::MV + (unsigned long long)i * SX);
+    if (b >= (unsigned)nb || z >= (unsigned)nz) { // a padding row: never sampled, but finite (the allocation needs no memset)
+      if (z >= (unsigned)z0) {                    // ... written once: by the launch whose slices the row's layer belongs to (or the last one)
+        RowOut<TO, SX> zero;
+#pragma unroll
+        for (unsigned k = 0; k < SX; ++k) zero.v[k] = (TO)0;
+        *row = zero;
+      }
+      continue;
+    }
+    if (z < (unsigned)z0 || z >= (unsigned)(z0 + nz_chunk)) continue; // another launch's slices
+    // the row's stored positions a0 ... a0 + SX - 1 = voxels a0 - 1 ... (clamp addressing baked into the data: position 0 is a copy of voxel 0,
+    // positions beyond the grid replicate the last voxel)
+    const int v0 = (int)((mx * V::mbx + bm) * V::cx) - 1;
+    TI in[SX];
+    bool done = false;
+    if constexpr (SRC::kLinear && !TR) {
+      if (v0 >= 0 && v0 + (int)SX <= nx) { // the whole row lies inside the grid: one (unaligned) vector load
+        const RowIn<TI, SX> w = *reinterpret_cast<const RowIn<TI, SX>*>(src.p + ((size_t)v0 + (size_t)nx * ((size_t)b + (size_t)ny * (size_t)(z - (unsigned)z0))));
+#pragma unroll
+        for (unsigned k = 0; k < SX; ++k) in[k] = w.v[k];
+        done = true;
+      }
+    }
+    if (!done) {
+#pragma unroll
+      for (unsigned k = 0; k < SX; ++k) {
+        const size_t as = (size_t)min(max(v0 + (int)k, 0), na - 1);
+        in[k] = TR ? src.get((size_t)b, as, z) : src.get(as, (size_t)b, z);
+      }
+    }
+    RowOut<TO, SX> out;
+#pragma unroll
+    for (unsigned k = 0; k < SX; ++k) out.v[k] = Conv<TI, TO>::cv(in[k]);
+    *row = out;
+  }
 }
 
 // quad replicas: one thread per cell writes the cell's 2 x 2 (x, y) voxels of its z slice as one 4-vector, neighbours beyond the
-// grid replaced by the last voxel (clamp-to-edge addressing)
+// grid replaced by the last voxel (clamp-to-edge addressing).  Cells in storage order, like relayout_kernel's rows: a workgroup owns the
+// 32 cells (y) x 2^lz slices slab of one macro row - inside a macro block one contiguous 32 KiB piece - and sweeps it along x, so every
+// 128-byte line is written whole (the thread-per-cell-along-x form of round 3 built C3's 17 GB replica in 40 ms), padding cells as zeros.
 template <typename SRC, int VT>
-__global__ __launch_bounds__(256) void relayout_quad_kernel(const SRC src, typename Vox<VT>::T* __restrict__ dst, int nx, int ny, unsigned int macro_y,
-                                                           unsigned long long macro_z, int z0, int nz_chunk)
+__global__ __launch_bounds__(256) void relayout_quad_kernel(const SRC src, typename Vox<VT>::T* __restrict__ dst, int nx, int ny, int macros_x, unsigned int macro_y,
+                                                           unsigned long long macro_z, int z0, int nz_chunk, int nz)
 {
   typedef typename SRC::value_type TI;
   typedef BrickMap<VT> M;
-  typedef typename Vox<VT>::T TO;
-  typedef typename Vox<VT>::Q Q;
-  // one thread per CELL (u, v) = (x + 1, y + 1), x in [-1, nx - 1], y in [-1, ny - 1]: grid x covers nx + 1 cells, grid y = ny + 1
-  const int u = (int)(blockIdx.x * 256u + threadIdx.x), v = (int)blockIdx.y, zl = (int)blockIdx.z;
-  if (u > nx || zl >= nz_chunk) return;
-  const int x = max(u - 1, 0), y = max(v - 1, 0);
-  const int x1 = min(u, nx - 1), y1 = min(v, ny - 1);
-  const unsigned z = (unsigned)(z0 + zl);
-  Q q;
-  q.x = Conv<TI, TO>::cv(src.get((size_t)x, (size_t)y, z)); q.y = Conv<TI, TO>::cv(src.get((size_t)x1, (size_t)y, z));
-  q.z = Conv<TI, TO>::cv(src.get((size_t)x, (size_t)y1, z)); q.w = Conv<TI, TO>::cv(src.get((size_t)x1, (size_t)y1, z));
-  const unsigned long long off = (unsigned long long)(M::X((unsigned)u) + M::Y((unsigned)v, macro_y)) + M::Zlo(z) + (unsigned long long)(z >> 5) * macro_z;
-  *reinterpret_cast<Q*>(dst + off) = q;
+  typedef Vox<VT> V;
+  typedef typename V::T TO;
+  typedef typename V::Q Q;
+  constexpr unsigned CB = 1u << (V::lx + V::ly + V::lz);          // cells per brick
+  constexpr unsigned LAYER = M::bx_ * M::by_ * M::BV;             // elements of one z layer (2^lz slices) of a macro block
+  constexpr unsigned CELLS = M::bx_ * M::by_ * CB;                // ... and its cells
+  constexpr unsigned LZ = 32u >> V::lz;
+  static_assert(CB * 4u == M::BV && CELLS * 4u == LAYER, "a brick is CB cells of 4 elements");
+  // grid: x = macro rows along y, y = z layers that meet [z0, z0 + nz_chunk) (+ the padding layers, in the launch of the last slices)
+  const unsigned my = blockIdx.x, layer = ((unsigned)z0 >> V::lz) + blockIdx.y;
+  const unsigned long long slab = (unsigned long long)my * macro_y + (unsigned long long)(layer & (LZ - 1u)) * LAYER + (unsigned long long)(layer / LZ) * macro_z;
+  const unsigned total = (unsigned)macros_x * CELLS;
+  for (unsigned g = threadIdx.x; g < total; g += 256u) {
+    const unsigned mx = g / CELLS, i = g - mx * CELLS;
+    const unsigned j = i & (CB - 1u), brick = i / CB;
+    // cell (u, v) = (x + 1, y + 1), x in [-1, nx - 1], y in [-1, ny - 1]
+    const int u = (int)(mx * 32u + ((brick & (M::bx_ - 1u)) << V::lx) + (j & ((1u << V::lx) - 1u)));
+    const int v = (int)(my * 32u + ((brick / M::bx_) << V::ly) + ((j >> V::lx) & ((1u << V::ly) - 1u)));
+    const unsigned z = (layer << V::lz) + (j >> (V::lx + V::ly));
+    Q* const cell = reinterpret_cast<Q*>(dst + slab + (unsigned long long)mx * M::MV + (unsigned long long)i * 4u);
+    if (u > nx || v > ny || z >= (unsigned)nz) { // a padding cell: never sampled, but finite
+      if (z >= (unsigned)z0) { Q zero; zero.x = zero.y = zero.z = zero.w = (TO)0; *cell = zero; }
+      continue;
+    }
+    if (z < (unsigned)z0 || z >= (unsigned)(z0 + nz_chunk)) continue; // another launch's slices
+    const int x = max(u - 1, 0), y = max(v - 1, 0);
+    const int x1 = min(u, nx - 1), y1 = min(v, ny - 1);
+    Q q;
+    q.x = Conv<TI, TO>::cv(src.get((size_t)x, (size_t)y, z)); q.y = Conv<TI, TO>::cv(src.get((size_t)x1, (size_t)y, z));
+    q.z = Conv<TI, TO>::cv(src.get((size_t)x, (size_t)y1, z)); q.w = Conv<TI, TO>::cv(src.get((size_t)x1, (size_t)y1, z));
+    *cell = q;
+  }
 }
 template <typename SRC, int VT>
 static hipError_t relayout_quad_s(const SRC& src, void* dst, const VolumeDesc& vd, int z0, int nzc, hipStream_t stream)
 {
-  dim3 grid((unsigned)((vd.nx + 1 + 255) / 256), (unsigned)(vd.ny + 1), (unsigned)nzc);
-  hipLaunchKernelGGL((relayout_quad_kernel<SRC, VT>), grid, dim3(256), 0, stream, src, (typename Vox<VT>::T*)dst, vd.nx, vd.ny, vd.macro_elems * (unsigned)vd.macros_x,
-                     (unsigned long long)vd.macro_elems * (unsigned long long)vd.macros_x * (unsigned long long)vd.macros_y, z0, nzc);
+  if (nzc <= 0) return hipSuccess;
+  const unsigned last = z0 + nzc >= vd.nz ? (unsigned)vd.macros_z * (32u >> Vox<VT>::lz) - 1u : (unsigned)(z0 + nzc - 1) >> Vox<VT>::lz;
+  dim3 grid((unsigned)vd.macros_y, last - ((unsigned)z0 >> Vox<VT>::lz) + 1u);
+  hipLaunchKernelGGL((relayout_quad_kernel<SRC, VT>), grid, dim3(256), 0, stream, src, (typename Vox<VT>::T*)dst, vd.nx, vd.ny, vd.macros_x, vd.macro_elems * (unsigned)vd.macros_x,
+                     (unsigned long long)vd.macro_elems * (unsigned long long)vd.macros_x * (unsigned long long)vd.macros_y, z0, nzc, vd.nz);
   return hipGetLastError();
 }
 template <typename TI, int VT>
@@ -529,12 +602,13 @@ static hipError_t relayout_quad_t(const void* src, void* dst, const VolumeDesc& 
 template <typename SRC, typename TO, int VT>
 static hipError_t relayout_s(const SRC& src, void* dst, const VolumeDesc& vd, int z0, int nzc, hipStream_t stream)
 {
-  typedef BrickMap<VT> M;
-  const int bricks_a = vd.macros_x * Vox<VT>::mbx;
-  const int nb = Vox<VT>::kTransposed ? vd.nx : vd.ny;
-  dim3 grid((unsigned)((bricks_a * M::SX + 255) / 256), (unsigned)nb, (unsigned)nzc);
-  hipLaunchKernelGGL((relayout_kernel<SRC, TO, VT>), grid, dim3(256), 0, stream, src, (TO*)dst, vd.nx, vd.ny, bricks_a,
-                     vd.macro_elems * (unsigned)vd.macros_x, (unsigned long long)vd.macro_elems * (unsigned long long)vd.macros_x * (unsigned long long)vd.macros_y, z0, nzc);
+  if (nzc <= 0) return hipSuccess;
+  // the launch of the volume's last slices also writes the padding layers behind them
+  const unsigned last = z0 + nzc >= vd.nz ? (unsigned)vd.macros_z * (32u >> Vox<VT>::bz) - 1u : (unsigned)(z0 + nzc - 1) >> Vox<VT>::bz;
+  const unsigned layers = last - ((unsigned)z0 >> Vox<VT>::bz) + 1u;
+  dim3 grid((unsigned)vd.macros_y, layers);
+  hipLaunchKernelGGL((relayout_kernel<SRC, TO, VT>), grid, dim3(256), 0, stream, src, (TO*)dst, vd.nx, vd.ny, vd.macros_x,
+                     vd.macro_elems * (unsigned)vd.macros_x, (unsigned long long)vd.macro_elems * (unsigned long long)vd.macros_x * (unsigned long long)vd.macros_y, z0, nzc, vd.nz);
   return hipGetLastError();
 }
 template <typename TI, typename TO, int VT>
@@ -701,32 +775,53 @@ hipError_t launch_axis_tables(VolumeDesc& vd, void* d_tables, hipStream_t stream
 // them; here the ray marcher and the shadow march skip the voxel fetch of samples whose cell has majorant 0 - such a
 // sample's opacity is exactly 0, so frames are bit-identical with and without skipping.
 // ------------------------------------------------------------------------------------------------------------------
-// value_range_kernel, sp_singlemc.cu:10-54: one WAVE per macrocell (the reference uses one thread), wave min/max reduction
+// value_range_kernel, sp_singlemc.cu:10-54: one WAVE per macrocell (the reference uses one thread), wave min/max reduction.
+// A lane owns (y, z) ROWS of the cell's 18^3 box - rows in storage order, so the four lanes of a quad read 64 contiguous bytes - and walks each
+// along x brick by brick: one 8- or 16-byte load per brick row (SX stored voxels), the voxels outside the box masked.  (Until round 4: one voxel per
+// lane and step, each with its own offset arithmetic and three runtime divisions - 2.8 ms for C3, 20.6 ms for C4, bound by the gather-instruction rate.)
 template <int VT>
 __global__ __launch_bounds__(256) void macrocell_range_kernel(const void* __restrict__ vol, VolumeDesc vd, int mcx, int mcy, int mcz, float2* __restrict__ out)
 {
   typedef BrickMap<VT> M;
-  typedef typename Vox<VT>::T T;
+  typedef Vox<VT> V;
+  typedef typename V::T T;
+  constexpr unsigned SX = M::SX, HY = 1u << V::by, HZ = 1u << V::bz;   // a brick: SX x HY x HZ stored voxels
+  constexpr int W = 16;
+  // brick-aligned spans that hold W + 2 rows at any alignment
+  constexpr unsigned AY = (W + 2 + 2 * (HY - 1) + HY - 1) / HY, AZ = (W + 2 + 2 * (HZ - 1) + HZ - 1) / HZ; // in bricks
   const int lane = threadIdx.x & 63;
   const unsigned long long cell = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (cell >= (unsigned long long)mcx * mcy * mcz) return;
   const int cx = (int)(cell % mcx), cy = (int)((cell / mcx) % mcy), cz = (int)(cell / ((unsigned long long)mcx * mcy));
-  const int W = 16;
   const int bx = max(cx * W - 1, 0), by = max(cy * W - 1, 0), bz = max(cz * W - 1, 0);
   const int ex = min(bx + W + 1, vd.nx), ey = min(by + W + 1, vd.ny), ez = min(bz + W + 1, vd.nz);
-  const int dx = ex - bx, dy = ey - by, dz = ez - bz;
   const unsigned macro_y = vd.macro_elems * (unsigned)vd.macros_x;
   const unsigned long long macro_z = (unsigned long long)vd.macro_elems * vd.macros_x * vd.macros_y;
   const T* base = static_cast<const T*>(vol);
+  // voxel x is stored at position x + 1: brick (x + 1) / cx, whose row holds the voxels brick * cx - 1 ... brick * cx + cx - 1
+  const unsigned b0 = M::div_cx((unsigned)bx + 1u), nbx = M::div_cx((unsigned)ex) - b0 + 1u; // the bricks along x that hold voxels bx ... ex - 1
+  const unsigned ya = (unsigned)by & ~(HY - 1u), za = (unsigned)bz & ~(HZ - 1u);
   float lo = INFINITY, hi = -INFINITY; // range1f() is empty
-  for (int i = lane; i < dx * dy * dz; i += 64) {
-    const int x = bx + i % dx, y = by + (i / dx) % dy, z = bz + i / (dx * dy);
-    const unsigned long long off = (unsigned long long)(M::X((unsigned)x + 1u) + M::Y((unsigned)y, macro_y)) + M::Zlo((unsigned)z) + (unsigned long long)((unsigned)z >> 5) * macro_z; // stored position = voxel + 1
-    float f = (float)base[off];
-    if (VT == VOX_U8) f = f / 255.f;                            // what the normalized texture read returns (array.cpp:304-306)
-    if (VT == VOX_I8) { f = f / 127.f; f = f < -1.f ? -1.f : f; }
-    lo = fminf(lo, f);
-    hi = fmaxf(hi, f);
+  for (unsigned t = (unsigned)lane; t < AY * AZ * HY * HZ; t += 64u) {
+    const unsigned q = t / (HY * HZ);
+    const unsigned y = ya + (q % AY) * HY + (t & (HY - 1u)), z = za + (q / AY) * HZ + ((t / HY) & (HZ - 1u));
+    if ((int)y < by || (int)y >= ey || (int)z < bz || (int)z >= ez) continue;
+    const unsigned long long row = (unsigned long long)M::Y(y, macro_y) + M::Zlo(z) + (unsigned long long)(z >> 5) * macro_z;
+    for (unsigned qx = 0; qx < nbx; ++qx) {
+      const unsigned br = b0 + qx;
+      const unsigned m = M::div_mbx(br), bm = br - m * V::mbx;
+      const RowOut<T, SX> w = *reinterpret_cast<const RowOut<T, SX>*>(base + (row + (bm * M::BV + m * M::MV)));
+      const int v0 = (int)(br * V::cx) - 1; // the voxel of the row's first element
+#pragma unroll
+      for (unsigned k = 0; k < SX; ++k) {
+        float f = (float)w.v[k];
+        if (VT == VOX_U8) f = f / 255.f;                            // what the normalized texture read returns (array.cpp:304-306)
+        if (VT == VOX_I8) { f = f / 127.f; f = f < -1.f ? -1.f : f; }
+        const bool in = v0 + (int)k >= bx && v0 + (int)k < ex;
+        lo = in ? fminf(lo, f) : lo;
+        hi = in ? fmaxf(hi, f) : hi;
+      }
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -785,11 +880,15 @@ hipError_t launch_macrocell_majorants(const float* minmax, unsigned int count, c
 
 // the volume's data range: min / max over all macrocell ranges (every voxel lies in at least one cell); fminf / fmaxf drop
 // NaN operands like the reference's std::min / std::max chain does (array.cpp:44-62)
-__global__ __launch_bounds__(1024) void minmax_reduce_kernel(const float2* __restrict__ ranges, unsigned long long cells, float* __restrict__ out)
+// two launches: kMinmaxBlocks workgroups reduce a slice each into out[2 + 2 b ...], one workgroup reduces those (one workgroup over all cells
+// took 0.94 ms for C4's 2 M cells)
+constexpr int kMinmaxBlocks = 256;
+__global__ __launch_bounds__(256) void minmax_reduce_kernel(const float2* __restrict__ ranges, unsigned long long cells, float* __restrict__ out, int final_pass)
 {
-  __shared__ float slo[16], shi[16];
+  __shared__ float slo[4], shi[4];
   float lo = FLT_MAX, hi = -FLT_MAX; // numeric_limits<float>::max() / lowest()
-  for (unsigned long long i = threadIdx.x; i < cells; i += 1024ull) {
+  const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < cells; i += stride) {
     const float2 r = ranges[i];
     lo = fminf(lo, r.x);
     hi = fmaxf(hi, r.y);
@@ -802,14 +901,17 @@ __global__ __launch_bounds__(1024) void minmax_reduce_kernel(const float2* __res
   if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 16; ++w) { lo = fminf(lo, slo[w]); hi = fmaxf(hi, shi[w]); }
-    out[0] = lo;
-    out[1] = hi;
+    for (int w = 1; w < 4; ++w) { lo = fminf(lo, slo[w]); hi = fmaxf(hi, shi[w]); }
+    float* o = final_pass ? out : out + 2 + 2 * blockIdx.x;
+    o[0] = lo;
+    o[1] = hi;
   }
 }
+size_t minmax_reduce_floats() { return 2 + 2 * (size_t)kMinmaxBlocks; }
 hipError_t launch_minmax_reduce(const float* minmax, unsigned long long cells, float* out, hipStream_t stream)
 {
-  hipLaunchKernelGGL(minmax_reduce_kernel, dim3(1), dim3(1024), 0, stream, (const float2*)minmax, cells, out);
+  hipLaunchKernelGGL(minmax_reduce_kernel, dim3(kMinmaxBlocks), dim3(256), 0, stream, (const float2*)minmax, cells, out, 0);
+  hipLaunchKernelGGL(minmax_reduce_kernel, dim3(1), dim3(256), 0, stream, (const float2*)(out + 2), (unsigned long long)kMinmaxBlocks, out, 1);
   return hipGetLastError();
 }
 

@@ -452,3 +452,39 @@ def test_setters_from_another_thread_never_tear_a_frame(ovr, oracle, hip_rendere
     finally:
         if devices:
             ren.close()
+
+
+@pytest.mark.parametrize("dtype,dims", [(np.float32, (37, 41, 29)), (np.uint16, (43, 35, 31)), (np.uint8, (45, 33, 37)), (np.int16, (33, 31, 35)),
+                                        (np.int8, (31, 47, 33)), (np.float64, (31, 33, 30)), (np.float32, (95, 7, 3)), (np.uint16, (5, 70, 66))])
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_the_upload_writes_every_element_of_a_layout(ovr, oracle, hip_renderer_factory, monkeypatch, dtype, dims, where):
+    """round 4: the relayout kernels take the layout's rows in storage order (whole 128-byte lines per workgroup) and write padding rows and
+    layers as zeros themselves - the allocation is no longer memset.  With the allocation poisoned first (OVR_HIP_POISON_ALLOC: 0xff bytes = NaN
+    for float voxels, the extreme of the integer types) every layout - the general one from the caller's array in host or device memory,
+    the thin and quad replicas from the general layout - still gives the oracle's frame, and the macrocell ranges are the oracle's."""
+    import torch
+    monkeypatch.setenv("OVR_HIP_POISON_ALLOC", "1")
+    case = make_case(ovr, oracle, n=max(dims), dtype=dtype, tf="dense", cam="oblique", size=(56, 40), shading=2, dims=dims, tf_n=256)
+    sc = oracle_scene(oracle, case)
+    ref, _, cnt = sc.render()
+    assert np.isfinite(ref).all()
+    if where == "device":
+        if dtype == np.uint16 and not hasattr(torch, "uint16"):
+            pytest.skip("no torch.uint16")
+        case = dict(case, vol=torch.from_numpy(case["vol"]).to("cuda:0"))
+    ren = hip_renderer_factory()
+    ren.set_volume_layouts(2)
+    hip_setup(ovr, ren, case)
+    for choice in (0, 1, 2, 3):
+        ren.set_layout_choice(choice)
+        ren.commit()
+        ren.render()
+        st = ren.stats()
+        rgba, grad = hip_frame(ovr, ren)
+        assert np.isfinite(rgba).all() and np.isfinite(grad).all(), (choice, st.layout)
+        compare(oracle, rgba, ref, name=f"{np.dtype(dtype).name} {dims} {where} layout {choice} -> {st.layout}")
+        assert st.samples == cnt.samples and st.shaded_samples == cnt.shaded_samples
+    minmax, _ = ren.macrocells()
+    ref_minmax = sc.macrocells()[0]
+    assert np.array_equal(np.asarray(minmax), np.asarray(ref_minmax))
+    ren.close()
