@@ -255,6 +255,8 @@ def run_extra_leg(argv, timeout_s):
                         "traffic": r.get("traffic"), "hbm_algorithmic_frac": r.get("hbm_algorithmic_frac"),
                         "kernels": {k: {f: v.get(f) for f in ("ms", "bound", "frac", "hbm_algorithmic_frac", "traffic_ratio", "utilisation")} for k, v in r.get("kernels", {}).items()},
                         "volume_upload_ms": r.get("volume_upload_ms"), "volume_resident_bytes": r.get("volume_resident_bytes")}}
+    if "without_phase_events" in doc:
+        out["ms_per_step_without_phase_events"] = doc["without_phase_events"]["ms_per_step"]
     if "device_group" in doc:
         out["device_group"] = doc["device_group"]
     return out
@@ -556,6 +558,14 @@ def worker(args, world):
     main_leg = timed_leg(args.steps, args.warmup)
     main_extra_warmup = timed_leg.extra_warmup
     dt, tot, kernel_ms, phase_ms, last_stats = main_leg["dt"], main_leg["tot"], main_leg["kernel_ms"], main_leg["phase_ms"], main_leg["last"]
+    # The same steps again without the two events between the frame's kernels (ovr_hip_set_phase_timing(0), ABI v9: what the plugin runs).  The
+    # headline's timed region keeps them - its per-kernel durations ARE those events - and pays ~16 us per frame for it; this leg is never `value`.
+    ren.set_phase_timing(False)
+    plain_leg = timed_leg(args.steps, 2)
+    ren.set_phase_timing(True)
+    without_phase_events = {"ms_per_step": plain_leg["dt"] / args.steps * 1e3, "fps": args.steps / plain_leg["dt"],
+                            "msamples_per_s": plain_leg["tot"]["samples"] / plain_leg["dt"] / 1e6, "steps": args.steps,
+                            "note": "ovr_hip_set_phase_timing(0): no hipEventRecord between the frame's kernels - the plugin's setting; same frames"}
     if multi and world == 1:
         # forced single-rank gather: the gathered frame must be the renderer's own frame
         fb = ovr.FrameBufferData()
@@ -758,6 +768,7 @@ def worker(args, world):
             "warmup": args.warmup,
             "extra_warmup": main_extra_warmup,
             "ms_per_step": dt / steps * 1e3,
+            "without_phase_events": without_phase_events,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OVR_HIP_ABI_VERSION 8
+#define OVR_HIP_ABI_VERSION 9
 
 /* error codes */
 #define OVR_HIP_OK 0
@@ -200,6 +200,11 @@ int ovr_hip_set_pixel_jitter(ovr_hip_renderer* r, int32_t mode);
  * stages, once per round of 16 steps, every brick its 8x8-pixel workgroup can touch into LDS with whole-line loads and taps read
  * LDS.  Bit-identical frames.  0 = off (default: 2.3 - 3 x slower than the L1 path on its best case, profiles/r02_notes.md), 1 = on. */
 int ovr_hip_set_lds_staging(ovr_hip_renderer* r, int32_t mode);
+/* extension (ABI v9): per-phase device times.  1 (default): two more events are recorded between the frame's kernels and
+ * ovr_hip_stats::march_ms / shade_ms / composite_ms say what each phase took; 0: those three read 0 and a frame is ~16 us shorter (hipEventRecord
+ * costs on both sides of the queue: 8 % of a 0.2 ms frame, 4 % of one GPU's share of an 8-GPU frame).  kernel_ms (first to last event) is measured
+ * either way.  Takes effect with the next frame launched; frames are identical.  The plugin switches it off (OVR_HIP_PHASE_TIMING=1 keeps it). */
+int ovr_hip_set_phase_timing(ovr_hip_renderer* r, int32_t on);
 /* downloads the macrocell grids (for known-answer tests): dims = cells per axis; minmax = 2 floats per cell, majorant = 1 */
 int ovr_hip_get_macrocells(ovr_hip_renderer* r, int32_t dims[3], float* minmax_host, float* majorant_host, size_t capacity_cells);
 /* extension (multi-GPU): this renderer draws only the image tiles owned by `rank` of `world`;

@@ -21,7 +21,7 @@ PIPELINE_AUTO, PIPELINE_IN_PLACE, PIPELINE_POOLED = 0, 1, 2
 JITTER_TEA, JITTER_BLUE_NOISE = 0, 1
 LAYOUT_AUTO, LAYOUT_GENERAL, LAYOUT_THIN, LAYOUT_THIN_T, LAYOUT_QUAD = -1, 0, 1, 2, 3
 # the ABI these ctypes structures describe: load() refuses a library of another version (ovr_hip_get_stats would write past them)
-EXPECTED_ABI = 8
+EXPECTED_ABI = 9
 
 
 class Stats(C.Structure):
@@ -110,6 +110,7 @@ SYMBOLS = {
     "ovr_hip_tea_floats": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int64]),
     "ovr_hip_set_pixel_jitter": (C.c_int, [_H, C.c_int32]),
     "ovr_hip_set_lds_staging": (C.c_int, [_H, C.c_int32]),
+    "ovr_hip_set_phase_timing": (C.c_int, [_H, C.c_int32]),
     "ovr_hip_query_addressing_mode": (C.c_int, [C.POINTER(C.c_int32), C.c_int, C.c_int32, C.c_int32, C.c_int32]),
     "ovr_hip_set_volume_layouts": (C.c_int, [_H, C.c_int32]),
     "ovr_hip_set_layout_choice": (C.c_int, [_H, C.c_int32]),

@@ -96,6 +96,9 @@ struct Size2 { int w = 0, h = 0; };
 
 } // namespace
 
+// the frame words on the device (ovr_hip_renderer::d_counters): 8 counters, the pool's control words from byte 128, the reduction's ticket word behind them
+constexpr size_t kFrameWordsBytes = 128 + (size_t)ovrhip::kPoolCtrlWords * sizeof(unsigned int) + 128;
+
 struct ovr_hip_renderer {
   int device = 0;
   std::mutex mtx; // protects the queued values (setters may come from any thread)
@@ -223,7 +226,10 @@ struct ovr_hip_renderer {
   unsigned long long sparse_prev_pixels = 0; // pixels of the previous sparse frame (RayMarchParams::sparse_hint_pixels)
 
   // counters
-  unsigned long long* d_counters = nullptr;
+  unsigned long long* d_counters = nullptr;  // start of the frame words: [0, 64) the counters, [128, 128 + ctrl) the pool's control words, then the reduction's ticket
+  bool phase_timing = true;                  // ovr_hip_set_phase_timing
+  bool frame_phase_timed = true;             // ... as the frame in flight was launched
+  bool frame_words_dirty = true;             // the next launch may not rely on the last frame's reduction having zeroed them (RayMarchParams::zero_first)
   unsigned int* d_block_counters = nullptr; // per-workgroup partial counters
   unsigned long long* d_trace = nullptr;    // OVR_HIP_TRACE=1 diagnostic buffer
   size_t trace_words = 0;
@@ -977,9 +983,8 @@ int enqueue_frame(ovr_hip_renderer* r)
     if (const char* pc = getenv("OVR_HIP_POOL_CHUNKS")) guess = std::max<size_t>(8, (size_t)atoll(pc)); // diagnostic: force the overflow path
     if (int e = ensure_pool(r, std::max<size_t>(guess, r->pool.capacity))) return e;
     if (!r->pool.ctrl) {
-      HIP_TRY(hipMalloc((void**)&r->pool.ctrl, (size_t)kPoolCtrlWords * sizeof(unsigned int)));
+      r->pool.ctrl = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(r->d_counters) + 128); // every sub-pool counter on a 128-byte line of its own
       HIP_TRY(hipMalloc((void**)&r->pool.shade_counters, pool_shade_blocks() * 2 * sizeof(unsigned int)));
-      HIP_TRY(hipHostMalloc((void**)&r->h_ctrl, (size_t)kPoolCtrlWords * sizeof(unsigned int), hipHostMallocDefault));
     }
     P.pool = r->pool;
     if (P.spp > 1 && !r->d_spp_rgba) {
@@ -997,9 +1002,19 @@ int enqueue_frame(ovr_hip_renderer* r)
 int launch_frame(ovr_hip_renderer* r)
 {
   hipStream_t st = r->stream();
-  HIP_TRY(launch_raymarch(r->P, st, r->ev));
-  HIP_TRY(hipMemcpyAsync(r->h_counters, r->d_counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-  if (r->P.pool.reqs) HIP_TRY(hipMemcpyAsync(r->h_ctrl, r->pool.ctrl, (size_t)kPoolCtrlWords * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+  // the frame's last reduction kernel writes the counters and the pool's control words into h_counters / h_ctrl itself and zeroes them on the
+  // device for the next frame (RayMarchParams::publish): a frame is its kernels, nothing in front of them and nothing behind
+  r->P.publish = r->h_counters;
+  r->P.reduce_done = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(r->d_counters) + 128 + (size_t)kPoolCtrlWords * sizeof(unsigned int));
+  r->P.zero_first = r->frame_words_dirty ? 1 : 0;
+  if (r->frame_words_dirty) HIP_TRY(hipMemsetAsync(r->P.reduce_done, 0, sizeof(unsigned int), st));
+  r->frame_words_dirty = true; // until the launch below has been enqueued completely
+  // the events between the frame's kernels (per-phase times) cost ~16 us a frame - hipEventRecord is not free on either side of the queue; the
+  // first and the last one (kernel_ms: what the layout / pipeline tuner compares) stay
+  hipEvent_t evs[4] = { r->ev[0], r->phase_timing ? r->ev[1] : nullptr, r->phase_timing ? r->ev[2] : nullptr, r->ev[3] };
+  r->frame_phase_timed = r->phase_timing;
+  HIP_TRY(launch_raymarch(r->P, st, evs));
+  r->frame_words_dirty = false;
   r->async_pending = true;
   return 0;
 }
@@ -1037,9 +1052,11 @@ int finish_frame_one(ovr_hip_renderer* r)
   }
   float ms = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, r->ev[0], r->ev[3]));
-  HIP_TRY(hipEventElapsedTime(&m1, r->ev[0], r->ev[1]));
-  HIP_TRY(hipEventElapsedTime(&m2, r->ev[1], r->ev[2]));
-  HIP_TRY(hipEventElapsedTime(&m3, r->ev[2], r->ev[3]));
+  if (r->frame_phase_timed) {
+    HIP_TRY(hipEventElapsedTime(&m1, r->ev[0], r->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&m2, r->ev[1], r->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&m3, r->ev[2], r->ev[3]));
+  }
   r->stats.kernel_ms = ms;
   r->stats.march_ms = m1;
   r->stats.shade_ms = m2;
@@ -1408,14 +1425,17 @@ int ovr_hip_create(ovr_hip_renderer** out, int device_id)
       HIP_TRY(hipStreamCreateWithPriority(&r->build_stream, hipStreamNonBlocking, hi));
     }
     for (int k = 0; k < kLayouts; ++k) HIP_TRY(hipEventCreateWithFlags(&r->build_ev[k], hipEventDisableTiming));
-    HIP_TRY(hipMalloc((void**)&r->d_counters, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&r->d_counters, kFrameWordsBytes));
+    HIP_TRY(hipMemset(r->d_counters, 0, kFrameWordsBytes));
     HIP_TRY(hipMalloc((void**)&r->d_sparse_count, sizeof(unsigned long long)));
     HIP_TRY(hipMalloc((void**)&r->d_data_range, minmax_reduce_floats() * sizeof(float)));
-    HIP_TRY(hipHostMalloc((void**)&r->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+    // pinned, read by the host after a frame: 8 counters, then the pool's control words (written by the frame's last reduction kernel)
+    HIP_TRY(hipHostMalloc((void**)&r->h_counters, 8 * sizeof(unsigned long long) + (size_t)kPoolCtrlWords * sizeof(unsigned int), hipHostMallocDefault));
+    r->h_ctrl = reinterpret_cast<unsigned int*>(r->h_counters + 8);
     return 0;
   };
   if (int e = acquire()) { ovr_hip_destroy(r); return e; } // nothing half-built leaks
-  std::memset(r->h_counters, 0, 8 * sizeof(unsigned long long));
+  std::memset(r->h_counters, 0, 8 * sizeof(unsigned long long) + (size_t)kPoolCtrlWords * sizeof(unsigned int));
   // defaults of the reference's parameter block (params.h:55-99, renderer.h:255-285)
   r->spp.current = r->spp.queued = 1;
   r->sparse.current = r->sparse.queued = 0;
@@ -1596,9 +1616,8 @@ void ovr_hip_destroy(ovr_hip_renderer* r)
   if (r->pool.reqs) (void)hipFree(r->pool.reqs);
   if (r->pool.chunk_next) (void)hipFree(r->pool.chunk_next);
   if (r->pool.chunk_n) (void)hipFree(r->pool.chunk_n);
-  if (r->pool.ctrl) (void)hipFree(r->pool.ctrl);
   if (r->pool.shade_counters) (void)hipFree(r->pool.shade_counters);
-  if (r->h_ctrl) (void)hipHostFree(r->h_ctrl);
+
   if (r->d_block_counters) (void)hipFree(r->d_block_counters);
   if (r->d_sched_info) (void)hipFree(r->d_sched_info);
   if (r->d_trace) (void)hipFree(r->d_trace);
@@ -1788,6 +1807,15 @@ int ovr_hip_query_addressing_mode(const int32_t dims[3], int value_type, int32_t
   volume_layout(rt, dims[0], dims[1], dims[2], vd);
   if (!layout_offsets_fit(vd)) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_query_addressing_mode: one z layer of this layout exceeds 2^32 elements - it is not built");
   return volume_addressing_mode(vd, n_colors, n_alphas);
+}
+
+int ovr_hip_set_phase_timing(ovr_hip_renderer* r, int32_t on)
+{
+  if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
+  GroupLock gl(r);
+  r->phase_timing = on != 0; // read when the next frame is launched; a frame in flight keeps what it was launched with
+  GROUP_FORWARD(r, ovr_hip_set_phase_timing(m, on));
+  return 0;
 }
 
 int ovr_hip_set_grid_convention(ovr_hip_renderer* r, int c)
@@ -2021,6 +2049,19 @@ int ovr_hip_render(ovr_hip_renderer* r)
   if (slow_trace && ms > 20.0)
     fprintf(stderr, "[hip] slow frame %d: enqueue %.2f ms, wait + finish %.2f ms (kernels %.2f ms)\n", r->frame_index, std::chrono::duration<double, std::milli>(tm - t0).count(),
             std::chrono::duration<double, std::milli>(t1 - tm).count(), r->stats.kernel_ms);
+  // diagnostic: OVR_HIP_FRAME_TIMING=n prints, every n frames, the mean host time of a blocking render() split into enqueue / wait, next to the
+  // frame's device time between its first and last event - the difference is launch latency, the counter read-back and the wake-up
+  static const int timing_every = getenv("OVR_HIP_FRAME_TIMING") ? atoi(getenv("OVR_HIP_FRAME_TIMING")) : 0;
+  if (timing_every > 0) {
+    static thread_local double acc[3] = { 0, 0, 0 };
+    static thread_local int n_acc = 0;
+    acc[0] += std::chrono::duration<double, std::milli>(tm - t0).count(); acc[1] += std::chrono::duration<double, std::milli>(t1 - tm).count(); acc[2] += r->stats.kernel_ms;
+    if (++n_acc == timing_every) {
+      fprintf(stderr, "[hip] %d frames: render() %.4f ms = enqueue %.4f + wait %.4f ; device first-to-last event %.4f ms ; outside the events %.4f ms\n", n_acc,
+              (acc[0] + acc[1]) / n_acc, acc[0] / n_acc, acc[1] / n_acc, acc[2] / n_acc, (acc[0] + acc[1] - acc[2]) / n_acc);
+      acc[0] = acc[1] = acc[2] = 0; n_acc = 0;
+    }
+  }
   r->stats.render_ms = ms;
   r->render_time_ms += ms;
   return 0;

@@ -1921,7 +1921,7 @@ constexpr int kReduceBlocks = 64;
 // the two kernels of the pooled pipeline that do not depend on the voxel type live in ovr_hip_kernels.hip
 hipError_t launch_composite(const RayMarchParams& q, dim3 grid, hipStream_t stream);
 hipError_t launch_reduce_counters(const unsigned int* partials, int n_blocks, const unsigned int* shade_partials, int n_shade_blocks,
-                                  unsigned long long* counters, unsigned int* pool_ctrl, hipStream_t stream);
+                                  unsigned long long* counters, unsigned int* pool_ctrl, unsigned long long* publish, unsigned int* done, hipStream_t stream);
 
 inline dim3 raymarch_grid(const RayMarchParams& p)
 {
@@ -1993,18 +1993,23 @@ inline hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
       if (grid.x > 0) hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (ev) { (void)hipEventRecord(ev[1], stream); (void)hipEventRecord(ev[2], stream); }
+    if (ev && ev[1] && ev[2]) { (void)hipEventRecord(ev[1], stream); (void)hipEventRecord(ev[2], stream); }
     if (p.block_counters && p.counters) {
-      if ((e = hipMemsetAsync(p.counters, 0, 8 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
-      if ((e = launch_reduce_counters(p.block_counters, (int)raymarch_grid_blocks(p), nullptr, 0, p.counters, nullptr, stream)) != hipSuccess) return e;
+      if (!p.publish || p.zero_first)
+        if ((e = hipMemsetAsync(p.counters, 0, 8 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+      if ((e = launch_reduce_counters(p.block_counters, (int)raymarch_grid_blocks(p), nullptr, 0, p.counters, nullptr, p.publish, p.reduce_done, stream)) != hipSuccess) return e;
     }
     return hipGetLastError();
   }
   if constexpr (SHADE != 0) { // (no pooled kernels are built for SHADE == 0: the in-place march above is its only pipeline)
     // ---- pooled pipeline: march -> shade -> composite, once per sample-per-pixel generation
-    if ((e = hipMemsetAsync(p.pool.ctrl, 0, (size_t)kPoolCtrlWords * sizeof(unsigned int), stream)) != hipSuccess) return e;
-    if (p.block_counters && p.counters)
-      if ((e = hipMemsetAsync(p.counters, 0, 8 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+    // (the last frame's final reduction left the control words and the counters zeroed - RayMarchParams::publish)
+    const bool self_cleaning = p.publish && p.block_counters && p.counters && !p.zero_first;
+    if (!self_cleaning) {
+      if ((e = hipMemsetAsync(p.pool.ctrl, 0, (size_t)kPoolCtrlWords * sizeof(unsigned int), stream)) != hipSuccess) return e;
+      if (p.block_counters && p.counters)
+        if ((e = hipMemsetAsync(p.counters, 0, 8 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+    }
     RayMarchParams q = p;
     for (int g = 0; g < p.spp; ++g) {
       q.spp_index = g;
@@ -2028,7 +2033,7 @@ inline hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
       }
-      if (ev && g == p.spp - 1) (void)hipEventRecord(ev[1], stream);
+      if (ev && ev[1] && g == p.spp - 1) (void)hipEventRecord(ev[1], stream);
       {
         const size_t lds = std::max<size_t>(tf_lds + table_lds_bytes(p, AM), 64);
         auto kern = shade_pool_kernel<VT, SHADE, AM, SKIP>;
@@ -2036,11 +2041,11 @@ inline hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
         hipLaunchKernelGGL(kern, dim3((unsigned)shade_grid_blocks(p)), block, lds, stream, q);
         if ((e = hipGetLastError()) != hipSuccess) return e;
       }
-      if (ev && g == p.spp - 1) (void)hipEventRecord(ev[2], stream);
+      if (ev && ev[2] && g == p.spp - 1) (void)hipEventRecord(ev[2], stream);
       if (grid.x > 0 && (e = launch_composite(q, grid, stream)) != hipSuccess) return e;
       if (p.block_counters && p.counters)
         if ((e = launch_reduce_counters(p.block_counters, (int)raymarch_grid_blocks(p), (const unsigned int*)p.pool.shade_counters, shade_grid_blocks(p), p.counters,
-                                        p.pool.ctrl, stream)) != hipSuccess) return e;
+                                        p.pool.ctrl, g == p.spp - 1 ? p.publish : nullptr, p.reduce_done, stream)) != hipSuccess) return e; // the frame's last generation publishes
     }
     return hipGetLastError();
   }

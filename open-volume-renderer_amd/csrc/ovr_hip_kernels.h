@@ -147,6 +147,13 @@ struct RayMarchParams {
   unsigned int lds_brick_offset;
   // counters: [0] rays [1] samples [2] shaded samples [3] shadow samples [4] active pixels [5] skipped samples [6] skipped shadow samples
   unsigned long long* counters;
+  // (round 4) the frame's last reduction publishes counters[0..7] and the pool's control words to `publish` (pinned host memory: 8 x u64, then
+  // kPoolCtrlWords x u32) and zeroes both on the device for the next frame - no memset in front of a frame, no copy behind it.  reduce_done: the
+  // reduction's ticket word (zero between launches).  zero_first: this launch may not rely on the last one having cleaned up (first frame, new pool,
+  // a failed launch): memset first, as every frame did until round 4.  publish == null: the old protocol (memsets, the caller copies)
+  unsigned long long* publish;
+  unsigned int* reduce_done;
+  int zero_first;
   const float* majorant;        // per-macrocell max TF opacity: empty-space skipping (null = off)
   const unsigned char* occupancy; // per 4^3 macrocells: majorant > 0 in one of them or next to them (set with majorant)
   const unsigned char* occupancy_fine; // the same per macrocell (primary rays refine their skip interval with it)

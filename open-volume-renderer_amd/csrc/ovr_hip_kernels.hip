@@ -100,7 +100,8 @@ __global__ __launch_bounds__(kBlock) void composite_kernel(const RayMarchParams 
 // sums the per-workgroup partials into counters[0..4]: each workgroup reduces a slice and adds its 5 sums with one
 // atomic each (integer sums: the result does not depend on the order); counters are zeroed by a memset node before
 __global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned int* __restrict__ partials, int n_blocks, const unsigned int* __restrict__ shade_partials,
-                                                             int n_shade_blocks, unsigned long long* counters, unsigned int* pool_ctrl)
+                                                             int n_shade_blocks, unsigned long long* counters, unsigned int* pool_ctrl,
+                                                             unsigned long long* publish, unsigned int* done)
 {
   if (pool_ctrl && blockIdx.x == 0 && threadIdx.x < 64) { // most chunks any sub-pool was asked for in any generation (kPoolSubs == 64: one wave)
     unsigned int v = threadIdx.x < (unsigned int)kPoolSubs ? pool_ctrl[32u * (threadIdx.x + 1u)] : 0u;
@@ -131,6 +132,27 @@ __global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned int
   }
   __syncthreads();
   if (threadIdx.x < kNC) atomicAdd(&counters[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (!publish) return; // the old protocol, or an earlier generation of a frame with several samples per pixel: the sums go on accumulating
+  // The workgroup that finishes last hands the frame's totals and the pool's control words to the host (pinned memory: visible when the
+  // stream has been synchronised) and leaves both zeroed for the next frame: no memset in front of a frame, no copy behind it.
+  __shared__ unsigned int ticket;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) ticket = atomicAdd(done, 1u);
+  __syncthreads();
+  if (ticket != gridDim.x - 1u) return;
+  __threadfence();
+  if (threadIdx.x < 8) {
+    publish[threadIdx.x] = threadIdx.x < kNC ? __hip_atomic_load(&counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    counters[threadIdx.x] = 0ull;
+  }
+  unsigned int* pub_ctrl = reinterpret_cast<unsigned int*>(publish + 8);
+  if (pool_ctrl)
+    for (int i = threadIdx.x; i < kPoolCtrlWords; i += 256) {
+      pub_ctrl[i] = __hip_atomic_load(&pool_ctrl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pool_ctrl[i] = 0u;
+    }
+  if (threadIdx.x == 0) *done = 0u;
 }
 // ------------------------------------------------------------------------------------------------------------------
 // launch order of the march workgroups: longest rays first
@@ -365,9 +387,10 @@ hipError_t launch_composite(const RayMarchParams& q, dim3 grid, hipStream_t stre
 }
 
 hipError_t launch_reduce_counters(const unsigned int* partials, int n_blocks, const unsigned int* shade_partials, int n_shade_blocks,
-                                  unsigned long long* counters, unsigned int* pool_ctrl, hipStream_t stream)
+                                  unsigned long long* counters, unsigned int* pool_ctrl, unsigned long long* publish, unsigned int* done, hipStream_t stream)
 {
-  hipLaunchKernelGGL(reduce_counters_kernel, dim3(kReduceBlocks), dim3(256), 0, stream, partials, n_blocks, shade_partials, n_shade_blocks, counters, pool_ctrl);
+  hipLaunchKernelGGL(reduce_counters_kernel, dim3(kReduceBlocks), dim3(256), 0, stream, partials, n_blocks, shade_partials, n_shade_blocks, counters, pool_ctrl,
+                     done ? publish : nullptr, done);
   return hipGetLastError();
 }
 
@@ -388,7 +411,7 @@ size_t pool_shade_blocks() { return kShadeBlocks; }
 
 hipError_t launch_raymarch(const RayMarchParams& p, hipStream_t stream, const hipEvent_t* ev)
 {
-  // ev (optional): ev[0] before the first kernel, ev[1] after the march, ev[2] after the shade kernel, ev[3] at the end
+  // ev (optional): ev[0] before the first kernel, ev[1] after the march, ev[2] after the shade kernel (both may be null: no per-phase times), ev[3] at the end
   if (ev) (void)hipEventRecord(ev[0], stream);
   hipError_t e;
   switch (p.vol.type) {

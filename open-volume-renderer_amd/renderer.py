@@ -218,6 +218,11 @@ class DeviceHIP:
         """LDS-staged bricks for the unshaded march of float volumes (include/ovr_hip.h); off by default"""
         L.check(self._lib.ovr_hip_set_lds_staging(self._h, int(bool(on))))
 
+    def set_phase_timing(self, on):
+        """per-phase device times in stats() (march_ms / shade_ms / composite_ms): on by default; off saves the two events between the
+        frame's kernels (~16 us per frame).  kernel_ms is measured either way; frames are identical."""
+        L.check(self._lib.ovr_hip_set_phase_timing(self._h, int(bool(on))))
+
     def set_volume_layouts(self, mode):
         """which layouts of the volume the next init / volume upload keeps in HBM: 0 general only, 1 (default) thin replicas
         when they fit comfortably, 2 always (include/ovr_hip.h)"""

@@ -103,6 +103,9 @@ public:
     // device has it on (OVR_HIP_SKIP_EMPTY=0 switches it off, e.g. to count every sample like the reference)
     const char* skip = std::getenv("OVR_HIP_SKIP_EMPTY");
     check(ovr_hip_set_empty_space_skipping(h, (skip && skip[0] == '0') ? 0 : 1));
+    // nothing behind this interface reads per-phase device times: no events between the frame's kernels (OVR_HIP_PHASE_TIMING=1 keeps them)
+    const char* phases = std::getenv("OVR_HIP_PHASE_TIMING");
+    check(ovr_hip_set_phase_timing(h, (phases && phases[0] == '1') ? 1 : 0));
     commit();
   }
 

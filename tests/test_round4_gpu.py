@@ -488,3 +488,65 @@ def test_the_upload_writes_every_element_of_a_layout(ovr, oracle, hip_renderer_f
     ref_minmax = sc.macrocells()[0]
     assert np.array_equal(np.asarray(minmax), np.asarray(ref_minmax))
     ren.close()
+
+
+def test_phase_timing_can_be_switched_off(ovr, oracle, hip_renderer_factory):
+    """ABI v9: without per-phase times a frame is its kernels and two events - the same frame bit for bit, the same counters, kernel_ms still
+    measured (the tuner compares it), march_ms / shade_ms / composite_ms zero; switching back brings them back.  (What it saves is measured by
+    bench.py's `without_phase_events` leg.)"""
+    case = make_case(ovr, oracle, n=40, dtype=np.float32, tf="sparse", cam="oblique", size=(96, 80), shading=2, tf_n=256)
+    ren = hip_setup(ovr, hip_renderer_factory(), case, accumulate=True)
+    ren2 = hip_setup(ovr, hip_renderer_factory(), case, accumulate=True)
+    ren2.set_phase_timing(False)
+    for pipeline in (2, 1):
+        for r in (ren, ren2):
+            r.set_shading_pipeline(pipeline)
+            r.commit()
+        for frame in range(3):
+            ren.render(); ren2.render()
+            a, b = ren.stats(), ren2.stats()
+            assert (a.samples, a.shaded_samples, a.shadow_samples, a.rays, a.pool_chunks) == (b.samples, b.shaded_samples, b.shadow_samples, b.rays, b.pool_chunks)
+            assert a.kernel_ms > 0 and b.kernel_ms > 0 and a.march_ms > 0
+            assert b.march_ms == 0 and b.shade_ms == 0 and b.composite_ms == 0
+            fa, fb = hip_frame(ovr, ren), hip_frame(ovr, ren2)
+            assert np.array_equal(fa[0], fb[0]) and np.array_equal(fa[1], fb[1])
+    ren2.set_phase_timing(True)
+    ren2.render()
+    assert ren2.stats().march_ms > 0
+    ren.close(); ren2.close()
+
+
+def test_a_frame_leaves_its_counters_clean_for_the_next_one(ovr, oracle, hip_renderer_factory, monkeypatch):
+    """round 4: the frame's last reduction kernel hands the counters and the request pool's control words to the host and zeroes them on the
+    device (no memset in front of a frame, no copy behind it).  Counters of consecutive frames must not leak into each other across everything
+    that changes the launch sequence: pipelines, several samples per pixel (one reduction per generation, only the last one publishes), a request
+    pool forced to overflow (the frame is rendered again).  Two renderers in lockstep - one with a pool that overflows whenever it is (re)sized
+    from the guess, the other with the opposite pipeline - count the same at every frame (the jitter of a frame depends on its index only), and
+    what the oracle counts where there is one sample per pixel."""
+    case = make_case(ovr, oracle, n=36, dtype=np.uint8, tf="dense", cam="oblique", size=(72, 64), shading=2, tf_n=256)
+    _, _, cnt = oracle_scene(oracle, case).render()
+    a = hip_setup(ovr, hip_renderer_factory(), case)
+    b = hip_setup(ovr, hip_renderer_factory(), case)
+    want = (cnt.samples, cnt.shaded_samples, cnt.shadow_samples)
+    overflowed = 0
+    for step, (pipeline, spp) in enumerate([(2, 1), (2, 1), (1, 1), (2, 3), (2, 3), (1, 3), (2, 1), (0, 1), (2, 2), (1, 2)]):
+        a.set_shading_pipeline(pipeline)
+        b.set_shading_pipeline({0: 0, 1: 2, 2: 1}[pipeline])
+        for r in (a, b):
+            r.set_sample_per_pixel(spp)
+            r.commit()
+        for frame in range(3):
+            monkeypatch.setenv("OVR_HIP_POOL_CHUNKS", "16")   # a's pooled frames start from a pool of 16 chunks: overflow, grown, rendered again
+            a.render()
+            monkeypatch.delenv("OVR_HIP_POOL_CHUNKS")
+            b.render()
+            sa, sb = a.stats(), b.stats()
+            ga, gb = (sa.rays, sa.samples, sa.shaded_samples, sa.shadow_samples, sa.active_pixels), (sb.rays, sb.samples, sb.shaded_samples, sb.shadow_samples, sb.active_pixels)
+            assert sa.frame_index == sb.frame_index
+            assert ga == gb, (step, pipeline, spp, frame)
+            assert sa.rays == spp * 72 * 64
+            if spp == 1:
+                assert ga[1:4] == want, (step, pipeline, spp, frame)
+            overflowed += int(sa.pipeline == 2)
+    assert overflowed > 0
+    a.close(); b.close()
