@@ -105,6 +105,8 @@ def traffic_key(config, cam, tf, shading, world, rate, fovy, sparse):
 
 
 N_CU, N_SIMD = 256, 1024
+GATHER_LINES_PER_S = 48.5e9   # 128-byte lines per second this chip gathers from a 16 GiB table, one random line per lane or per four lanes (tools/gather_granule.cpp,
+                              # profiles/r04_notes.md 13; 57e9 from the 256 MB memory-side cache): the ceiling of a scattered read, 6.2 of the 8 TB/s
 GATHER_CLK = 16.0      # texture-addresser clocks per 64-lane gather instruction whose quads each stay in one line (tools/ubench_lines.hip)
 VALU_CLK = 4.0         # issue clocks of a VALU instruction of one wave (MI355X_MICROARCH.md; tools/ubench_valu.hip)
 
@@ -131,6 +133,11 @@ def kernel_bound(kms, abytes, ctr):
         bound = max(("ta", "valu"), key=lambda k: u[k])
     out = {"bound": bound, "utilisation": {k: round(v, 4) for k, v in u.items()}, "traffic": traffic, "clock_ghz": clocks / t_prof / 1e9,
            "l1_fill_bytes": ctr.get("TCP_TCC_READ_REQ_sum", 0.0) * 128.0, "ta_busy": ctr.get("TA_TA_BUSY_sum", 0.0) / (N_CU * clocks)}
+    # the memory side's read requests (one per 128-byte line: FETCH_SIZE x 2 KiB / 128) against the measured random-line ceiling: what a gather
+    # kernel is really up against (C3 march 0.77, C4 march 0.84 - while their byte fractions read 0.65 and 0.23)
+    lines = 2.0 * ctr.get("FETCH_SIZE", 0.0) * 1024.0 / 128.0
+    out["gather_lines"] = {"read_requests_per_launch": lines, "g_lines_per_s": lines / t_prof / 1e9, "ceiling_g_lines_per_s": GATHER_LINES_PER_S / 1e9,
+                           "frac": lines / t_prof / GATHER_LINES_PER_S}
     if bound == "ta":
         out.update(achieved=ctr["SQ_INSTS_VMEM_RD"] / t_prof / 1e9, peak=N_CU * (clocks / t_prof) / GATHER_CLK / 1e9, unit="G gather instr/s")
     elif bound == "valu":
@@ -253,7 +260,8 @@ def run_extra_leg(argv, timeout_s):
            "samples_per_frame": doc["per_frame"]["samples"],
            "roofline": {"kernel": r.get("kernel"), "bound": r.get("bound"), "frac": r.get("frac"), "achieved": r.get("achieved"), "peak": r.get("peak"), "unit": r.get("unit"),
                         "traffic": r.get("traffic"), "hbm_algorithmic_frac": r.get("hbm_algorithmic_frac"),
-                        "kernels": {k: {f: v.get(f) for f in ("ms", "bound", "frac", "hbm_algorithmic_frac", "traffic_ratio", "utilisation")} for k, v in r.get("kernels", {}).items()},
+                        "kernels": {k: dict({f: v.get(f) for f in ("ms", "bound", "frac", "hbm_algorithmic_frac", "traffic_ratio", "utilisation")}, gather_line_rate_frac=(v.get("gather_lines") or {}).get("frac"))
+                                    for k, v in r.get("kernels", {}).items()},
                         "volume_upload_ms": r.get("volume_upload_ms"), "volume_resident_bytes": r.get("volume_resident_bytes")}}
     if "without_phase_events" in doc:
         out["ms_per_step_without_phase_events"] = doc["without_phase_events"]["ms_per_step"]
@@ -538,7 +546,7 @@ def worker(args, world):
                 if kb_:
                     # traffic_ratio = counter bytes / algorithmic bytes: well above 1 = lines fetched for a fraction of their voxels (C4: rays 3-5 voxels
                     # apart, one 128-byte brick per 2 x 2 footprint - 2.85), below 1 = the caches serve part of the algorithmic bytes
-                    kern[kname].update(traffic=kb_["traffic"], traffic_ratio=(kb_["traffic"] / kb if kb > 0 else None), utilisation=kb_["utilisation"],
+                    kern[kname].update(traffic=kb_["traffic"], traffic_ratio=(kb_["traffic"] / kb if kb > 0 else None), utilisation=kb_["utilisation"], gather_lines=kb_["gather_lines"],
                                        l1_fill_bytes=kb_["l1_fill_bytes"], ta_busy=kb_["ta_busy"], clock_ghz=kb_["clock_ghz"], hbm_algorithmic_frac=kern[kname]["frac"])
                     if kb_["bound"] != "hbm":
                         kern[kname].update(bound=kb_["bound"], achieved=kb_["achieved"], peak=kb_["peak"], unit=kb_["unit"], frac=kb_["frac"])
