@@ -176,7 +176,7 @@ size_t raymarch_grid_blocks(const RayMarchParams& p);
 // sorts the n owned blocks of src (bx | by << 16, any order) by descending ray length into dst; uses p's camera and box
 // (workspace: schedule_workspace_elems(n) words).  Round 4 - `exact` (one sample per pixel, no jitter: a pixel's ray is known): the class of a block
 // NONE of whose 64 rays meets the volume's box is 0 - tested with the march's own expressions, bit for bit - and nothing else is: those blocks end
-// up last in dst, `info` (2 words, device) receives { blocks with a hit = how many entries of dst need a march / composite workgroup, active pixels of
+// up last in dst, `info` (2 words the device can write - pinned host memory: the caller synchronises the stream and reads them, no copy) receives { blocks with a hit = how many entries of dst need a march / composite workgroup, active pixels of
 // the others }.  The march of a C3 frame used to spend its last 100-150 us dispatching ~25 000 workgroups that found no ray to march (77 % of a
 // 1920x1080 frame lies outside the box's silhouette); they are no longer launched, their pixels are cleared by launch_clear_blocks.
 size_t schedule_workspace_elems(unsigned int n);

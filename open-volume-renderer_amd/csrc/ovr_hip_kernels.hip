@@ -164,34 +164,39 @@ __global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned int
 // short ones fill the gaps.  One workgroup; runs when the camera, the framebuffer size, the volume's box or the shard changes.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kSchedClasses = 64;
-__device__ __forceinline__ unsigned int schedule_class(const RayMarchParams& P, const MarchConsts& mc, unsigned int e)
+// length of probe ray k of block e inside the box (k = 0: the block's centre, 1 ... 4: its corners), -1 = it misses
+__device__ __forceinline__ float schedule_probe(const RayMarchParams& P, const MarchConsts& mc, unsigned int e, int k)
 {
   const f3 c0 = ld3(P.cam_dir), h0 = ld3(P.cam_hor), v0 = ld3(P.cam_ver);
   const f3 oo = to_object(mc, ld3(P.cam_pos));
   const int bx = (int)(e & 0xffffu) * 8, by = (int)(e >> 16) * 8;
-  float longest = -1.f;
-#pragma unroll
-  for (int k = 0; k < 5; ++k) { // the block's centre and corners
-    const int ix = min(bx + (k == 0 ? 4 : (k & 1) ? 0 : 7), P.width - 1), iy = min(by + (k == 0 ? 4 : (k & 2) ? 0 : 7), P.height - 1);
-    const float ux = ((float)ix + .5f) / (float)P.width - 0.5f, uy = ((float)iy + .5f) / (float)P.height - 0.5f;
-    const f3 d = normalize3_exact(mk3(c0.x + ux * h0.x + uy * v0.x, c0.y + ux * h0.y + uy * v0.y, c0.z + ux * h0.z + uy * v0.z));
-    float a = 0.f, b = FLT_MAX;
-    if (intersect_unit_box(a, b, oo, mk3(d.x * mc.inv_scale.x, d.y * mc.inv_scale.y, d.z * mc.inv_scale.z))) longest = fmaxf(longest, b - a);
-  }
-  if (!(longest >= 0.f)) return 0u; // no ray of the block meets the volume: last
+  const int ix = min(bx + (k == 0 ? 4 : (k & 1) ? 0 : 7), P.width - 1), iy = min(by + (k == 0 ? 4 : (k & 2) ? 0 : 7), P.height - 1);
+  const float ux = ((float)ix + .5f) / (float)P.width - 0.5f, uy = ((float)iy + .5f) / (float)P.height - 0.5f;
+  const f3 d = normalize3_exact(mk3(c0.x + ux * h0.x + uy * v0.x, c0.y + ux * h0.y + uy * v0.y, c0.z + ux * h0.z + uy * v0.z));
+  float a = 0.f, b = FLT_MAX;
+  if (intersect_unit_box(a, b, oo, mk3(d.x * mc.inv_scale.x, d.y * mc.inv_scale.y, d.z * mc.inv_scale.z))) return b - a;
+  return -1.f;
+}
+// the block's class from the longest of its five probe rays: 0 = none meets the volume (last), 1 ... kSchedClasses - 1 by length
+__device__ __forceinline__ unsigned int schedule_class_of(const RayMarchParams& P, float longest)
+{
+  if (!(longest >= 0.f)) return 0u;
   const float rel = longest / (P.long_ray_steps * P.step); // 1 = the volume's diagonal
   return (unsigned int)min(kSchedClasses - 1, 1 + (int)(rel * (float)(kSchedClasses - 2)));
 }
 
-// Two launches of ceil(n / 1024) workgroups (a single workgroup needed 0.35 ms for the 32 400 blocks of a 1080p frame - on every
-// camera change, i.e. on every frame of an interactive session; now ~10 us):
-//   schedule_hist_kernel     class of every block, one histogram per workgroup: hist[wg][class]
+// Three launches (a single workgroup needed 0.35 ms for the 32 400 blocks of a 1080p frame - on every camera change, i.e. on every frame of
+// an interactive session), nothing in front of them and no copy behind (`tools/camera_move_breakdown.py`):
+//   schedule_hist_kernel     ceil(n / 1024) workgroups: one histogram row per workgroup, hist[wg][class], + the active pixels of its class-0 blocks
 //   schedule_scatter_kernel  workgroup wg's blocks of class c start at (all blocks of longer classes) + (class-c blocks of the
 //                            workgroups before wg); inside the workgroup they keep their list order (stable: the host lists the
 //                            blocks supertile by supertile, 4x4 blocks = 32x32 pixels, so blocks that run at the same time are
-//                            compact squares of the image and share their bricks in L2 / Infinity Cache)
+//                            compact squares of the image and share their bricks in L2 / Infinity Cache).  Workgroup 0 writes `info`
+//                            (pinned host memory): how many blocks need a workgroup, the pixels of the others
+// (One kernel in which every workgroup counts the whole list itself: 38 us instead of 5 + 10 - the per-wave loop over distinct classes is long
+// inside the silhouette, where 64 consecutive entries hold ~20 length classes.)
 // (Mapping the 16 blocks of a supertile to ONE XCD - workgroup s runs on XCD s % 8 - was measured slower: C3 march 1.63 vs 1.57 ms.)
-//   schedule_classify_kernel one WAVE per block: its length class (five probe rays) and - `exact` - whether ANY of its 64 pixel rays meets the box
+//   schedule_classify_kernel one WAVE per block: its length class (five probe rays, one per lane) and - `exact` - whether ANY of its 64 pixel rays meets the box
 //                            (pixel_ray_hits_box: the march's own test); cls[i] = class | active pixels << 8, class 0 <=> (exact) no ray hits
 __global__ __launch_bounds__(256) void schedule_classify_kernel(const RayMarchParams P, const unsigned int* __restrict__ src, unsigned int n, int exact,
                                                                unsigned int* __restrict__ cls)
@@ -246,43 +251,44 @@ __global__ __launch_bounds__(256) void schedule_classify_kernel(const RayMarchPa
     }
     culled = beyond && sign_safe;
   }
+  float longest = lane < 5 ? schedule_probe(P, mc, e, lane) : -1.f; // (until round 4 lane 0 traced all five: 58 us per camera change at 1080p)
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) longest = fmaxf(longest, __shfl_xor(longest, off));
   if (lane == 0) {
-    unsigned int c = schedule_class(P, mc, e);
+    unsigned int c = schedule_class_of(P, longest);
     if (exact == 1) c = any != 0ull ? max(c, 1u) : 0u;
     if (exact == 2) c = culled ? 0u : max(c, 1u);
     cls[i] = c | ((unsigned int)__popcll(act) << 8);
   }
 }
 
-__global__ __launch_bounds__(1024) void schedule_hist_kernel(const unsigned int* __restrict__ cls, unsigned int n, unsigned int* __restrict__ hist, unsigned int* __restrict__ info)
+constexpr int kSchedRow = kSchedClasses + 1; // a workgroup's histogram row: its class counts, then the active pixels of its class-0 blocks
+__global__ __launch_bounds__(1024) void schedule_hist_kernel(const unsigned int* __restrict__ cls, unsigned int n, unsigned int* __restrict__ hist)
 {
-  __shared__ unsigned int count[kSchedClasses];
-  __shared__ unsigned int empty_pixels;
-  if (threadIdx.x < kSchedClasses) count[threadIdx.x] = 0u;
-  if (threadIdx.x == 0) empty_pixels = 0u;
+  __shared__ unsigned int count[kSchedRow];
+  if (threadIdx.x < kSchedRow) count[threadIdx.x] = 0u;
   __syncthreads();
   const unsigned int i = blockIdx.x * 1024u + threadIdx.x;
   if (i < n) {
     const unsigned int c = cls[i];
     atomicAdd(&count[c & 0xffu], 1u);
-    if ((c & 0xffu) == 0u) atomicAdd(&empty_pixels, c >> 8);
+    if ((c & 0xffu) == 0u) atomicAdd(&count[kSchedClasses], c >> 8);
   }
   __syncthreads();
-  if (threadIdx.x < kSchedClasses) hist[blockIdx.x * kSchedClasses + threadIdx.x] = count[threadIdx.x];
-  if (threadIdx.x == 0 && info && empty_pixels) atomicAdd(&info[1], empty_pixels); // active pixels of the class-0 blocks (one atomic per workgroup)
+  if (threadIdx.x < kSchedRow) hist[blockIdx.x * kSchedRow + threadIdx.x] = count[threadIdx.x];
 }
 
 __global__ __launch_bounds__(1024) void schedule_scatter_kernel(const unsigned int* __restrict__ src, const unsigned int* __restrict__ cls_in, unsigned int n,
                                                                 const unsigned int* __restrict__ hist, unsigned int* __restrict__ dst, unsigned int* __restrict__ info)
 {
-  __shared__ unsigned int base[kSchedClasses], total[kSchedClasses];
+  __shared__ unsigned int base[kSchedRow], total[kSchedRow];
   __shared__ unsigned int wave_count[16][kSchedClasses];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // per class: blocks in the workgroups before this one, and in all of them
-  if (threadIdx.x < kSchedClasses) {
+  // per class: blocks in the workgroups before this one, and in all of them (last column: the pixels of the class-0 blocks)
+  if (threadIdx.x < kSchedRow) {
     unsigned int before = 0u, all = 0u;
     for (unsigned int w = 0; w < gridDim.x; ++w) {
-      const unsigned int h = hist[w * kSchedClasses + threadIdx.x];
+      const unsigned int h = hist[w * kSchedRow + threadIdx.x];
       before += w < blockIdx.x ? h : 0u;
       all += h;
     }
@@ -294,7 +300,8 @@ __global__ __launch_bounds__(1024) void schedule_scatter_kernel(const unsigned i
   if (threadIdx.x == 0) { // descending classes: the longest rays first
     unsigned int at = 0u;
     for (int c = kSchedClasses - 1; c >= 0; --c) { const unsigned int t = total[c]; base[c] += at; at += t; }
-    if (info && blockIdx.x == 0) info[0] = n - total[0]; // the blocks that need a workgroup: everything before class 0
+    // what the host waits for (pinned memory): the blocks that need a workgroup - everything before class 0 - and the active pixels of the others
+    if (info && blockIdx.x == 0) { info[0] = n - total[0]; info[1] = total[kSchedClasses]; }
   }
   const unsigned int i = blockIdx.x * 1024u + threadIdx.x;
   const bool valid = i < n;
@@ -321,21 +328,19 @@ __global__ __launch_bounds__(1024) void schedule_scatter_kernel(const unsigned i
   if (valid) dst[wave_count[wave][cls] + rank] = e;
 }
 
-size_t schedule_workspace_elems(unsigned int n) { return (size_t)((n + 1023u) / 1024u) * kSchedClasses + (size_t)n; } // histograms + one class word per block
+size_t schedule_workspace_elems(unsigned int n) { return (size_t)((n + 1023u) / 1024u) * kSchedRow + (size_t)n; } // histogram rows + one class word per block
 
 hipError_t launch_schedule(const RayMarchParams& p, const unsigned int* src, unsigned int n, unsigned int* dst, unsigned int* workspace, int exact, unsigned int* info,
                            hipStream_t stream)
 {
-  if (info) {
-    const hipError_t e = hipMemsetAsync(info, 0, 2 * sizeof(unsigned int), stream);
-    if (e != hipSuccess) return e;
+  if (n == 0) { // nothing to sort: the caller does not read info
+    return hipSuccess;
   }
-  if (n == 0) return hipSuccess;
   const dim3 grid((n + 1023u) / 1024u);
   unsigned int* hist = workspace;
-  unsigned int* cls = workspace + (size_t)grid.x * kSchedClasses;
+  unsigned int* cls = workspace + (size_t)grid.x * kSchedRow;
   hipLaunchKernelGGL(schedule_classify_kernel, dim3((n + 3u) / 4u), dim3(256), 0, stream, p, src, n, exact, cls);
-  hipLaunchKernelGGL(schedule_hist_kernel, grid, dim3(1024), 0, stream, cls, n, hist, info);
+  hipLaunchKernelGGL(schedule_hist_kernel, grid, dim3(1024), 0, stream, cls, n, hist);
   hipLaunchKernelGGL(schedule_scatter_kernel, grid, dim3(1024), 0, stream, src, cls, n, hist, dst, info);
   return hipGetLastError();
 }
