@@ -190,7 +190,10 @@ struct ovr_hip_renderer {
 
   // transfer function
   float* d_tf_color = nullptr;
-  float* d_tf_alpha = nullptr;
+  float* d_tf_alpha = nullptr;   // inside d_tf_color's allocation: the colours (n_color x 4 floats), then the alphas
+  float* h_tf = nullptr;         // pinned staging of both tables
+  hipEvent_t ev_tf = nullptr;    // behind the last table copy
+  bool tf_copy_pending = false;  // a frame has not yet been ordered behind ev_tf
   int n_color = 0, n_alpha = 0;
   bool have_tfn = false;
 
@@ -468,7 +471,26 @@ int upload_tfn(ovr_hip_renderer* r)
   const TfnP& t = r->tfn.current;
   const int nc = (int)(t.colors.size() / 3), na = (int)(t.alphas.size() / 2);
   if (nc == 0 || na == 0) return 0; // volume.cpp:125: nothing happens for an empty TF
-  std::vector<float> c4((size_t)nc * 4), a((size_t)na);
+  // One pinned staging buffer, one device buffer (colours, then alphas), ONE stream-ordered copy on the render stream: the frames that read the
+  // tables are enqueued behind it, the frame before it has been resolved by the commit.  (Until round 4: hipDeviceSynchronize and two
+  // synchronous copies from pageable vectors - 60 of the 105 us a transfer-function edit cost beside its frame, `tools/tf_edit_time.py`.)
+  const size_t words = (size_t)nc * 4 + (size_t)na;
+  if (r->n_color != nc || r->n_alpha != na) {
+    HIP_TRY(hipDeviceSynchronize()); // nothing may still read (or be copying into) the old tables
+    if (r->d_tf_color) HIP_TRY(hipFree(r->d_tf_color));
+    if (r->h_tf) HIP_TRY(hipHostFree(r->h_tf));
+    r->d_tf_color = r->d_tf_alpha = nullptr; r->h_tf = nullptr;
+    r->n_color = r->n_alpha = 0;
+    HIP_TRY(hipMalloc((void**)&r->d_tf_color, words * sizeof(float)));
+    HIP_TRY(hipHostMalloc((void**)&r->h_tf, words * sizeof(float), hipHostMallocDefault));
+    r->d_tf_alpha = r->d_tf_color + (size_t)nc * 4;
+    r->n_color = nc;
+    r->n_alpha = na;
+  }
+  // (a copy of an earlier commit that has not run yet would read this buffer while it is rewritten - and be overwritten by this commit's copy, which
+  // is enqueued behind it, before any frame reads the tables)
+  float* c4 = r->h_tf;
+  float* a = r->h_tf + (size_t)nc * 4;
   for (int i = 0; i < nc; ++i) { // volume.cpp:112-118
     c4[4 * i + 0] = t.colors[3 * i + 0];
     c4[4 * i + 1] = t.colors[3 * i + 1];
@@ -476,19 +498,11 @@ int upload_tfn(ovr_hip_renderer* r)
     c4[4 * i + 3] = 1.f;
   }
   for (int i = 0; i < na; ++i) a[i] = t.alphas[2 * i + 1]; // volume.cpp:120-123
-  HIP_TRY(hipDeviceSynchronize());
-  if (r->n_color != nc) {
-    if (r->d_tf_color) HIP_TRY(hipFree(r->d_tf_color));
-    HIP_TRY(hipMalloc((void**)&r->d_tf_color, c4.size() * sizeof(float)));
-    r->n_color = nc;
-  }
-  if (r->n_alpha != na) {
-    if (r->d_tf_alpha) HIP_TRY(hipFree(r->d_tf_alpha));
-    HIP_TRY(hipMalloc((void**)&r->d_tf_alpha, a.size() * sizeof(float)));
-    r->n_alpha = na;
-  }
-  HIP_TRY(hipMemcpy(r->d_tf_color, c4.data(), c4.size() * sizeof(float), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(r->d_tf_alpha, a.data(), a.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpyAsync(r->d_tf_color, r->h_tf, words * sizeof(float), hipMemcpyHostToDevice, r->stream()));
+  // the next frame may run on the other framebuffer set's stream (a swap in between: renderapp's order): it waits for this event
+  if (!r->ev_tf) HIP_TRY(hipEventCreateWithFlags(&r->ev_tf, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(r->ev_tf, r->stream()));
+  r->tf_copy_pending = true;
   r->have_tfn = true;
   return 0;
 }
@@ -762,6 +776,7 @@ int enqueue_frame(ovr_hip_renderer* r)
   const int W = r->fbsize.current.w, H = r->fbsize.current.h;
   if (W <= 0 || H <= 0) return 0; // device_impl.cpp:216-217
   hipStream_t st = r->stream();
+  if (r->tf_copy_pending) { HIP_TRY(hipStreamWaitEvent(st, r->ev_tf, 0)); r->tf_copy_pending = false; } // the tables' copy may sit on the other set's stream
   RayMarchParams& P = r->P;
   const bool accumulate = r->accumulate.current != 0;
   const bool sparse = r->sparse.current != 0;
@@ -1603,7 +1618,8 @@ void ovr_hip_destroy(ovr_hip_renderer* r)
     if (r->d_axis[k]) (void)hipFree(r->d_axis[k]);
   }
   if (r->d_tf_color) (void)hipFree(r->d_tf_color);
-  if (r->d_tf_alpha) (void)hipFree(r->d_tf_alpha);
+  if (r->h_tf) (void)hipHostFree(r->h_tf);
+  if (r->ev_tf) (void)hipEventDestroy(r->ev_tf);
   if (r->d_noise) (void)hipFree(r->d_noise);
   if (r->d_mc_minmax) (void)hipFree(r->d_mc_minmax);
   if (r->d_mc_majorant) (void)hipFree(r->d_mc_majorant);
@@ -1635,6 +1651,7 @@ int ovr_hip_set_stream(ovr_hip_renderer* r, void* s)
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
   if (r->members.size() > 1 && s) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_stream: a device group renders on one stream per device");
   if (int e = finish_frame(r)) return e;
+  HIP_TRY(hipStreamSynchronize(r->stream())); // table copies and the like enqueued on the stream that is being left
   r->user_stream = (hipStream_t)s;
   r->use_user_stream = (s != nullptr);
   return 0;
