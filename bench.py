@@ -137,7 +137,8 @@ def kernel_bound(kms, abytes, ctr):
     # kernel is really up against (C3 march 0.77, C4 march 0.84 - while their byte fractions read 0.65 and 0.23)
     lines = 2.0 * ctr.get("FETCH_SIZE", 0.0) * 1024.0 / 128.0
     out["gather_lines"] = {"read_requests_per_launch": lines, "g_lines_per_s": lines / t_prof / 1e9, "ceiling_g_lines_per_s": GATHER_LINES_PER_S / 1e9,
-                           "frac": lines / t_prof / GATHER_LINES_PER_S}
+                           "frac": lines / t_prof / GATHER_LINES_PER_S,
+                           "note": "ceiling = RANDOM lines from HBM; a kernel whose requests share DRAM pages or hit the 256 MB memory-side cache (the shade kernel: neighbouring bricks) can exceed it - 57 G/s from that cache, ~62 G/s streaming"}
     if bound == "ta":
         out.update(achieved=ctr["SQ_INSTS_VMEM_RD"] / t_prof / 1e9, peak=N_CU * (clocks / t_prof) / GATHER_CLK / 1e9, unit="G gather instr/s")
     elif bound == "valu":
