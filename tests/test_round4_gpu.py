@@ -455,7 +455,8 @@ def test_setters_from_another_thread_never_tear_a_frame(ovr, oracle, hip_rendere
 
 
 @pytest.mark.parametrize("dtype,dims", [(np.float32, (37, 41, 29)), (np.uint16, (43, 35, 31)), (np.uint8, (45, 33, 37)), (np.int16, (33, 31, 35)),
-                                        (np.int8, (31, 47, 33)), (np.float64, (31, 33, 30)), (np.float32, (95, 7, 3)), (np.uint16, (5, 70, 66))])
+                                        (np.int8, (31, 47, 33)), (np.float64, (31, 33, 30)), (np.float32, (95, 7, 3)), (np.uint16, (5, 70, 66)),
+                                        (np.float32, (2, 2, 2)), (np.uint8, (3, 2, 5)), (np.uint16, (2, 40, 2)), (np.float32, (4, 3, 2))])
 @pytest.mark.parametrize("where", ["host", "device"])
 def test_the_upload_writes_every_element_of_a_layout(ovr, oracle, hip_renderer_factory, monkeypatch, dtype, dims, where):
     """round 4: the relayout kernels take the layout's rows in storage order (whole 128-byte lines per workgroup) and write padding rows and
