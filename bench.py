@@ -440,7 +440,7 @@ def worker(args, world):
 
     gatherer = None
     if multi:
-        gatherer = ovr.tiles.TileGather(ren, W, H, args.tile, rank, world, dev)
+        gatherer = ovr.tiles.TileGather(ren, W, H, args.tile, rank, world, dev, time_every=4)   # the steps beside the rendering are timed on every 4th pair of frames
 
     def step():
         if not multi:

@@ -81,7 +81,7 @@ class TileGather:
     `ren.render_async()`, `flush()` after the last frame; the caller's `ren.sync()` is the only host wait per frame.
     The reference keeps two framebuffer sets for the same reason (`swap`, device_impl.cpp:102-111)."""
 
-    def __init__(self, ren, width, height, tile, rank, world, device, dst=0):
+    def __init__(self, ren, width, height, tile, rank, world, device, dst=0, time_every=1):
         import ctypes as C
         import torch
         self.C, self.torch = C, torch
@@ -110,6 +110,10 @@ class TileGather:
         self._t_used = {k: [False, False] for k in self._t}
         self.times_ms = {k: 0.0 for k in self._t}   # sums over the frames whose events have been read
         self.times_n = {k: 0 for k in self._t}
+        # an event record costs a few microseconds on both sides of the queue (profiles/r04_notes.md 15): with time_every = n only every n-th frame
+        # carries the timing pairs (the means stay representative), the two events the pipeline itself needs are recorded on every frame
+        self.time_every = max(1, int(time_every))
+        self._timed = [True, True]
         self.payload_bytes = self.payload[0].numel() * 4
         self.index = 0
         self.outstanding = None   # buffer whose gather was enqueued and whose tiles are not scattered yet
@@ -136,20 +140,25 @@ class TileGather:
         C, ren, b = self.C, self.ren, self.outstanding
         if b is None:
             return
-        self._collect("gather_wait", b)
-        self._t["gather_wait"][b][0].record(self.render_stream)
+        timed = self._timed[b]
+        if timed:
+            self._collect("gather_wait", b)
+            self._t["gather_wait"][b][0].record(self.render_stream)
         self.render_stream.wait_event(self.gathered[b])   # also frees payload[b] for the next pack into it
-        self._t["gather_wait"][b][1].record(self.render_stream)
-        self._t_used["gather_wait"][b] = True
+        if timed:
+            self._t["gather_wait"][b][1].record(self.render_stream)
+            self._t_used["gather_wait"][b] = True
         if self.rank == self.dst:
             with self.torch.cuda.stream(self.render_stream):
                 recv = self.recv[b]
-                self._collect("unpack", b)
-                self._t["unpack"][b][0].record(self.render_stream)
+                if timed:
+                    self._collect("unpack", b)
+                    self._t["unpack"][b][0].record(self.render_stream)
                 L.check(ren._lib.ovr_hip_unpack_all_tiles(ren._h, C.c_void_p(recv.data_ptr()), recv[0].numel() * 4, recv.numel() * 4,
                                                            C.c_void_p(self.frame.data_ptr()), self.frame.numel() * 4))
-                self._t["unpack"][b][1].record(self.render_stream)
-                self._t_used["unpack"][b] = True
+                if timed:
+                    self._t["unpack"][b][1].record(self.render_stream)
+                    self._t_used["unpack"][b] = True
         self.outstanding = None
 
     def run(self):
@@ -158,21 +167,28 @@ class TileGather:
         from . import _lib as L
         C, ren, torch = self.C, self.ren, self.torch
         b = self.index & 1
-        self._collect("pack", b)
-        self._collect("gather", b)
+        timed = (self.index // 2) % self.time_every == 0   # (per buffer set: both sets of a timed pair of frames)
+        if timed:
+            self._collect("pack", b)
+            self._collect("gather", b)
         with torch.cuda.stream(self.render_stream):
-            self._t["pack"][b][0].record(self.render_stream)
+            if timed:
+                self._t["pack"][b][0].record(self.render_stream)
             L.check(ren._lib.ovr_hip_pack_tiles(ren._h, C.c_void_p(self.payload[b].data_ptr()), self.payload[b].numel() * 4))
-            self._t["pack"][b][1].record(self.render_stream)
-            self._t_used["pack"][b] = True
+            if timed:
+                self._t["pack"][b][1].record(self.render_stream)
+                self._t_used["pack"][b] = True
             self.packed[b].record(self.render_stream)
         self._scatter_outstanding()
+        self._timed[b] = timed
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(self.packed[b])
-            self._t["gather"][b][0].record(self.comm_stream)
+            if timed:
+                self._t["gather"][b][0].record(self.comm_stream)
             dist.gather(self.payload[b], gather_list=self.bufs[b], dst=self.dst)
-            self._t["gather"][b][1].record(self.comm_stream)
-            self._t_used["gather"][b] = True
+            if timed:
+                self._t["gather"][b][1].record(self.comm_stream)
+                self._t_used["gather"][b] = True
             self.gathered[b].record(self.comm_stream)
         self.outstanding = b
         self.index += 1
