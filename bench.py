@@ -105,6 +105,7 @@ def traffic_key(config, cam, tf, shading, world, rate, fovy, sparse):
 
 
 N_CU, N_SIMD = 256, 1024
+PHASE_EVERY = 4            # timed_leg: the steps whose frames carry per-phase events
 GATHER_LINES_PER_S = 48.5e9   # 128-byte lines per second this chip gathers from a 16 GiB table, one random line per lane or per four lanes (tools/gather_granule.cpp,
                               # profiles/r04_notes.md 13; 57e9 from the 256 MB memory-side cache): the ceiling of a scattered read, 6.2 of the 8 TB/s
 GATHER_CLK = 16.0      # texture-addresser clocks per 64-lane gather instruction whose quads each stay in one line (tools/ubench_lines.hip)
@@ -493,17 +494,30 @@ def worker(args, world):
         torch.cuda.synchronize()
         tot = dict(samples=0, shaded_samples=0, shadow_samples=0, rays=0, active_pixels=0, skipped_samples=0, skipped_shadow_samples=0)
         leg = dict(kernel_ms=0.0, phase_ms=[0.0, 0.0, 0.0], last=None)
+        # per-phase times (two more events between the frame's kernels, ~16 us a frame) are taken on every PHASE_EVERY-th step of the region and scaled:
+        # the per-kernel durations are still HIP events over the timed region, the region pays a quarter of what they cost
+        phases_on = timed_leg.phases
+        n_phase = 0
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
+            sampled = phases_on and i % PHASE_EVERY == 0
+            if phases_on:
+                ren.set_phase_timing(sampled)
             step()
             st = ren.stats()
             for k in tot:
                 tot[k] += getattr(st, k)
             leg["kernel_ms"] += st.kernel_ms
-            leg["phase_ms"][0] += st.march_ms
-            leg["phase_ms"][1] += st.shade_ms
-            leg["phase_ms"][2] += st.composite_ms
+            if sampled:
+                n_phase += 1
+                leg["phase_ms"][0] += st.march_ms
+                leg["phase_ms"][1] += st.shade_ms
+                leg["phase_ms"][2] += st.composite_ms
             leg["last"] = st
+        if phases_on:
+            ren.set_phase_timing(True)
+            leg["phase_ms"] = [p * steps / max(n_phase, 1) for p in leg["phase_ms"]]   # as sums over `steps` frames, like kernel_ms
+            leg["phase_steps_sampled"] = n_phase
         if gatherer is not None:
             if step.gathered != step.count:   # --gather-every: the last frame has not been gathered yet
                 gatherer.run()
@@ -564,17 +578,20 @@ def worker(args, world):
         dom = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
         return kern, dom, abytes
 
+    timed_leg.phases = True
     main_leg = timed_leg(args.steps, args.warmup)
     main_extra_warmup = timed_leg.extra_warmup
     dt, tot, kernel_ms, phase_ms, last_stats = main_leg["dt"], main_leg["tot"], main_leg["kernel_ms"], main_leg["phase_ms"], main_leg["last"]
     # The same steps again without the two events between the frame's kernels (ovr_hip_set_phase_timing(0), ABI v9: what the plugin runs).  The
     # headline's timed region keeps them - its per-kernel durations ARE those events - and pays ~16 us per frame for it; this leg is never `value`.
     ren.set_phase_timing(False)
+    timed_leg.phases = False
     plain_leg = timed_leg(args.steps, 2)
+    timed_leg.phases = True
     ren.set_phase_timing(True)
     without_phase_events = {"ms_per_step": plain_leg["dt"] / args.steps * 1e3, "fps": args.steps / plain_leg["dt"],
                             "msamples_per_s": plain_leg["tot"]["samples"] / plain_leg["dt"] / 1e6, "steps": args.steps,
-                            "note": "ovr_hip_set_phase_timing(0): no hipEventRecord between the frame's kernels - the plugin's setting; same frames"}
+                            "note": "ovr_hip_set_phase_timing(0): no hipEventRecord between the frame's kernels - the plugin's setting; same frames (the headline's region takes them on every 4th step)"}
     if multi and world == 1:
         # forced single-rank gather: the gathered frame must be the renderer's own frame
         fb = ovr.FrameBufferData()
