@@ -230,7 +230,7 @@ struct ovr_hip_renderer {
 
   // counters
   unsigned long long* d_counters = nullptr;  // start of the frame words: [0, 64) the counters, [128, 128 + ctrl) the pool's control words, then the reduction's ticket
-  bool phase_timing = true;                  // ovr_hip_set_phase_timing
+  std::atomic<bool> phase_timing{ true };    // ovr_hip_set_phase_timing (any thread)
   bool frame_phase_timed = true;             // ... as the frame in flight was launched
   bool frame_words_dirty = true;             // the next launch may not rely on the last frame's reduction having zeroed them (RayMarchParams::zero_first)
   unsigned int* d_block_counters = nullptr; // per-workgroup partial counters
@@ -1027,8 +1027,9 @@ int launch_frame(ovr_hip_renderer* r)
   r->frame_words_dirty = true; // until the launch below has been enqueued completely
   // the events between the frame's kernels (per-phase times) cost ~16 us a frame - hipEventRecord is not free on either side of the queue; the
   // first and the last one (kernel_ms: what the layout / pipeline tuner compares) stay
-  hipEvent_t evs[4] = { r->ev[0], r->phase_timing ? r->ev[1] : nullptr, r->phase_timing ? r->ev[2] : nullptr, r->ev[3] };
-  r->frame_phase_timed = r->phase_timing;
+  const bool phases = r->phase_timing.load();
+  hipEvent_t evs[4] = { r->ev[0], phases ? r->ev[1] : nullptr, phases ? r->ev[2] : nullptr, r->ev[3] };
+  r->frame_phase_timed = phases;
   HIP_TRY(launch_raymarch(r->P, st, evs));
   r->frame_words_dirty = false;
   r->async_pending = true;
@@ -1831,7 +1832,7 @@ int ovr_hip_set_phase_timing(ovr_hip_renderer* r, int32_t on)
 {
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
   GroupLock gl(r);
-  r->phase_timing = on != 0; // read when the next frame is launched; a frame in flight keeps what it was launched with
+  r->phase_timing.store(on != 0); // read when the next frame is launched; a frame in flight keeps what it was launched with
   GROUP_FORWARD(r, ovr_hip_set_phase_timing(m, on));
   return 0;
 }
