@@ -787,8 +787,11 @@ int enqueue_frame(ovr_hip_renderer* r)
         // (the set this frame renders into needs no memset when the frame writes every pixel of it: dense sampling, the whole image - launched
         // blocks write their pixels, the others are cleared by launch_clear_blocks; 2 x 7 us per camera change of an accumulating session)
         if (i == r->cur && !sparse && r->shard.current.world <= 1) continue;
-        HIP_TRY(hipMemsetAsync(r->d_rgba[i], 0, n * 4 * sizeof(float), st));
-        HIP_TRY(hipMemsetAsync(r->d_grad[i], 0, n * 3 * sizeof(float), st));
+        // the other set is cleared on ITS stream (whatever touches it next - a frame after a swap, a mapframe - is enqueued there): the memsets
+        // run beside this frame's schedule kernels instead of in front of them
+        hipStream_t si = (r->use_user_stream || i == r->cur) ? st : r->own_stream[i];
+        HIP_TRY(hipMemsetAsync(r->d_rgba[i], 0, n * 4 * sizeof(float), si));
+        HIP_TRY(hipMemsetAsync(r->d_grad[i], 0, n * 3 * sizeof(float), si));
       }
       // the reference leaves the accumulation buffer as it is (device_impl.cpp:229-230 are commented out), which is
       // only sound because frame 1 overwrites it; sparse frames do not overwrite every pixel, so it is cleared here
