@@ -65,6 +65,13 @@ for name in sorted(f for f in os.listdir(SCENES) if f.endswith('.json') and pick
         ren.set_empty_space_skipping(skip); ren.commit()
         for _ in range(int(os.environ.get('OVR_SCENE_WARMUP', '3'))):
             ren.render()
+        # (round 4) replicas are built in the background and the renderer measures layout / pipeline on shade-heavy scenes: time settled frames
+        t_settle, n_settle = time.perf_counter(), 0
+        while n_settle < 64 and time.perf_counter() - t_settle < 5.0 and (ren.stats().tuning == 1 or ren.stats().replicas_building > 0):
+            ren.render(); n_settle += 1
+        if n_settle:
+            for _ in range(3):
+                ren.render()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10):
             ren.render()
