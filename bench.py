@@ -11,7 +11,12 @@ into tiles dealt over the ranks (one process per GPU, volume replicated) and eve
 tiles to rank 0 over RCCL - total work is fixed, so scaling is "strong".
 
 `python bench.py --gpus N` starts its own N ranks (a child `python -m torch.distributed.run`, before this process touches
-the GPU); under an external launcher (WORLD_SIZE set) it is one of the ranks.  Prints ONE JSON line on rank 0."""
+the GPU); under an external launcher (WORLD_SIZE set) it is one of the ranks.
+
+Output (round 5): rank 0 prints ONE JSON line of < 4 KB on stdout - the contract's fields, the dominant kernel's `roofline`, `cpu_baseline`,
+a four-figure summary per variant and extra leg (`compact_record`) - and writes the full record (views, variants, per-kernel counters, per-rank
+tables, the device group, the extra legs) to `bench_detail.json` beside this script (`--detail-file`), to gpurun_out/ when that directory
+exists, and as one `[bench detail]` line to stderr."""
 import argparse
 import hashlib
 import itertools
@@ -233,12 +238,119 @@ def cpu_baseline(cfg, vol_host, colors, alphas, vr, cam, noise=None, budget_s=10
     return out
 
 
+COMPACT_LIMIT = 4096   # bytes of the ONE stdout line (the driver's record keeps a few KB of stdout; 20 KB of detail made it unparseable)
+
+
+def _sig(x, digits=5):
+    """floats of the stdout line: `digits` significant digits (the detail file keeps full precision)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def _leg_summary(leg):
+    """one extra / variant leg in the stdout line: what it took, what it delivered, and the bound of its dominant kernel"""
+    if not isinstance(leg, dict):
+        return None
+    if "error" in leg:
+        return {"error": str(leg["error"])[:120]}
+    r = leg.get("roofline") or {}
+    dom = (r.get("kernel") or leg.get("kernel") or "").split(" ")[0]
+    kd = (r.get("kernels") or {}).get(dom, {})
+    out = {"ms_per_step": _sig(leg.get("ms_per_step")), "value": _sig(leg.get("value", (leg.get("gsamples_per_s") or 0.0) * 1e3 if leg.get("gsamples_per_s") is not None else None)),
+           "bound": r.get("bound", leg.get("bound")), "frac": _sig(r.get("frac", leg.get("frac"))),
+           "traffic_ratio": _sig(kd.get("traffic_ratio", leg.get("traffic_ratio")))}
+    for k in ("gather_line_rate_frac", "compulsory_floor_bytes", "march_ms", "shade_ms", "upload_ms", "host_us_per_frame", "gather"):
+        v = kd.get(k, r.get(k, leg.get(k)))
+        if v is not None:
+            out[k] = _sig(v)
+    return out
+
+
+def compact_record(d, detail_name):
+    """The ONE stdout line (< COMPACT_LIMIT bytes): the contract's fields, the dominant kernel's roofline, the CPU baseline and a summary per extra leg.
+    Everything else - views, variants, per-kernel notes, per-rank tables, the device group - is in the detail file (and on stderr).  Protocol mirrored:
+    apps/main_batch.cpp:278-289 (5 warm-up + N timed blocking render() calls, fps = N / wall)."""
+    r = d.get("roofline", {})
+    dom = (r.get("kernel") or "").split(" ")[0]
+    kd = (r.get("kernels") or {}).get(dom, {})
+    c = d.get("config", {})
+    out = {k: _sig(d.get(k)) for k in ("metric", "value", "unit", "fps", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = {k: c.get(k) for k in ("workload", "name", "volume", "image", "camera", "transfer_function", "sampling_rate", "spp", "shading", "volume_layout_read", "parallelism") if k in c}
+    pf = d.get("per_frame", {})
+    out["per_frame"] = {k: _sig(pf.get(k), 10) for k in ("samples", "shaded_samples", "shadow_samples", "active_pixels") if k in pf}
+    out["roofline"] = {"kernel": r.get("kernel"), "bound": r.get("bound"), "achieved": _sig(r.get("achieved")), "peak": r.get("peak"), "unit": r.get("unit"), "frac": _sig(r.get("frac")),
+                       "traffic": r.get("traffic"), "traffic_ratio": _sig(kd.get("traffic_ratio")), "kernel_ms": _sig(r.get("kernel_ms")),
+                       "algorithmic_bytes_per_launch": r.get("algorithmic_bytes_per_launch"),
+                       "gather_line_rate_frac": _sig((kd.get("gather_lines") or {}).get("frac")),
+                       "frame": {"frac": _sig((r.get("pipeline") or {}).get("frac")), "kernel_ms": _sig((r.get("pipeline") or {}).get("kernel_ms")),
+                                 "algorithmic_bytes": (r.get("pipeline") or {}).get("algorithmic_bytes_per_launch")},
+                       "kernels_ms": {k: _sig(v.get("ms")) for k, v in (r.get("kernels") or {}).items()},
+                       "kernels_frac": {k: _sig(v.get("frac")) for k, v in (r.get("kernels") or {}).items()},
+                       "compulsory_floor_bytes": r.get("compulsory_floor_bytes"), "upload_ms": r.get("upload_ms")}
+    if "cpu_baseline" in d:
+        cb = d["cpu_baseline"]
+        out["cpu_baseline"] = {k: _sig(cb.get(k)) for k in ("value", "unit", "cores", "cpu_model", "kind", "sample")}
+    if d.get("without_phase_events"):
+        out["ms_per_step_without_phase_events"] = _sig(d["without_phase_events"].get("ms_per_step"))
+    if d.get("with_empty_space_skipping"):
+        sk = d["with_empty_space_skipping"]
+        out["with_empty_space_skipping"] = {"ms_per_step": _sig(sk.get("ms_per_step")), "frames_bit_identical": sk.get("frames_bit_identical")}
+    var = r.get("variants") or {}
+    if var:
+        out["variants"] = {k: {kk: vv for kk, vv in _leg_summary(v).items() if kk in ("ms_per_step", "bound", "frac")} for k, v in var.items()}
+    if d.get("extra"):
+        out["extra"] = {k: _leg_summary(v) for k, v in d["extra"].items()}
+    for k in ("rccl_ranks", "backend", "device_count", "gather"):
+        if k in d:
+            out[k] = d[k]
+    if d.get("ranks"):
+        rk = d["ranks"]
+        out["ranks"] = {k: {m: _sig(rk[k][m], 4) for m in ("min", "mean", "max")} for k in ("kernel_ms", "gather_ms", "gather_wait_ms", "step_ms") if k in rk}
+        out["ranks"]["work_imbalance_max_over_mean"] = _sig(rk.get("work_imbalance_max_over_mean"), 4)
+    if d.get("device_group"):
+        g = d["device_group"]
+        out["device_group"] = {"devices": g.get("devices"), "gather": g.get("gather"), "host_us_per_frame": _sig(g.get("host_us_per_frame")),
+                               "kernel_ms_per_member": [_sig(v, 4) for v in (g.get("per_member") or {}).get("kernel_ms", [])][:16]}
+    out["detail"] = detail_name
+    line = json.dumps(out, separators=(",", ":"))
+    # never above the limit: shed the optional blocks, least important first (the contract's fields, roofline and cpu_baseline stay)
+    for k in ("device_group", "ranks", "variants", "with_empty_space_skipping", "per_frame", "extra"):
+        if len(line) < COMPACT_LIMIT:
+            break
+        out.pop(k, None)
+        out["shed"] = out.get("shed", []) + [k]
+        line = json.dumps(out, separators=(",", ":"))
+    return line
+
+
+def write_detail(d, path):
+    """the full record: beside the script (or --detail-file), under gpurun_out/ when that exists (merged back from the GPU box), and on stderr"""
+    text = json.dumps(d)
+    paths = [path]
+    g = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(g) and os.path.dirname(os.path.abspath(path)) == ROOT:
+        paths.append(os.path.join(g, os.path.basename(path)))
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                f.write(text + "\n")
+        except OSError as e:
+            print(f"[bench] could not write {p}: {e}", file=sys.stderr)
+    print("[bench detail] " + text, file=sys.stderr)
+
+
 def run_extra_leg(argv, timeout_s):
     """one more configuration as a child `python bench.py ...` (its own process: its own volume, nothing shared with the timed region that
     has already finished), trimmed to the figures the record needs.  Never raises: a failure is reported in place of the figures."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE",
                                                                "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "OVR_BENCH_FORCE_GATHER", "OVR_BENCH_CONFIG")}
-    cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--no-extras", "--no-cpu-baseline", "--no-views", "--no-skip-leg"]
+    import tempfile
+    fd, detail = tempfile.mkstemp(prefix="ovr_bench_leg_", suffix=".json")
+    os.close(fd)
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--no-extras", "--no-cpu-baseline", "--no-views", "--no-skip-leg", "--detail-file", detail]
     t0 = time.perf_counter()
     try:
         p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
@@ -253,9 +365,15 @@ def run_extra_leg(argv, timeout_s):
             return {"command": " ".join(cmd[1:]), "error": f"timed out after {timeout_s} s"}
         if p.returncode != 0:
             return {"command": " ".join(cmd[1:]), "error": f"exit code {p.returncode}: {(se or '')[-600:]}"}
-        doc = json.loads([l for l in so.splitlines() if l.startswith("{")][-1])
+        with open(detail) as f:   # the child's full record (its stdout carries the compact line only)
+            doc = json.load(f)
     except Exception as e:  # noqa: BLE001 - an extra leg must never take the headline down
         return {"command": " ".join(cmd[1:]), "error": repr(e)[:600]}
+    finally:
+        try:
+            os.unlink(detail)
+        except OSError:
+            pass
     r = doc.get("roofline", {})
     out = {"command": " ".join(cmd[1:]), "wall_s": round(time.perf_counter() - t0, 1), "workload": doc["config"]["workload"], "parallelism": doc["config"].get("parallelism"),
            "value": doc["value"], "unit": doc["unit"], "fps": doc["fps"], "ms_per_step": doc["ms_per_step"], "steps": doc["steps"], "dtype": doc["dtype"],
@@ -264,7 +382,8 @@ def run_extra_leg(argv, timeout_s):
                         "traffic": r.get("traffic"), "hbm_algorithmic_frac": r.get("hbm_algorithmic_frac"),
                         "kernels": {k: dict({f: v.get(f) for f in ("ms", "bound", "frac", "hbm_algorithmic_frac", "traffic_ratio", "utilisation")}, gather_line_rate_frac=(v.get("gather_lines") or {}).get("frac"))
                                     for k, v in r.get("kernels", {}).items()},
-                        "volume_upload_ms": r.get("volume_upload_ms"), "volume_resident_bytes": r.get("volume_resident_bytes")}}
+                        "volume_upload_ms": r.get("volume_upload_ms"), "upload_ms": r.get("upload_ms"), "volume_resident_bytes": r.get("volume_resident_bytes"),
+                        "compulsory_floor_bytes": r.get("compulsory_floor_bytes"), "compulsory_floor_ms": r.get("compulsory_floor_ms")}}
     if "without_phase_events" in doc:
         out["ms_per_step_without_phase_events"] = doc["without_phase_events"]["ms_per_step"]
     if "device_group" in doc:
@@ -314,6 +433,8 @@ def main():
     ap.add_argument("--sparse-sampling", action="store_true", help="the foveated mode with the interactive app's default focus (apps/main_app.cpp:123-124)")
     ap.add_argument("--devices", default=None, help="ONE process drives these HIP devices as an in-process device group (ovr_hip_create_group - what the C++ plugin does "
                     "for OVR_HIP_DEVICES / --hip-devices): image tiles over the devices, gathered on the first one over RCCL or peer copies; e.g. 0,1,2,3 (0,0: a rehearsal on one card)")
+    ap.add_argument("--detail-file", default=os.path.join(ROOT, "bench_detail.json"), help="where rank 0 writes the full record (views, variants, per-kernel counters, per-rank tables, "
+                    "extra legs); stdout carries one compact line of < 4 KB")
     ap.add_argument("--no-extras", action="store_true", help="do not run the extra legs of the default command (C4 and C5 on one GPU, rank 0's shard of 8, the device group)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -888,7 +1009,8 @@ def worker(args, world):
                 del os.environ["OVR_HIP_GATHER"]
             out["extra"] = extra
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        write_detail(out, args.detail_file)
+        os.write(json_fd, (compact_record(out, os.path.basename(args.detail_file)) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -62,6 +62,9 @@ def load():
     lib.ovr_oracle_sample_tfn.argtypes = [C.POINTER(Scene), C.c_float, fp]
     lib.ovr_oracle_opacity_correction.argtypes = [C.c_float, C.c_float, C.c_float]
     lib.ovr_oracle_opacity_correction.restype = C.c_float
+    lib.ovr_oracle_set_powf_mode.argtypes = [C.c_int]
+    lib.ovr_oracle_set_powf_mode.restype = C.c_int
+    lib.ovr_oracle_get_powf_mode.restype = C.c_int
     lib.ovr_oracle_render_frame.argtypes = [C.POINTER(Scene), C.c_int, C.c_int, fp, fp, fp, C.POINTER(Counters), C.c_int]
     lib.ovr_oracle_trace_ray.argtypes = [C.POINTER(Scene), fp, fp, fp, fp, C.POINTER(Counters)]
     lib.ovr_oracle_rgba8.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
@@ -86,6 +89,15 @@ def load():
 
 def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+POWF_EXP2_LOG2, POWF_LIBM = 0, 1
+
+
+def set_powf_mode(mode):
+    """how the oracle restates __powf (shaders_raymarching.cu:64-66,118-122): POWF_EXP2_LOG2 (default, CUDA's documented definition
+    exp2f(y * __log2f(x))) or POWF_LIBM (libm's powf, rounds 1-4).  Process-wide; returns the previous mode."""
+    return load().ovr_oracle_set_powf_mode(int(mode))
 
 
 class OracleScene:

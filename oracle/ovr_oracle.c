@@ -13,7 +13,13 @@
  *    (for the diagonal instance transform this is one fma per component)
  *  - CUDA linear texture filtering is restated with full fp32 weights (not the hardware's 8-bit fraction):
  *    x = u*N - 0.5, i = floor(x), f = x - i, both taps clamped to [0, N-1]   (CUDA programming guide, "linear filtering")
- *  - __powf(x,y) is restated as powf(x,y); __frcp_rn(x) as 1.f/x (both correctly rounded)
+ *  - __powf(x,y) is restated as what CUDA documents it to be, exp2f(y * __log2f(x)) (CUDA C programming guide, "Intrinsic
+ *    functions": "__powf(x, y) is implemented as exp2f(y * __log2f(x))"), with a float product and libm's exp2f / log2f
+ *    standing in for the hardware's ex2.approx / lg2.approx (round 5; until round 4 it was libm's powf - the
+ *    only place where the restatement departed from the reference's own structure: 1 - (1 - a)^dt for a <~ 1e-6 is a
+ *    difference of two floats next to 1, and powf lands on other 6e-8 steps there than the two-step form does).
+ *    ovr_oracle_set_powf_mode(1) / OVR_ORACLE_POWF=libm selects libm's powf again.
+ *  - __frcp_rn(x) is restated as 1.f/x (correctly rounded)
  */
 #include "ovr_oracle.h"
 
@@ -284,11 +290,38 @@ void ovr_oracle_sample_tfn(const ovr_oracle_scene* s, float sample, float rgba[4
   tfn_rgba_at(s, &r, sample, rgba);
 }
 
-/* shaders_raymarching.cu:118-122 with nearly_equal (shaders_common.h:321-327) and corrected_value */
+/* __powf of shaders_raymarching.cu:64-66,118-122.  mode 0 (default): exp2f(y * log2f(x)) - CUDA's documented definition of
+ * __powf, the product rounded to float (the kernel's v_exp_f32(y * v_log_f32(x)) has the same structure);
+ * mode 1: libm's powf (rounds x^y once; the restatement of rounds 1-4).  -1 = not chosen yet: OVR_ORACLE_POWF=libm|exp2. */
+static int g_powf_mode = -1;
+int ovr_oracle_set_powf_mode(int mode)
+{
+  const int old = g_powf_mode;
+  g_powf_mode = mode ? 1 : 0;
+  return old < 0 ? 0 : old;
+}
+static inline int powf_mode(void)
+{
+  if (g_powf_mode < 0) {
+    const char* e = getenv("OVR_ORACLE_POWF");
+    g_powf_mode = (e && strcmp(e, "libm") == 0) ? 1 : 0;
+  }
+  return g_powf_mode;
+}
+int ovr_oracle_get_powf_mode(void) { return powf_mode(); }
+static inline float fast_powf(float x, float y)
+{
+  if (powf_mode() == 1) return powf(x, y);
+  const float l = log2f(x);
+  const float m = y * l;
+  return exp2f(m);
+}
+
+/* shaders_raymarching.cu:118-122 (and :64-66 in the shadow march) with nearly_equal (shaders_common.h:321-327) and corrected_value */
 float ovr_oracle_opacity_correction(float alpha, float base, float dt)
 {
   const float adj = base * dt;
-  if (!(fabsf(adj - 1.f) < 1e-7f)) alpha = clamp01(1.f - powf(1.f - alpha, adj));
+  if (!(fabsf(adj - 1.f) < 1e-7f)) alpha = clamp01(1.f - fast_powf(1.f - alpha, adj));
   return alpha;
 }
 

@@ -135,6 +135,11 @@ void ovr_oracle_jitter(const ovr_oracle_scene* s, int ix, int iy, int frame_inde
 uint16_t ovr_oracle_float_to_half(float f);
 float ovr_oracle_half_to_float(uint16_t h);
 
+/* how __powf (shaders_raymarching.cu:64-66,118-122) is restated: 0 (default) = exp2f(y * log2f(x)), CUDA's documented definition of the
+ * intrinsic; 1 = libm's powf (rounds 1-4).  Process-wide; returns the previous mode.  OVR_ORACLE_POWF=libm sets the initial mode. */
+int ovr_oracle_set_powf_mode(int mode);
+int ovr_oracle_get_powf_mode(void);
+
 /* ovr/devices/optix7/shaders_common.h:186-193 + texture setup array.cpp:300-306: clamp p to [0,1]^3,
  * linear-filtered, clamp-addressed sample at normalized coordinate p (object space) */
 float ovr_oracle_sample_volume(const ovr_oracle_scene* s, const float p[3]);

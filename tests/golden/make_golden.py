@@ -24,7 +24,7 @@ CASES = {
 }
 
 
-def main():
+def generate():
     out = {}
     for name, kw in CASES.items():
         case = make_case(ovr, O, **kw)
@@ -37,8 +37,18 @@ def main():
     rgba, grad, cnt = oracle_scene(O, case).render(frames=3, accumulate=True, nthreads=1)
     out["accum3_spp2/rgba"] = rgba
     out["accum3_spp2/counters"] = np.array([cnt.rays, cnt.samples, cnt.shaded_samples, cnt.shadow_samples, cnt.shadow_samples_visible], dtype=np.int64)
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "frames.npz"), **out)
-    print("wrote", len(out), "arrays")
+    return out
+
+
+def main():
+    """frames.npz: the oracle's default restatement of __powf, exp2f(y * log2f(x)) (round 5); frames_powf_libm.npz: the same scenes with libm's powf
+    (O.POWF_LIBM) - the file rounds 1-4 committed as frames.npz, kept so that the switch is known to reproduce the old oracle bit for bit"""
+    for mode, name in ((O.POWF_EXP2_LOG2, "frames.npz"), (O.POWF_LIBM, "frames_powf_libm.npz")):
+        old = O.set_powf_mode(mode)
+        out = generate()
+        O.set_powf_mode(old)
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", name), **out)
+        print("wrote", len(out), "arrays to", name)
 
 
 if __name__ == "__main__":

@@ -1,5 +1,33 @@
 """shared helpers for the parity tests: build the same scene for the HIP device and for the CPU oracle"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
 import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(argv, env=None, timeout=900):
+    """`python bench.py <argv>` as the driver runs it: stdout must carry exactly ONE line starting with `{` - the compact record, below 4 KB
+    (a 20 KB line left the driver's record unparsed) - and the full record goes to --detail-file.  Returns (compact, detail, process)."""
+    fd, detail = tempfile.mkstemp(prefix="ovr_bench_test_", suffix=".json")
+    os.close(fd)
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv) + ["--detail-file", detail], env=env, capture_output=True, text=True, timeout=timeout)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, f"{len(lines)} JSON lines on stdout"
+        assert len(lines[0].encode()) < 4096, len(lines[0])
+        with open(detail) as f:
+            return json.loads(lines[0]), json.load(f), out
+    finally:
+        try:
+            os.unlink(detail)
+        except OSError:
+            pass
 
 
 def make_case(ovr, O, n=32, dtype=np.float32, tf="sparse", cam="front", size=(64, 48), shading=2, rate=1.0, spp=1,

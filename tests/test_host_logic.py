@@ -126,3 +126,43 @@ def test_bench_refuses_a_launcher_mismatch_and_keys_traffic_by_the_kernel_hash(t
     assert bench.kernel_bound(1.0, 5.0e9, ctr_hbm)["bound"] == "hbm"
     assert bench.kernel_bound(1.0, 9.0e9, ctr_hbm)["bound"] != "hbm"   # more algorithmic bytes than traffic: the caches serve it, HBM is not the bound
     assert bench.kernel_bound(1.0, 5.0e9, None) is None
+
+
+def test_the_stdout_line_of_bench_is_compact(tmp_path):
+    """the driver keeps a few KB of stdout - round 4's 20 KB line left BENCH_r04.parsed null.  The line is built from the full
+    record by bench.compact_record: below 4 KB, the contract's fields, the dominant kernel's roofline, the CPU baseline, a summary per extra leg;
+    everything else goes to the detail file.  Checked on round 4's real 20 KB record (committed) and on a stub with hostile sizes."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    with open(os.path.join(root, "profiles", "r04_default_cmd", "bench.json")) as f:
+        full = json.loads([l for l in f if l.startswith("{")][-1])
+    assert len(json.dumps(full)) > 15000
+    line = bench.compact_record(full, "bench_detail.json")
+    assert len(line.encode()) < bench.COMPACT_LIMIT == 4096 and "\n" not in line
+    c = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in c, k
+    assert abs(c["value"] - full["value"]) <= 1e-4 * full["value"] and abs(c["ms_per_step"] - full["ms_per_step"]) <= 1e-4 * full["ms_per_step"]
+    assert c["config"]["workload"] == full["config"]["workload"] and "model" not in c["config"]
+    r = c["roofline"]
+    for k in ("kernel", "bound", "frac", "achieved", "peak", "unit", "traffic", "traffic_ratio", "kernel_ms", "algorithmic_bytes_per_launch"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] == full["roofline"]["traffic"]
+    assert set(c["cpu_baseline"]) == {"value", "unit", "cores", "cpu_model", "kind", "sample"} and c["cpu_baseline"]["kind"] == "port"
+    assert set(c["extra"]) == set(full["extra"])
+    for leg in c["extra"].values():
+        assert {"ms_per_step", "value", "frac", "traffic_ratio"} <= set(leg)
+    assert c["variants"]["sampling_rate_4"]["ms_per_step"] > 20 and c["variants"]["sampling_rate_4"]["bound"] == "valu"   # the number renderapp users get (VERDICT r4 #7)
+    assert "shed" not in c and c["detail"] == "bench_detail.json"
+    # a stub whose optional blocks are oversized: they are shed, the contract's fields stay, the limit holds
+    stub = dict(full, extra={f"leg{i}": {"error": "x" * 500} for i in range(40)})
+    stub["ranks"] = {k: {"min": 0.1, "mean": 0.2, "max": 0.3} for k in ("kernel_ms", "gather_ms", "gather_wait_ms", "step_ms")}
+    line = bench.compact_record(stub, "d.json")
+    c = json.loads(line)
+    assert len(line.encode()) < 4096 and "extra" in c["shed"] and c["roofline"]["frac"] == r["frac"] and "cpu_baseline" in c
+    # write_detail: the file beside the script holds the full record
+    bench.write_detail(full, str(tmp_path / "bench_detail.json"))
+    assert json.load(open(tmp_path / "bench_detail.json"))["roofline"]["views"] == full["roofline"]["views"]

@@ -131,6 +131,35 @@ def test_tfn_nodal_lerp(ovr, oracle):
     assert sc.tfn(-7.0)[3] == 0.0 and sc.tfn(99.0)[3] == 1.0  # clamped to the value range
 
 
+def test_powf_is_restated_as_cuda_defines_the_intrinsic(oracle):
+    """__powf(x, y) = exp2f(y * __log2f(x)) (CUDA C programming guide, intrinsic functions; shaders_raymarching.cu:64-66,118-122): the default
+    opacity correction is 1 - exp2f(float(dt * log2f(1 - a))) evaluated in float32 steps, libm's powf is the switch"""
+    f = oracle.load().ovr_oracle_opacity_correction
+    assert oracle.load().ovr_oracle_get_powf_mode() == oracle.POWF_EXP2_LOG2
+    rng = np.random.default_rng(11)
+    a = np.concatenate([rng.random(2000), 10.0 ** rng.uniform(-8, -1, 2000), 1.0 - 10.0 ** rng.uniform(-7, -1, 2000)]).astype(np.float32)
+    dt = np.concatenate([rng.uniform(0.01, 2.0, 3000), np.full(3000, 0.25)]).astype(np.float32)
+    got = np.array([f(float(x), 1.0, float(t)) for x, t in zip(a, dt)], dtype=np.float32)
+    x = (np.float32(1.0) - a).astype(np.float32)
+    l = np.log2(x.astype(np.float64))                      # log2f is correctly rounded to < 1 ulp: compare through float64 with 1-ulp slack on each step
+    m = (dt.astype(np.float64) * l.astype(np.float32).astype(np.float64)).astype(np.float32)
+    want = np.clip(np.float32(1.0) - np.exp2(m.astype(np.float64)).astype(np.float32), 0.0, 1.0)
+    keep = np.abs(dt - 1.0) >= 1e-7
+    assert np.max(np.abs(got[keep] - want[keep])) <= 2.4e-7           # two float steps next to 1 (log2f / exp2f within an ulp of the float64 route)
+    # the two modes differ exactly where rounds 1-4's tolerances came from: on the 6e-8 grid of 1 - x next to 1
+    old = oracle.set_powf_mode(oracle.POWF_LIBM)
+    libm = np.array([f(float(x), 1.0, float(t)) for x, t in zip(a, dt)], dtype=np.float32)
+    oracle.set_powf_mode(old)
+    assert np.max(np.abs(libm - got)) <= 2.4e-7 and np.any(libm != got)
+    small = (a < 1e-6) & keep
+    assert np.all(np.abs(libm[small] - got[small]) <= 1.2e-7)
+    for m_ in (oracle.POWF_EXP2_LOG2, oracle.POWF_LIBM):
+        o = oracle.set_powf_mode(m_)
+        assert f(1.0, 1.0, 0.5) == 1.0 and f(0.0, 1.0, 0.5) == 0.0 and f(0.3, 1.0, 1.0) == np.float32(0.3)
+        assert f(1.5, 1.0, 0.5) == 0.0                       # 1 - a < 0: NaN through log2 / pow, clamp01(NaN) = 0 (fminf / fmaxf, gdt.h:118-120)
+        oracle.set_powf_mode(o)
+
+
 def test_opacity_correction(oracle):
     f = oracle.load().ovr_oracle_opacity_correction
     assert f(0.3, 1.0, 1.0) == pytest.approx(0.3)                       # |base*dt - 1| < 1e-7 -> untouched
@@ -175,9 +204,20 @@ def test_rgba8_quantisation(oracle):
     assert list(out[0, 2]) == [0, 254, 1, 254]
 
 
+@pytest.fixture(params=["exp2_log2", "libm"])
+def powf_golden(request, oracle):
+    """both restatements of __powf (shaders_raymarching.cu:64-66,118-122) with their golden file: the default exp2f(y * log2f(x)) - CUDA's
+    definition of the intrinsic, round 5 - and libm's powf, whose file is the frames.npz rounds 1-4 committed (the switch reproduces the old
+    oracle bit for bit)"""
+    mode, name = (oracle.POWF_EXP2_LOG2, "frames.npz") if request.param == "exp2_log2" else (oracle.POWF_LIBM, "frames_powf_libm.npz")
+    old = oracle.set_powf_mode(mode)
+    yield np.load(os.path.join(HERE, "golden", name))
+    oracle.set_powf_mode(old)
+
+
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_golden_frames(ovr, oracle, name):
-    gold = np.load(os.path.join(HERE, "golden", "frames.npz"))
+def test_golden_frames(ovr, oracle, name, powf_golden):
+    gold = powf_golden
     case = make_case(ovr, oracle, **CASES[name])
     rgba, grad, cnt = oracle_scene(oracle, case).render(nthreads=2)
     assert np.array_equal(rgba, gold[name + "/rgba"])
@@ -186,8 +226,8 @@ def test_golden_frames(ovr, oracle, name):
     assert cnt.samples > 0 and np.isfinite(rgba).all()
 
 
-def test_golden_accumulation(ovr, oracle):
-    gold = np.load(os.path.join(HERE, "golden", "frames.npz"))
+def test_golden_accumulation(ovr, oracle, powf_golden):
+    gold = powf_golden
     case = make_case(ovr, oracle, n=12, tf="sparse", cam="oblique", size=(24, 16), shading=2, spp=2)
     rgba, _, cnt = oracle_scene(oracle, case).render(frames=3, accumulate=True, nthreads=2)
     assert np.array_equal(rgba, gold["accum3_spp2/rgba"])

@@ -84,7 +84,12 @@ class Spec:
 
     @staticmethod
     def correct(a, dt):
-        return a if abs(dt - 1.0) < 1e-7 else min(max(1.0 - (1.0 - a) ** dt, 0.0), 1.0)
+        # __powf(x, y) = exp2(y * log2(x)) (CUDA's definition of the intrinsic, shaders_raymarching.cu:64-66,118-122); in float64 the two forms agree to 1e-16
+        if abs(dt - 1.0) < 1e-7:
+            return a
+        x = 1.0 - a
+        pw = 2.0 ** (dt * math.log2(x)) if x > 0.0 else (0.0 if x == 0.0 else float("nan"))
+        return min(max(1.0 - pw, 0.0), 1.0) if pw == pw else 0.0
 
     def shadow(self, pos):
         o, d = self.to_object(pos), LIGHT / self.scale

@@ -10,7 +10,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import compare, hip_frame, hip_setup, make_case, oracle_scene
+from helpers import compare, hip_frame, hip_setup, make_case, oracle_scene, run_bench
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -227,12 +227,11 @@ def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` (no launcher) starts two ranks itself; rehearsed on one card over gloo"""
     env = dict(os.environ, OVR_BENCH_BACKEND="gloo", OVR_BENCH_ONE_GPU="1")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "4", "--warmup", "1"],
-                         env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+    c, d, _ = run_bench(["--gpus", "2", "--config", "tiny", "--steps", "4", "--warmup", "1"], env=env, timeout=600)
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"].startswith("gloo") and d["value"] > 0
+    # the stdout line: the contract's fields and a per-rank summary; the tables are in the detail file
+    assert c["n_gpus"] == 2 and c["rccl_ranks"] == 2 and c["steps"] == 4 and c["warmup"] == 1 and abs(c["value"] - d["value"]) <= 1e-4 * d["value"]
+    assert set(c["ranks"]["step_ms"]) == {"min", "mean", "max"} and c["detail"].endswith(".json") and "roofline" in c
     assert d["per_frame"]["rays"] == 256 * 256
     # round 3: the N > 1 line carries what a first multi-GPU run needs to explain itself
     rk = d["ranks"]
@@ -253,10 +252,7 @@ def test_one_rank_of_n_as_a_profilable_stand_in():
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     res = {}
     for extra in ([], ["--shard-of", "2"], ["--shard-of", "2", "--shard-rank", "1"]):
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                              "--no-views", "--no-skip-leg"] + extra, env=env, capture_output=True, text=True, timeout=600)
-        assert out.returncode == 0, out.stderr[-2000:]
-        res[tuple(extra)] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        _, res[tuple(extra)], _ = run_bench(["--config", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-views", "--no-skip-leg"] + extra, env=env, timeout=600)
     whole, r0, r1 = res[()], res[("--shard-of", "2")], res[("--shard-of", "2", "--shard-rank", "1")]
     assert "stand-in" in r0["config"]["parallelism"] and "stand-in" not in whole["config"]["parallelism"] and r0["n_gpus"] == 1
     assert r0["per_frame"]["samples"] + r1["per_frame"]["samples"] == whole["per_frame"]["samples"]
@@ -271,19 +267,13 @@ def test_two_ranks_on_one_card_at_the_8_gpu_configurations_shapes(config, n):
     edge, two gloo ranks on one card: the frame's work is the sum of the ranks' and the line carries the per-rank report"""
     env = dict(os.environ, OVR_BENCH_BACKEND="gloo", OVR_BENCH_ONE_GPU="1")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", config, "--n", str(n), "--steps", "3", "--warmup", "1"],
-                         env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    _, d, _ = run_bench(["--gpus", "2", "--config", config, "--n", str(n), "--steps", "3", "--warmup", "1"], env=env)
     w, h = (1920, 1080) if config == "c4" else (3840, 2160)
     assert d["n_gpus"] == 2 and d["per_frame"]["rays"] == w * h and d["dtype"] == ("u16" if config == "c4" else "f32")
     assert len(d["ranks"]["per_rank"]["kernel_ms"]) == 2 and d["ranks"]["work_imbalance_max_over_mean"] < 1.5
     if config == "c5":
         # progressive accumulation gathered only when it is mapped (SURVEY 8e on C5): same frames, one gather at the end of the timed region
-        out2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", config, "--n", str(n), "--steps", "3", "--warmup", "1",
-                               "--gather-every", "64"], env=env, capture_output=True, text=True, timeout=900)
-        assert out2.returncode == 0, out2.stderr[-2000:]
-        d2 = json.loads([l for l in out2.stdout.splitlines() if l.startswith("{")][-1])
+        _, d2, _ = run_bench(["--gpus", "2", "--config", config, "--n", str(n), "--steps", "3", "--warmup", "1", "--gather-every", "64"], env=env)
         assert d2["gather"].startswith("every 64th") and d["gather"] == "every frame" and d2["per_frame"] == d["per_frame"]
 
 
