@@ -536,6 +536,9 @@ def worker(args, world):
     ren.init(scene, ovr.Camera(*cam))   # ovr_hip_set_volume (re-layout into bricks; on every device of a group) + the first commit
     volume_upload_ms = (time.perf_counter() - t_up) * 1e3
     resident_after_upload = int(ren.volume_info().resident_bytes)
+    # (round 5) what ovr_hip_set_volume itself spent where: allocation (a FRESH hipMalloc: 30-60 ms per GiB - C4's 21.5 GB in a new process),
+    # copies into the device (none for this device array), kernels (re-bricking, macrocell ranges, data range)
+    upload_split = {k: round(v, 3) for k, v in ren.upload_times().items()}
 
     def set_cam():
         if args.fovy == 60.0:
@@ -943,7 +946,7 @@ def worker(args, world):
                          "compulsory_floor_ms": floor_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
                          "compulsory_floor_bytes": floor_bytes,
                          # (round 4) ovr_hip_set_volume uploads the general layout only; replicas are built in the background when a frame asks for one
-                         "volume_upload_ms": volume_upload_ms, "volume_resident_bytes_after_upload": resident_after_upload,
+                         "volume_upload_ms": volume_upload_ms, "upload_ms": upload_split, "volume_resident_bytes_after_upload": resident_after_upload,
                          "volume_resident_bytes": int(ren.volume_info().resident_bytes), "volume_layout_read_bytes": read_bytes,
                          "phase_ms_rank0": {"march": ph[0], "shade": ph[1], "composite": ph[2]},
                          "pool_chunks": int(last_stats.pool_chunks),
@@ -958,6 +961,8 @@ def worker(args, world):
                                             f"16x16 over {gn} member(s), gathered on device {group_devices[0]}")
             out["device_group"] = {"devices": group_devices, "distinct_devices": len(set(group_devices)), "gather": ["none", "peer copies", "RCCL send/recv (ncclCommInitAll)"][gkind],
                                    "gather_tail_ms_last_frame": gms,
+                                   "host_us_last_frame": dict(zip(("enqueue", "ship", "finish", "scatter"), (round(v, 1) for v in ren.group_host_times()))),
+                                   "host_us_per_frame": round(sum(ren.group_host_times()[:2]), 1),
                                    "per_member": {"march_ms": [m.march_ms for m in members], "shade_ms": [m.shade_ms for m in members], "composite_ms": [m.composite_ms for m in members],
                                                   "kernel_ms": [m.kernel_ms for m in members], "samples": [int(m.samples) for m in members],
                                                   "layout": [m.layout for m in members], "pipeline": [m.pipeline for m in members]},

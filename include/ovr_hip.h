@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OVR_HIP_ABI_VERSION 9
+#define OVR_HIP_ABI_VERSION 10
 
 /* error codes */
 #define OVR_HIP_OK 0
@@ -115,6 +115,10 @@ int ovr_hip_group_info(const ovr_hip_renderer* r, int32_t* n_devices, int32_t* g
 /* diagnostic: the RCCL entry points a device group uses (ncclCommInitAll, ncclGroupStart / End, ncclSend, ncclRecv on a stream), exercised on
  * ONE device - a communicator of one rank sends 256 KiB to itself.  0 = they work; OVR_HIP_ESTATE = librccl.so is not loadable (groups use peer copies) */
 int ovr_hip_rccl_selftest(int device_id);
+/* ABI v10: host time of the last frame's steps on the calling (leader's) thread, microseconds: [0] launching every member's frame (each follower on
+ * its own host thread, the leader on this one), [1] packing + shipping the followers' tiles, [2] every member's frame to its end, [3] waiting for the
+ * shipments + the scatter on the leader.  Zeros for an ordinary renderer.  Round 4 drove all members from one thread: [0] was 225 us at 8 members. */
+int ovr_hip_group_host_times(const ovr_hip_renderer* r, double out_us[4]);
 /* the counters of ONE member's last frame (member 0 = the leader's own tiles) */
 int ovr_hip_get_member_stats(const ovr_hip_renderer* r, int32_t member, ovr_hip_stats* out);
 
@@ -127,6 +131,11 @@ int ovr_hip_set_stream(ovr_hip_renderer* r, void* hip_stream);
  * x fastest.  The volume is re-laid out into HBM-resident bricks; `data` is not referenced after the call returns. */
 int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int value_type, const int32_t dims[3],
                        const float grid_origin[3], const float grid_spacing[3]);
+/* ABI v10: where the last ovr_hip_set_volume spent its time, milliseconds: [0] the whole call (a device group: over all members, which upload side by
+ * side), [1] allocation (a FRESH hipMalloc costs 30-60 ms per GiB on this platform - the driver maps and clears the pages; C4's 21.5 GB layout: 0.5-1.2 s
+ * in a new process, 0.1 ms when the runtime still holds a freed block of that size), [2] copies into the device (host input: through a 1 GiB staging buffer;
+ * a device array on another GPU: peer copies), [3] kernels (re-bricking, macrocell ranges, data range; layouts mode 2: the replicas) */
+int ovr_hip_get_upload_times(const ovr_hip_renderer* r, double out_ms[4]);
 int ovr_hip_set_grid_convention(ovr_hip_renderer* r, int convention);
 /* diagnostic, pure host arithmetic (no device needed): the addressing mode the kernels would take for a volume of these dimensions and
  * type in the given layout (0 general ... 3 quad) with a transfer function of n_colors / n_alphas entries: 0 = 32-bit byte offsets,
@@ -219,8 +228,10 @@ int ovr_hip_commit(ovr_hip_renderer* r);
  * frame is complete on the device; adds the elapsed milliseconds to the value ovr_hip_render_time_ms() returns. */
 int ovr_hip_render(ovr_hip_renderer* r);
 /* non-blocking variant: enqueues the frame on the renderer's stream and returns (for hipEvent timing / graphs).  (Round 4: the first frame after
- * a camera / volume / size change reads 8 bytes back from the device before it launches - how many 8x8-pixel blocks have a ray that meets the
- * volume's box; the others get no workgroup, their pixels are cleared - a stream synchronisation of ~20 us.) */
+ * a camera / volume / size / spp / jitter change reads 8 bytes back from the device before it launches - how many 8x8-pixel blocks have a ray that
+ * meets the volume's box; the others get no workgroup, their pixels are cleared - a stream synchronisation of ~20 us.  Such a frame cannot be
+ * captured into a hipGraph: on a caller's stream under capture it fails with OVR_HIP_ESTATE - render it once outside the capture; the frames of an
+ * unchanged configuration launch without a host wait and capture.) */
 int ovr_hip_render_async(ovr_hip_renderer* r);
 /* waits for the frame enqueued by render_async and for everything else enqueued on the renderer's stream
  * (ovr_hip_pack_tiles / ovr_hip_unpack_tiles launches included) */

@@ -21,7 +21,7 @@ PIPELINE_AUTO, PIPELINE_IN_PLACE, PIPELINE_POOLED = 0, 1, 2
 JITTER_TEA, JITTER_BLUE_NOISE = 0, 1
 LAYOUT_AUTO, LAYOUT_GENERAL, LAYOUT_THIN, LAYOUT_THIN_T, LAYOUT_QUAD = -1, 0, 1, 2, 3
 # the ABI these ctypes structures describe: load() refuses a library of another version (ovr_hip_get_stats would write past them)
-EXPECTED_ABI = 9
+EXPECTED_ABI = 10
 
 
 class Stats(C.Structure):
@@ -74,6 +74,8 @@ SYMBOLS = {
     "ovr_hip_destroy": (None, [_H]),
     "ovr_hip_create_group": (C.c_int, [C.POINTER(_H), C.POINTER(C.c_int32), C.c_int32]),
     "ovr_hip_group_info": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "ovr_hip_group_host_times": (C.c_int, [_H, C.POINTER(C.c_double)]),
+    "ovr_hip_get_upload_times": (C.c_int, [_H, C.POINTER(C.c_double)]),
     "ovr_hip_get_member_stats": (C.c_int, [_H, C.c_int32, C.POINTER(Stats)]),
     "ovr_hip_rccl_selftest": (C.c_int, [C.c_int]),
     "ovr_hip_set_stream": (C.c_int, [_H, C.c_void_p]),

@@ -20,6 +20,8 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -97,6 +99,8 @@ struct Size2 { int w = 0, h = 0; };
 } // namespace
 
 // the frame words on the device (ovr_hip_renderer::d_counters): 8 counters, the pool's control words from byte 128, the reduction's ticket word behind them
+struct GroupWorker; // one host thread per follower of a device group (below)
+
 constexpr size_t kFrameWordsBytes = 128 + (size_t)ovrhip::kPoolCtrlWords * sizeof(unsigned int) + 128;
 
 struct ovr_hip_renderer {
@@ -293,6 +297,18 @@ struct ovr_hip_renderer {
   void* rccl_comm = nullptr;              // every member of an RCCL group: its communicator
   ovr_hip_stats own_stats{};              // leader: its own frame's counters (stats holds the group's sums)
   double group_gather_ms = 0.0;           // leader: host time of the last frame's gather tail (after the slowest member's frame: wait for the shipments + scatter)
+  // Round 5: every follower has a host thread of its own (device set once, persistent): the leader posts commit / render_async / ship / finish to all of
+  // them and waits on their counters, so the members' frames are enqueued side by side instead of one after the other (one thread driving 8 members
+  // spent 225 us per frame on it, beside 485 us of device time per member).
+  double upload_ms[4] = { 0, 0, 0, 0 };   // the last ovr_hip_set_volume of THIS renderer: total, allocation, copies into the device, kernels (ovr_hip_get_upload_times)
+  double group_upload_ms = 0.0;           // leader: wall time of the last upload over all members
+  GroupWorker* worker = nullptr;          // follower only
+  hipEvent_t ev_gathered = nullptr;       // leader, RCCL: behind the ONE grouped receive of a frame on its comm_stream
+  // A member whose commit or volume upload failed leaves the group in mixed state: the group refuses to render until a commit has
+  // succeeded on every member AND they agree on what was committed / until a volume upload has succeeded on all of them
+  bool group_broken = false;
+  std::string group_broken_why;
+  double group_host_us[4] = { 0, 0, 0, 0 }; // leader: host time of the last frame's steps (enqueue, ship, finish, scatter), microseconds
 
   hipStream_t stream() const { return use_user_stream ? user_stream : own_stream[cur]; }
 };
@@ -959,6 +975,13 @@ int enqueue_frame(ovr_hip_renderer* r)
       r->n_work = r->n_sched;
       r->empty_pixels = 0;
       if (exact && r->n_sched > 0) { // how many entries need a workgroup: two words from the device, once per camera / volume / size change
+        // (a stream under graph capture cannot be waited for: the frame after a change is rendered outside the capture - ADVICE r4; frames of an
+        // unchanged configuration launch without any host wait and capture as before.  In a device group every member waits on its own thread.)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (r->use_user_stream && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+          return fail(OVR_HIP_ESTATE, "[hip] ovr_hip_render_async: the first frame after a camera / volume / size / spp / jitter change reads 8 bytes back from the device and "
+                                      "cannot be captured into a graph - render it once outside the capture");
+        (void)hipGetLastError();
         HIP_TRY(hipStreamSynchronize(st));
         r->n_work = std::min(r->d_sched_info[0], r->n_sched);
         r->empty_pixels = r->d_sched_info[1];
@@ -1304,44 +1327,139 @@ int group_buffers(ovr_hip_renderer* L)
   return 0;
 }
 
-// follower m: pack the tiles of the frame in flight (or just finished) and send them to the leader; the shipment ends in m->ev_shipped
-int group_ship(ovr_hip_renderer* L, ovr_hip_renderer* m)
+// ---- the followers' host threads --------------------------------------------------------------------------------------------------
+// One per follower, created with the group, pinned to the member's device once (hipSetDevice is per thread).  The leader's thread posts a
+// command to every worker and waits for all of them: the members' commits, frame launches, packs and frame ends run side by side.  A worker
+// spins on its mailbox for a short while after a command (a render loop posts the next one within microseconds) and then sleeps on a
+// condition variable; results travel back in the mailbox (g_last_error is thread-local).
+enum { GW_NONE = 0, GW_COMMIT, GW_RENDER, GW_SHIP, GW_FINISH, GW_SWAP, GW_CALL, GW_QUIT };
+} // namespace
+struct GroupWorker {
+  ovr_hip_renderer* m = nullptr;
+  std::thread th;
+  std::mutex mx;
+  std::condition_variable cv;
+  std::atomic<uint64_t> posted{ 0 }, done{ 0 };
+  std::atomic<bool> asleep{ false };
+  int cmd = GW_NONE;          // written by the leader before `posted` advances, read by the worker after it has seen it
+  std::function<int()> fn;    // GW_CALL
+  int rc = 0;                 // the command's result ...
+  std::string err;            // ... and its message
+};
+namespace {
+int group_pack(ovr_hip_renderer* L, ovr_hip_renderer* m);
+int finish_frame_one(ovr_hip_renderer* r);
+
+inline void cpu_relax() { __builtin_ia32_pause(); }
+
+void group_worker_main(GroupWorker* w)
 {
-  const int n = (int)L->members.size();
+  ovr_hip_renderer* m = w->m;
+  (void)hipSetDevice(m->device);
+  uint64_t seen = 0;
+  static const int spin_us = getenv("OVR_HIP_WORKER_SPIN_US") ? atoi(getenv("OVR_HIP_WORKER_SPIN_US")) : 200;
+  for (;;) {
+    // wait for the next command: spin first (the render loop's next post is microseconds away), then sleep
+    const auto t0 = std::chrono::steady_clock::now();
+    int polls = 0;
+    while (w->posted.load(std::memory_order_acquire) == seen) {
+      cpu_relax();
+      if ((++polls & 255) == 0 && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_us) {
+        std::unique_lock<std::mutex> lk(w->mx);
+        w->asleep.store(true);
+        w->cv.wait(lk, [&] { return w->posted.load() != seen; });
+        w->asleep.store(false);
+      }
+    }
+    seen = w->posted.load(std::memory_order_acquire);
+    int rc = 0;
+    g_last_error.clear();
+    switch (w->cmd) {
+    case GW_COMMIT: rc = ovr_hip_commit(m); break;
+    case GW_RENDER: rc = ovr_hip_render_async(m); break;
+    case GW_SHIP: rc = group_pack(m->leader, m); break;
+    case GW_FINISH: rc = finish_frame_one(m); break;
+    case GW_SWAP: rc = ovr_hip_swap(m); break;
+    case GW_CALL: rc = w->fn ? w->fn() : 0; break;
+    case GW_QUIT: w->done.store(seen, std::memory_order_release); return;
+    default: break;
+    }
+    w->rc = rc;
+    if (rc) w->err = g_last_error;
+    w->done.store(seen, std::memory_order_release);
+  }
+}
+
+void gw_post(GroupWorker* w, int cmd)
+{
+  w->cmd = cmd;
+  w->posted.fetch_add(1); // (seq_cst: ordered against the worker's `asleep` store - either it sees the post or this thread sees it asleep)
+  if (w->asleep.load()) {
+    std::lock_guard<std::mutex> lk(w->mx);
+    w->cv.notify_one();
+  }
+}
+int gw_wait(GroupWorker* w)
+{
+  const uint64_t want = w->posted.load();
+  int polls = 0;
+  while (w->done.load(std::memory_order_acquire) != want) {
+    cpu_relax();
+    if ((++polls & 4095) == 0) std::this_thread::yield();
+  }
+  if (w->rc) g_last_error = w->err;
+  return w->rc;
+}
+// the same command on every follower, the leader's own share (if any) meanwhile on this thread; the first error wins, every worker is waited for
+template <typename Own> int group_run(ovr_hip_renderer* L, int cmd, Own own)
+{
+  const size_t n = L->members.size();
+  for (size_t i = 1; i < n; ++i) gw_post(L->members[i]->worker, cmd);
+  int e = own();
+  std::string msg = e ? g_last_error : std::string();
+  for (size_t i = 1; i < n; ++i) {
+    const int ei = gw_wait(L->members[i]->worker);
+    if (ei && !e) { e = ei; msg = g_last_error; }
+  }
+  if (e) g_last_error = msg;
+  return e;
+}
+int group_run(ovr_hip_renderer* L, int cmd) { return group_run(L, cmd, [] { return 0; }); }
+// an arbitrary call per follower (volume upload, noise tile: rare, may allocate)
+int group_call(ovr_hip_renderer* L, const std::function<int(ovr_hip_renderer*)>& f)
+{
+  const size_t n = L->members.size();
+  for (size_t i = 1; i < n; ++i) {
+    ovr_hip_renderer* m = L->members[i];
+    m->worker->fn = [m, &f] { return f(m); };
+  }
+  return group_run(L, GW_CALL);
+}
+void group_stop_workers(ovr_hip_renderer* L)
+{
+  for (size_t i = 1; i < L->members.size(); ++i) {
+    GroupWorker* w = L->members[i]->worker;
+    if (!w) continue;
+    if (w->th.joinable()) { gw_post(w, GW_QUIT); w->th.join(); }
+    delete w;
+    L->members[i]->worker = nullptr;
+  }
+}
+
+// follower m (on its own thread): pack the tiles of the frame in flight (or just finished) behind it; with peer copies the payload leaves at once
+// on m's comm_stream (ends in m->ev_shipped), with RCCL it waits in m->d_payload for the leader's grouped send / recv (group_rccl)
+int group_pack(ovr_hip_renderer* L, ovr_hip_renderer* m)
+{
   const int W = L->fbsize.current.w, H = L->fbsize.current.h;
   const ShardP& s = m->shard.current;
-  HIP_TRY(hipSetDevice(m->device));
-  if (m->payload_floats[0] == 0) { HIP_TRY(hipEventRecord(m->ev_shipped, m->comm_stream)); m->shipped_by_rccl = false; return 0; }
+  m->shipped_by_rccl = false;
+  if (m->payload_floats[0] == 0) { HIP_TRY(hipEventRecord(m->ev_shipped, m->comm_stream)); return 0; }
   // ovr_hip_pack_tiles resolves a frame whose request pool is not yet known to be roomy before it packs (a pool overflow renders the frame again)
   if (int e = ovr_hip_pack_tiles(m, m->d_payload[0], m->payload_floats[0] * sizeof(float))) return e;
   if (L->group_grad) HIP_TRY(launch_pack_tiles(m->d_grad[m->cur], m->d_payload[1], W, H, s.tw, s.th, s.rank, s.world, m->stream(), 3));
   HIP_TRY(hipEventRecord(m->ev_packed, m->stream()));
   HIP_TRY(hipStreamWaitEvent(m->comm_stream, m->ev_packed, 0));
-  if (L->gather_kind == 2) {
-    const RcclApi& N = rccl_api();
-    HIP_TRY(hipSetDevice(L->device));
-    HIP_TRY(hipStreamWaitEvent(L->comm_stream, m->ev_packed, 0)); // (the matching recv must not start before the payload exists - harmless, but keeps the pair aligned)
-    int rc = N.GroupStart();
-    for (int c = 0; c < 2 && rc == 0; ++c) {
-      if (c == 1 && !L->group_grad) break;
-      (void)hipSetDevice(m->device);
-      rc = N.Send(m->d_payload[c], m->payload_floats[c], kNcclFloat, 0, m->rccl_comm, m->comm_stream);
-      (void)hipSetDevice(L->device);
-      if (rc == 0) rc = N.Recv(L->d_gather[c] + (size_t)m->group_rank * L->group_stride[c], m->payload_floats[c], kNcclFloat, m->group_rank, L->rccl_comm, L->comm_stream);
-    }
-    const int rc2 = N.GroupEnd();
-    if (rc == 0 && rc2 == 0) {
-      HIP_TRY(hipSetDevice(L->device));
-      HIP_TRY(hipEventRecord(m->ev_received, L->comm_stream)); // the receive side: ordered after every earlier member's receive on that stream
-      m->shipped_by_rccl = true;
-      (void)n;
-      return 0;
-    }
-    // RCCL refused the pair: this group goes on with peer copies (same bytes, same destination), and says so once
-    fprintf(stderr, "[hip] RCCL send / recv of a group member's tiles failed (%s): falling back to peer copies\n", N.GetErrorString ? N.GetErrorString(rc != 0 ? rc : rc2) : "?");
-    L->gather_kind = 1;
-    HIP_TRY(hipSetDevice(m->device));
-  }
+  if (L->gather_kind == 2) return 0;
   for (int c = 0; c < 2; ++c) {
     if (c == 1 && !L->group_grad) break;
     float* dst = L->d_gather[c] + (size_t)m->group_rank * L->group_stride[c];
@@ -1349,7 +1467,60 @@ int group_ship(ovr_hip_renderer* L, ovr_hip_renderer* m)
     else HIP_TRY(hipMemcpyPeerAsync(dst, L->device, m->d_payload[c], m->device, m->payload_floats[c] * sizeof(float), m->comm_stream));
   }
   HIP_TRY(hipEventRecord(m->ev_shipped, m->comm_stream));
-  m->shipped_by_rccl = false;
+  return 0;
+}
+
+// leader thread, RCCL: the payloads of the listed followers travel inside ONE ncclGroupStart / End - n - 1 sends on the followers' communicators and
+// comm streams, n - 1 receives on the leader's - and the leader's comm_stream records ONE event behind them (round 4 issued a group per follower: 7
+// launch pairs a frame at 8 members, each receive queued behind the slowest member packed before it).  false = RCCL refused: the caller falls back.
+bool group_rccl(ovr_hip_renderer* L, const std::vector<ovr_hip_renderer*>& who)
+{
+  const RcclApi& N = rccl_api();
+  if (hipSetDevice(L->device) != hipSuccess) return false;
+  // the receives start once every listed payload exists (a receive kernel spinning beside the leader's own frame would only take CUs from it)
+  for (ovr_hip_renderer* m : who)
+    if (m->payload_floats[0] > 0 && hipStreamWaitEvent(L->comm_stream, m->ev_packed, 0) != hipSuccess) return false;
+  int rc = N.GroupStart();
+  for (size_t k = 0; k < who.size() && rc == 0; ++k) {
+    ovr_hip_renderer* m = who[k];
+    if (m->payload_floats[0] == 0) continue;
+    for (int c = 0; c < 2 && rc == 0; ++c) {
+      if (c == 1 && !L->group_grad) break;
+      (void)hipSetDevice(m->device);
+      rc = N.Send(m->d_payload[c], m->payload_floats[c], kNcclFloat, 0, m->rccl_comm, m->comm_stream);
+      (void)hipSetDevice(L->device);
+      if (rc == 0) rc = N.Recv(L->d_gather[c] + (size_t)m->group_rank * L->group_stride[c], m->payload_floats[c], kNcclFloat, m->group_rank, L->rccl_comm, L->comm_stream);
+    }
+  }
+  const int rc2 = N.GroupEnd();
+  (void)hipSetDevice(L->device);
+  if (rc != 0 || rc2 != 0) {
+    fprintf(stderr, "[hip] RCCL send / recv of a device group's tiles failed (%s): the group goes on with peer copies\n", N.GetErrorString ? N.GetErrorString(rc != 0 ? rc : rc2) : "?");
+    return false;
+  }
+  if (hipEventRecord(L->ev_gathered, L->comm_stream) != hipSuccess) return false;
+  for (ovr_hip_renderer* m : who) m->shipped_by_rccl = true;
+  return true;
+}
+
+// packs (workers, side by side) and ships the tiles of the listed followers; `all` = every follower (the common case: one post per worker)
+int group_ship(ovr_hip_renderer* L, const std::vector<ovr_hip_renderer*>& who, bool all)
+{
+  auto pack = [&]() -> int {
+    if (all) return group_run(L, GW_SHIP);
+    for (ovr_hip_renderer* m : who) gw_post(m->worker, GW_SHIP);
+    int e = 0;
+    std::string msg;
+    for (ovr_hip_renderer* m : who) { const int ei = gw_wait(m->worker); if (ei && !e) { e = ei; msg = g_last_error; } }
+    if (e) g_last_error = msg;
+    return e;
+  };
+  if (int e = pack()) return e;
+  if (L->gather_kind == 2 && !group_rccl(L, who)) {
+    L->gather_kind = 1; // same bytes, same destination, by peer copies from here on
+    (void)hipGetLastError();
+    if (int e = pack()) return e;
+  }
   return 0;
 }
 
@@ -1361,31 +1532,37 @@ int group_finish(ovr_hip_renderer* L)
   if (!any) return 0;
   const int W = L->fbsize.current.w, H = L->fbsize.current.h;
   if (int e = group_buffers(L)) return e;
-  // 1. the followers pack behind their frames and ship on their comm streams while everything still renders
-  for (int i = 1; i < n; ++i)
-    if (int e = group_ship(L, L->members[i])) { (void)hipSetDevice(L->device); return e; }
-  // 2. every frame to its end (a follower whose request pool overflowed renders again: its early payload is stale)
-  HIP_TRY(hipSetDevice(L->device));
-  if (int e = finish_frame_one(L)) return e;
-  for (int i = 1; i < n; ++i) {
-    ovr_hip_renderer* m = L->members[i];
-    HIP_TRY(hipSetDevice(m->device));
-    if (int e = finish_frame_one(m)) { (void)hipSetDevice(L->device); return e; }
-    if (m->stats.stale_tiles)
-      if (int e = group_ship(L, m)) { (void)hipSetDevice(L->device); return e; }
-  }
   const auto t0 = std::chrono::high_resolution_clock::now();
+  // 1. the followers pack behind their frames and ship on their comm streams while everything still renders
+  std::vector<ovr_hip_renderer*> followers(L->members.begin() + 1, L->members.end());
+  if (int e = group_ship(L, followers, true)) return e;
+  const auto t1 = std::chrono::high_resolution_clock::now();
+  // 2. every frame to its end (a follower whose request pool overflowed renders again: its early payload is stale)
+  if (int e = group_run(L, GW_FINISH, [&] { return finish_frame_one(L); })) return e;
+  std::vector<ovr_hip_renderer*> stale;
+  for (ovr_hip_renderer* m : followers)
+    if (m->stats.stale_tiles) stale.push_back(m);
+  if (!stale.empty())
+    if (int e = group_ship(L, stale, false)) return e;
+  const auto t2 = std::chrono::high_resolution_clock::now();
   // 3. the leader scatters the payloads into the framebuffer set the frame rendered into
-  HIP_TRY(hipSetDevice(L->device));
   hipStream_t st = L->stream();
-  for (int i = 1; i < n; ++i) HIP_TRY(hipStreamWaitEvent(st, L->members[i]->shipped_by_rccl ? L->members[i]->ev_received : L->members[i]->ev_shipped, 0));
+  bool waited_rccl = false;
+  for (ovr_hip_renderer* m : followers) {
+    if (!m->shipped_by_rccl) HIP_TRY(hipStreamWaitEvent(st, m->ev_shipped, 0));
+    else if (!waited_rccl) { HIP_TRY(hipStreamWaitEvent(st, L->ev_gathered, 0)); waited_rccl = true; } // (recorded behind the LAST grouped receive: covers a re-shipment too)
+  }
   const ShardP& s = L->shard.current;
   if (W > 0 && H > 0 && L->d_gather[0]) {
     HIP_TRY(launch_unpack_tiles(L->d_gather[0], L->d_rgba[L->frame_set], W, H, s.tw, s.th, -1, n, L->group_stride[0], st, 4, 0));
     if (L->group_grad && L->d_gather[1]) HIP_TRY(launch_unpack_tiles(L->d_gather[1], L->d_grad[L->frame_set], W, H, s.tw, s.th, -1, n, L->group_stride[1], st, 3, 0));
   }
   HIP_TRY(hipStreamSynchronize(st));
-  L->group_gather_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+  const auto t3 = std::chrono::high_resolution_clock::now();
+  L->group_gather_ms = std::chrono::duration<double, std::milli>(t3 - t2).count();
+  L->group_host_us[1] = std::chrono::duration<double, std::micro>(t1 - t0).count();
+  L->group_host_us[2] = std::chrono::duration<double, std::micro>(t2 - t1).count();
+  L->group_host_us[3] = std::chrono::duration<double, std::micro>(t3 - t2).count();
   // 4. the frame's counters: sums over the members, times of the slowest
   L->own_stats = L->stats;
   for (int i = 1; i < n; ++i) {
@@ -1513,6 +1690,7 @@ int ovr_hip_create_group(ovr_hip_renderer** out, const int32_t* device_ids, int3
       (void)hipGetLastError(); // hipErrorPeerAccessAlreadyEnabled is not an error
     }
     HIP_TRY(hipSetDevice(L->device));
+    HIP_TRY(hipEventCreateWithFlags(&L->ev_gathered, hipEventDisableTiming));
     if (const char* g = getenv("OVR_HIP_MAP_GRAD")) L->group_grad = g[0] != '0';
     const char* want = getenv("OVR_HIP_GATHER");
     const bool force_rccl = want && std::string(want) == "rccl", force_copy = want && std::string(want) == "copy";
@@ -1530,6 +1708,34 @@ int ovr_hip_create_group(ovr_hip_renderer** out, const int32_t* device_ids, int3
       HIP_TRY(hipSetDevice(L->device));
     }
     else if (force_rccl) return fail(OVR_HIP_EDEVICE, distinct ? "[hip] OVR_HIP_GATHER=rccl but librccl.so could not be loaded" : "[hip] OVR_HIP_GATHER=rccl needs distinct devices (RCCL refuses a device listed twice)");
+    // one host thread per follower (round 5): device set once, persistent - commits, frame launches, packs and frame ends of the members run side by side
+    for (int i = 1; i < n_devices; ++i) {
+      GroupWorker* w = new GroupWorker();
+      w->m = L->members[i];
+      L->members[i]->worker = w;
+      try { w->th = std::thread(group_worker_main, w); }
+      catch (const std::exception& ex) { return fail(OVR_HIP_EDEVICE, std::string("[hip] ovr_hip_create_group: no host thread for a member: ") + ex.what()); }
+    }
+    // the first multi-GPU run explains itself: which way the tiles travel and why, and what the platform says about every pair
+    if (!(getenv("OVR_HIP_QUIET") && atoi(getenv("OVR_HIP_QUIET")) != 0)) {
+      std::string why = L->gather_kind == 2 ? "RCCL send / recv (ncclCommInitAll over the listed devices; one ncclGroupStart / End per frame)"
+                        : force_copy       ? "peer copies (OVR_HIP_GATHER=copy)"
+                        : !distinct        ? "peer copies (a device is listed more than once: RCCL refuses that)"
+                        : !rccl_api().ok   ? "peer copies (librccl.so could not be loaded)"
+                                           : "peer copies (ncclCommInitAll failed)";
+      std::string devs, peers;
+      for (int i = 0; i < n_devices; ++i) devs += (i ? "," : "") + std::to_string(device_ids[i]);
+      for (int i = 0; i < n_devices; ++i) {
+        peers += i ? " | " : "";
+        for (int j = 0; j < n_devices; ++j) {
+          int can = device_ids[i] == device_ids[j] ? 1 : 0;
+          if (!can && hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[j]) != hipSuccess) { (void)hipGetLastError(); can = -1; }
+          peers += can < 0 ? "?" : can ? "1" : "0";
+        }
+      }
+      fprintf(stderr, "[hip] device group: devices [%s], image tiles %dx%d, gather to device %d by %s; gradient layer %s; hipDeviceCanAccessPeer rows (member -> member): %s\n",
+              devs.c_str(), tw, th, device_ids[0], why.c_str(), L->group_grad ? "travels too" : "stays (OVR_HIP_MAP_GRAD=0)", peers.c_str());
+    }
     return 0;
   };
   if (int e = build()) { const std::string msg = g_last_error; ovr_hip_destroy(L); g_last_error = msg; return e; }
@@ -1589,6 +1795,13 @@ int ovr_hip_group_info(const ovr_hip_renderer* r, int32_t* n_devices, int32_t* g
   return 0;
 }
 
+int ovr_hip_group_host_times(const ovr_hip_renderer* r, double out_us[4])
+{
+  if (!r || !out_us) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_group_host_times: null argument");
+  for (int i = 0; i < 4; ++i) out_us[i] = r->members.size() > 1 ? r->group_host_us[i] : 0.0;
+  return 0;
+}
+
 int ovr_hip_get_member_stats(const ovr_hip_renderer* r, int32_t member, ovr_hip_stats* out)
 {
   if (!r || !out) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_get_member_stats: null argument");
@@ -1602,6 +1815,7 @@ int ovr_hip_get_member_stats(const ovr_hip_renderer* r, int32_t member, ovr_hip_
 void ovr_hip_destroy(ovr_hip_renderer* r)
 {
   if (!r) return;
+  if (r->members.size() > 1) group_stop_workers(r);
   for (size_t i = 1; i < r->members.size(); ++i) ovr_hip_destroy(r->members[i]); // a group leader takes its followers with it
   r->members.clear();
   join_builders(r);
@@ -1616,6 +1830,7 @@ void ovr_hip_destroy(ovr_hip_renderer* r)
   if (r->ev_packed) (void)hipEventDestroy(r->ev_packed);
   if (r->ev_shipped) (void)hipEventDestroy(r->ev_shipped);
   if (r->ev_received) (void)hipEventDestroy(r->ev_received);
+  if (r->ev_gathered) (void)hipEventDestroy(r->ev_gathered);
   (void)free_framebuffers(r);
   for (int k = 0; k < kLayouts; ++k) {
     if (r->d_replica[k]) (void)hipFree(r->d_replica[k]);
@@ -1656,21 +1871,32 @@ int ovr_hip_set_stream(ovr_hip_renderer* r, void* s)
   if (r->members.size() > 1 && s) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_stream: a device group renders on one stream per device");
   if (int e = finish_frame(r)) return e;
   HIP_TRY(hipStreamSynchronize(r->stream())); // table copies and the like enqueued on the stream that is being left
+  // ... and what a reset left on the OTHER set's own stream (its memsets: enqueue_frame; a table copy recorded there): the caller's stream is not
+  // ordered behind either of them
+  for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamSynchronize(r->own_stream[i]));
   r->user_stream = (hipStream_t)s;
   r->use_user_stream = (s != nullptr);
   return 0;
 }
 
-int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int value_type, const int32_t dims[3],
-                       const float grid_origin[3], const float grid_spacing[3])
+} // extern "C"
+namespace {
+double ms_since(std::chrono::high_resolution_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count(); }
+
+// one renderer's volume upload (a group member's or a single renderer's).  r->upload_ms = { total, allocation, host-to-device / peer copies, kernels }
+int set_volume_one(ovr_hip_renderer* r, const void* data, int mem_kind, int value_type, const int32_t dims[3],
+                   const float grid_origin[3], const float grid_spacing[3])
 {
+  const auto t_call = std::chrono::high_resolution_clock::now();
+  double t_alloc = 0.0, t_copy = 0.0, t_kern = 0.0;
   if (!r || !data || !dims || !grid_origin || !grid_spacing) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_volume: null argument");
+  for (double& v : r->upload_ms) v = 0.0;
   if (dims[0] < 1 || dims[1] < 1 || dims[2] < 1) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_volume: dims must be positive");
   const int vt = device_voxel_type(value_type);
   if (vt < 0) return fail(OVR_HIP_EINVAL, "[Optix7] unexpected volume type ..."); // array.cpp:348, same text
   if (mem_kind != OVR_HIP_MEM_HOST && mem_kind != OVR_HIP_MEM_DEVICE) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_volume: bad mem_kind");
   if (int e = set_device(r)) return e;
-  if (int e = finish_frame(r)) return e;
+  if (int e = finish_frame_one(r)) return e;
   HIP_TRY(hipDeviceSynchronize());
 
   hipStream_t st_ = r->own_stream[0];
@@ -1684,6 +1910,7 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
   if (!layout_offsets_fit(vd))
     return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_volume: one z layer of the volume exceeds 2^32 stored voxels (x * y too large for the 32-bit in-plane offsets)");
 
+  auto t_seg = std::chrono::high_resolution_clock::now();
   join_builders(r);                               // a builder thread may still be enqueueing a replica of the OLD volume
   HIP_TRY(hipStreamSynchronize(r->build_stream)); // ... which reads the old general layout
   for (int k = 0; k < kLayouts; ++k) {
@@ -1737,6 +1964,10 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
     }
   }
   HIP_TRY(hipMalloc(&r->d_axis[0], axis_table_bytes(r->vd_replica[0]))); // the layout's per-axis offset tables, staged into LDS by every march / shade workgroup
+  // (allocation: a FRESH hipMalloc costs 30-60 ms per GiB on this platform - the driver maps and clears the pages - and microseconds when the runtime
+  // still holds a freed block of that size: C4's 21.5 GB layout is 0.5-1.2 s in a new process, 0.1 ms on the next upload; tools/malloc_time.cpp)
+  t_alloc += ms_since(t_seg);
+  t_seg = std::chrono::high_resolution_clock::now();
   HIP_TRY(launch_axis_tables(r->vd_replica[0], r->d_axis[0], st_));
   vd = r->vd_replica[0];
   auto relayout_all = [&](const void* src, int z0, int nzc) -> hipError_t {
@@ -1759,24 +1990,33 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
       HIP_TRY(relayout_all((const char*)data + (size_t)z0 * slice_bytes, z0, nzc));
     }
     HIP_TRY(hipStreamSynchronize(st));
+    t_kern += ms_since(t_seg);
   }
   else {
     // host input: staged through a bounded device buffer (<= 1 GiB), slab by slab
     size_t slab = std::max<size_t>(1, ((size_t)1 << 30) / std::max<size_t>(1, slice_bytes));
     slab = std::min<size_t>(slab, (size_t)vd.nz);
     void* d_stage = nullptr;
+    t_seg = std::chrono::high_resolution_clock::now();
     HIP_TRY(hipMalloc(&d_stage, slab * slice_bytes));
+    t_alloc += ms_since(t_seg);
     for (int z0 = 0; z0 < vd.nz; z0 += (int)slab) {
       const int nzc = (int)std::min<size_t>(slab, (size_t)(vd.nz - z0));
+      t_seg = std::chrono::high_resolution_clock::now();
       hipError_t e = mem_kind == OVR_HIP_MEM_DEVICE
                          ? hipMemcpyPeerAsync(d_stage, r->device, (const char*)data + (size_t)z0 * slice_bytes, src_device, (size_t)nzc * slice_bytes, st)
                          : hipMemcpyAsync(d_stage, (const char*)data + (size_t)z0 * slice_bytes, (size_t)nzc * slice_bytes, hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st); // (the slab is waited for before its re-bricking starts: the split of the upload time is exact, and
+      t_copy += ms_since(t_seg);                          // the next copy could not overlap the kernel anyway - it writes the one staging buffer the kernel reads)
+      t_seg = std::chrono::high_resolution_clock::now();
       if (e == hipSuccess) e = relayout_all(d_stage, z0, nzc);
       if (e == hipSuccess) e = hipStreamSynchronize(st);
+      t_kern += ms_since(t_seg);
       if (e != hipSuccess) { (void)hipFree(d_stage); return fail(OVR_HIP_EDEVICE, std::string("[hip] volume upload failed: ") + hipGetErrorString(e)); }
     }
     HIP_TRY(hipFree(d_stage));
   }
+  t_seg = std::chrono::high_resolution_clock::now();
   r->vd = vd;
   if (r->layouts.current == 2) { // all planned replicas now, before the call returns
     for (int k = 1; k < kLayouts; ++k) {
@@ -1814,7 +2054,42 @@ int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int 
   r->fb_reset = true;
   r->tune_state = 0;
   r->pool_roomy = false; // a pooled frame of THIS volume has to prove the pool (ovr_hip_pack_tiles packs early only then)
-  GROUP_FORWARD(r, ovr_hip_set_volume(m, data, mem_kind, value_type, dims, grid_origin, grid_spacing)); // replicated on every device of a group
+  t_kern += ms_since(t_seg); // mode-2 replica builds, macrocell ranges, the data range
+  r->upload_ms[0] = ms_since(t_call); r->upload_ms[1] = t_alloc; r->upload_ms[2] = t_copy; r->upload_ms[3] = t_kern;
+  return 0;
+}
+} // namespace
+extern "C" {
+
+int ovr_hip_set_volume(ovr_hip_renderer* r, const void* data, int mem_kind, int value_type, const int32_t dims[3],
+                       const float grid_origin[3], const float grid_spacing[3])
+{
+  if (!r) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_set_volume: null argument");
+  if (r->members.size() <= 1) return set_volume_one(r, data, mem_kind, value_type, dims, grid_origin, grid_spacing);
+  // a device group: the volume is replicated - every member uploads on its own thread, side by side (a device array is staged to the other
+  // devices by peer copies).  A failure on ANY member leaves no member renderable: the members must never render different volumes
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  if (int e = set_device(r)) return e;
+  if (int e = finish_frame(r)) return e;
+  for (size_t i = 1; i < r->members.size(); ++i) {
+    ovr_hip_renderer* m = r->members[i];
+    m->worker->fn = [=] { return set_volume_one(m, data, mem_kind, value_type, dims, grid_origin, grid_spacing); };
+  }
+  const int e = group_run(r, GW_CALL, [&] { return set_volume_one(r, data, mem_kind, value_type, dims, grid_origin, grid_spacing); });
+  if (e) {
+    const std::string msg = g_last_error;
+    for (ovr_hip_renderer* m : r->members) m->have_volume = false;
+    return fail(e, msg + " (device group: the upload failed on a member - no member keeps a volume)");
+  }
+  r->group_upload_ms = ms_since(t0);
+  return 0;
+}
+
+int ovr_hip_get_upload_times(const ovr_hip_renderer* r, double out_ms[4])
+{
+  if (!r || !out_ms) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_get_upload_times: null argument");
+  for (int i = 0; i < 4; ++i) out_ms[i] = r->upload_ms[i];
+  if (r->members.size() > 1) out_ms[0] = r->group_upload_ms;
   return 0;
 }
 
@@ -1946,7 +2221,8 @@ int ovr_hip_set_noise_tile(ovr_hip_renderer* r, const float* tile, int32_t xy)
   HIP_TRY(hipMemcpy(r->d_noise, tr.data(), bytes, hipMemcpyHostToDevice));
   r->noise_xy = xy;
   r->fb_reset = true;
-  GROUP_FORWARD(r, ovr_hip_set_noise_tile(m, tile, xy));
+  if (r->members.size() > 1)
+    if (int e = group_call(r, [=](ovr_hip_renderer* m) { return ovr_hip_set_noise_tile(m, tile, xy); })) return e;
   return 0;
 }
 
@@ -1971,13 +2247,48 @@ int ovr_hip_set_image_shard(ovr_hip_renderer* r, int32_t rank, int32_t world, in
   return 0;
 }
 
+} // extern "C"
+namespace {
+int commit_one(ovr_hip_renderer* r);
+// what every member of a group must agree on after a commit (each applied its own copy of the queued values)
+bool same_committed_state(const ovr_hip_renderer* a, const ovr_hip_renderer* b)
+{
+  return a->fbsize.current.w == b->fbsize.current.w && a->fbsize.current.h == b->fbsize.current.h && std::memcmp(&a->camera.current, &b->camera.current, sizeof(CameraP)) == 0
+         && a->spp.current == b->spp.current && a->sparse.current == b->sparse.current && a->accumulate.current == b->accumulate.current && a->shading.current == b->shading.current
+         && a->rate.current == b->rate.current && a->jitter.current == b->jitter.current && a->grid_convention.current == b->grid_convention.current
+         && a->tfn.current.lo == b->tfn.current.lo && a->tfn.current.hi == b->tfn.current.hi && a->tfn.current.colors == b->tfn.current.colors && a->tfn.current.alphas == b->tfn.current.alphas
+         && std::memcmp(&a->focus.current, &b->focus.current, sizeof(FocusP)) == 0 && a->shard.current.world == b->shard.current.world && a->shard.current.tw == b->shard.current.tw
+         && a->shard.current.th == b->shard.current.th && a->have_tfn == b->have_tfn;
+}
+} // namespace
+extern "C" {
+
 int ovr_hip_commit(ovr_hip_renderer* r)
 {
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
   if (int e = set_device(r)) return e;
   if (int e = finish_frame(r)) return e;
+  if (r->members.size() <= 1) return commit_one(r);
   GroupLock gl(r); // every member applies the same queued values: no setter call of another thread is split between them
-  GROUP_FORWARD(r, ovr_hip_commit(m));
+  // every member commits on its own thread, the leader on this one.  A failure on any member (a framebuffer that does not fit ...) leaves the members
+  // on different states: the group then refuses to render until a later commit has succeeded everywhere and the members agree again
+  const int e = group_run(r, GW_COMMIT, [&] { return commit_one(r); });
+  bool same = true;
+  for (size_t i = 1; i < r->members.size() && same; ++i) same = same_committed_state(r, r->members[i]);
+  if (e || !same) {
+    const std::string msg = e ? g_last_error : std::string("[hip] the members of the device group disagree on the committed state");
+    r->group_broken = true;
+    r->group_broken_why = msg;
+    return fail(e ? e : OVR_HIP_ESTATE, msg);
+  }
+  r->group_broken = false;
+  return 0;
+}
+
+} // extern "C"
+namespace {
+int commit_one(ovr_hip_renderer* r)
+{
   std::lock_guard<std::mutex> lk(r->mtx);
   const bool reset_pending = r->fb_reset; // (without accumulation the flag is never consumed)
   r->fb_reset = false;
@@ -2039,14 +2350,22 @@ int ovr_hip_commit(ovr_hip_renderer* r)
   r->fb_reset = other_changed || only_camera_so_far || reset_pending;
   return 0;
 }
+} // namespace
+extern "C" {
 
 int ovr_hip_render_async(ovr_hip_renderer* r)
 {
   if (!r) return fail(OVR_HIP_EINVAL, "[hip] null renderer");
   if (int e = set_device(r)) return e;
   if (int e = finish_frame(r)) return e;
-  GROUP_FORWARD(r, ovr_hip_render_async(m)); // every device starts its tiles; the gather happens when the frame is resolved (group_finish)
-  return enqueue_frame(r);
+  if (r->members.size() <= 1) return enqueue_frame(r);
+  if (r->group_broken) return fail(OVR_HIP_ESTATE, "[hip] the device group is not renderable since a member failed: " + r->group_broken_why);
+  // every device starts its tiles - each member's frame is enqueued by its own thread, the leader's by this one; the gather happens when the
+  // frame is resolved (group_finish)
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  const int e = group_run(r, GW_RENDER, [&] { return enqueue_frame(r); });
+  r->group_host_us[0] = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count();
+  return e;
 }
 
 int ovr_hip_sync(ovr_hip_renderer* r)
@@ -2197,7 +2516,7 @@ int ovr_hip_swap(ovr_hip_renderer* r)
   if (int e = finish_frame(r)) return e;
   HIP_TRY(hipStreamSynchronize(r->stream())); // device_impl.cpp:105
   r->cur = (r->cur + 1) % 2;                  // safe_swap, optix7_common.h:366-370
-  GROUP_FORWARD(r, ovr_hip_swap(m));
+  if (r->members.size() > 1) return group_run(r, GW_SWAP);
   return 0;
 }
 

@@ -403,6 +403,18 @@ class DeviceHIP:
         L.check(self._lib.ovr_hip_group_info(self._h, C.byref(n), C.byref(kind), C.byref(ms)))
         return n.value, kind.value, ms.value
 
+    def group_host_times(self):
+        """host microseconds of the last frame's steps on the leader's thread: (enqueue, ship, finish, scatter); zeros without a group (ABI v10)"""
+        out = (C.c_double * 4)()
+        L.check(self._lib.ovr_hip_group_host_times(self._h, out))
+        return tuple(out)
+
+    def upload_times(self):
+        """milliseconds of the last ovr_hip_set_volume: dict(total, alloc, copy, kernels) (ABI v10)"""
+        out = (C.c_double * 4)()
+        L.check(self._lib.ovr_hip_get_upload_times(self._h, out))
+        return dict(total_ms=out[0], alloc_ms=out[1], copy_ms=out[2], kernels_ms=out[3])
+
     def member_stats(self, member):
         s = L.Stats()
         L.check(self._lib.ovr_hip_get_member_stats(self._h, int(member), C.byref(s)))

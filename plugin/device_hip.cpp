@@ -77,7 +77,10 @@ public:
     // (ovr_hip_create_group); everything below is the same for both.
     std::string list = std::getenv("OVR_HIP_DEVICES") ? std::getenv("OVR_HIP_DEVICES") : "";
     int device_id = 0;
-    for (int i = 1; i + 1 < argc; ++i) {
+    bool no_skip_flag = false;
+    for (int i = 1; i < argc; ++i) {
+      if (std::string(argv[i]) == "--hip-no-skip") no_skip_flag = true; // = OVR_HIP_SKIP_EMPTY=0 (a host that forwards its arguments; the reference's
+      if (i + 1 >= argc) continue;                                      // own apps reject flags they do not know - args::ParseError - and use the variable)
       if (std::string(argv[i]) == "--hip-device") device_id = std::stoi(argv[i + 1]);
       if (std::string(argv[i]) == "--hip-devices") list = argv[i + 1];
     }
@@ -101,8 +104,13 @@ public:
     // The reference builds its macrocell grids for every volume / transfer function (accel/sp_singlemc.cu) but only its path
     // tracer walks them; here the ray marcher skips empty space with them - the frames are bit-identical, so the drop-in
     // device has it on (OVR_HIP_SKIP_EMPTY=0 switches it off, e.g. to count every sample like the reference)
+    // (any fps quoted through this device must say which: with skipping the march fetches a fraction of the reference's samples - C3: 889 vs 373 fps)
     const char* skip = std::getenv("OVR_HIP_SKIP_EMPTY");
-    check(ovr_hip_set_empty_space_skipping(h, (skip && skip[0] == '0') ? 0 : 1));
+    const bool skipping = !(no_skip_flag || (skip && skip[0] == '0'));
+    check(ovr_hip_set_empty_space_skipping(h, skipping ? 1 : 0));
+    if (!(std::getenv("OVR_HIP_QUIET") && std::getenv("OVR_HIP_QUIET")[0] != '0'))
+      std::fprintf(stderr, "[hip] empty-space skipping %s\n", skipping ? "ON (bit-identical frames, fewer samples fetched than the reference's marcher; OVR_HIP_SKIP_EMPTY=0 / --hip-no-skip: the reference's exact work)"
+                                                                      : "OFF (every sample fetched, like the reference's marcher)");
     // nothing behind this interface reads per-phase device times: no events between the frame's kernels (OVR_HIP_PHASE_TIMING=1 keeps them)
     const char* phases = std::getenv("OVR_HIP_PHASE_TIMING");
     check(ovr_hip_set_phase_timing(h, (phases && phases[0] == '1') ? 1 : 0));
