@@ -295,6 +295,15 @@ int ovr_hip_sparse_mask(ovr_hip_renderer* r, int32_t frame_index, int32_t* out_x
 /* ovr/common/random/random.h:146-188: n (v0,v1) states -> 2n floats, states advanced in place */
 int ovr_hip_tea_floats(ovr_hip_renderer* r, uint32_t* v0v1_device, float* out_device, int64_t n);
 
+/* ABI v10 - shaders_raymarching.cu:64-66,118-122: the `__powf(x, y)` of the opacity correction as the kernels evaluate it, n (x, y) pairs -> n floats
+ * (device buffers).  which = 0: the pow this library was built with - v_exp_f32(y * v_log_f32(x)), CUDA's documented structure of the intrinsic, in
+ * the product; 1: a machine-independent log2 / exp2 pair (fmaf Horner chains; the CPU oracle's mode 2 is the same arithmetic, bit for bit).  A library
+ * built with -DOVR_PARITY_EXACT=1 (libovr_hip_parity.so: a test instrument for the parity tests, never the product - ovr_hip_built_for_exact_parity() == 1)
+ * marches with that pair: every sample count then equals the oracle's exactly, which pins the transcendental's last bit as the one source of the
+ * tolerated count differences. */
+int ovr_hip_pow_floats(ovr_hip_renderer* r, const float* x_device, const float* y_device, float* out_device, int64_t n, int32_t which);
+int ovr_hip_built_for_exact_parity(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,8 @@ SYMBOLS = {
     "ovr_hip_group_info": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "ovr_hip_group_host_times": (C.c_int, [_H, C.POINTER(C.c_double)]),
     "ovr_hip_get_upload_times": (C.c_int, [_H, C.POINTER(C.c_double)]),
+    "ovr_hip_pow_floats": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    "ovr_hip_built_for_exact_parity": (C.c_int, []),
     "ovr_hip_get_member_stats": (C.c_int, [_H, C.c_int32, C.POINTER(Stats)]),
     "ovr_hip_rccl_selftest": (C.c_int, [C.c_int]),
     "ovr_hip_set_stream": (C.c_int, [_H, C.c_void_p]),

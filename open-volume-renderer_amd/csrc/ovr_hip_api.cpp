@@ -2627,6 +2627,17 @@ int ovr_hip_sparse_mask(ovr_hip_renderer* r, int32_t frame_index, int32_t* out_x
   return 0;
 }
 
+int ovr_hip_pow_floats(ovr_hip_renderer* r, const float* x, const float* y, float* out, int64_t n, int32_t which)
+{
+  if (!r || !x || !y || !out || n < 0 || which < 0 || which > 1) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_pow_floats: bad arguments");
+  if (int e = set_device(r)) return e;
+  HIP_TRY(launch_pow(x, y, out, n, which, r->stream()));
+  HIP_TRY(hipStreamSynchronize(r->stream()));
+  return 0;
+}
+
+int ovr_hip_built_for_exact_parity(void) { return built_for_exact_parity(); }
+
 int ovr_hip_tea_floats(ovr_hip_renderer* r, uint32_t* v0v1, float* out, int64_t n)
 {
   if (!r || !v0v1 || !out || n < 0) return fail(OVR_HIP_EINVAL, "[hip] ovr_hip_tea_floats: bad arguments");

@@ -26,8 +26,21 @@ __device__ __forceinline__ float clampf(float x, float lo, float hi) { return __
 __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); } // NaN -> 0 like CUDA fminf/fmaxf (folds into a clamp modifier)
 __device__ __forceinline__ float lerpf(float a, float b, float f) { return fmaf(f, b - a, a); }
 // gdt normalize (extern/gdt/gdt/math/vec.h:443-448) with the hardware reciprocal square root (1 ulp)
+// OVR_PARITY_EXACT = 1 builds the PARITY INSTRUMENT (libovr_hip_parity.so; never the product, nothing loads it by default): the four places where the
+// kernels deliberately depart from the oracle's float arithmetic take the oracle's form instead - (1) the opacity correction's __powf is
+// the machine-independent det_powf below instead of v_exp_f32(y * v_log_f32(x)), (2) the three per-sample normalisations divide by sqrtf instead of
+// multiplying with v_rsq_f32, (3) the gradient divides by the step instead of multiplying with its reciprocal, (4) 8-bit voxels are normalised one by
+// one before the filter instead of once behind it.  tests/test_parity_exact_gpu.py: frames and every counter then equal the oracle's (mode "det") - which
+// pins those four as the ONLY sources of the product's tolerated differences.
+#ifndef OVR_PARITY_EXACT
+#define OVR_PARITY_EXACT 0
+#endif
 __device__ __forceinline__ f3 normalize3(f3 v)
 {
+#if OVR_PARITY_EXACT
+  const float l = sqrtf(dot3(v, v)); // gdt normalize: (v * 1.f) / sqrt(dot(v, v)), extern/gdt/gdt/math/vec.h:443-448
+  return mk3(v.x / l, v.y / l, v.z / l);
+#endif
   const float r = __builtin_amdgcn_rsqf(dot3(v, v));
   return mk3(v.x * r, v.y * r, v.z * r);
 }
@@ -42,9 +55,60 @@ __device__ __forceinline__ f3 normalize3_exact(f3 v)
 // BF: branch-free form (bit select instead of the exec-mask branch the compiler builds around the two transcendentals);
 // same value - adj == 1 keeps a exactly as the reference's branch does.  Only the skipping shadow march gains from it
 // (0.85 -> 0.71 ms on C3); the other kernels are measurably slower with it, so they keep the branch.
+// A log2 / exp2 pair that is the same float arithmetic on every machine (fmaf Horner chains, integer exponent handling; ~1 ulp each, the accuracy
+// class of v_log_f32 / v_exp_f32).  NOT the product's pow: a library built with -DOVR_PARITY_EXACT=1 (libovr_hip_parity.so) evaluates __powf with it, and so
+// does the CPU oracle in its mode 2 - with the same pow on both sides every sample count equals the oracle's exactly (tests/test_parity_exact_gpu.py): the
+// last bit of the transcendentals is all that the parity tests' remaining tolerances come from.  Constants: tests/golden/make_detpow.py.
+__device__ __forceinline__ float det_log2f(float x)
+{
+  if (!(x > 0.f)) return x == 0.f ? -__builtin_inff() : __builtin_nanf("");
+  if (x > 3.402823466e+38f) return x;
+  unsigned int ix = __float_as_uint(x);
+  int e = (int)(ix >> 23) - 127;
+  if (e == -127) { ix = __float_as_uint(x * 8388608.f); e = (int)(ix >> 23) - 127 - 23; }
+  float m = __uint_as_float((ix & 0x007fffffu) | 0x3f800000u);
+  if (m > 0x1.6a09e6p+0f) { m = m * 0.5f; e += 1; }
+  const float f = m - 1.f;
+  float p = -0x1.b8f078p-4f;
+  p = fmaf(p, f, 0x1.7aec18p-3f);
+  p = fmaf(p, f, -0x1.881ca4p-3f);
+  p = fmaf(p, f, 0x1.a37bc2p-3f);
+  p = fmaf(p, f, -0x1.eab168p-3f);
+  p = fmaf(p, f, 0x1.277a9ap-2f);
+  p = fmaf(p, f, -0x1.715a9p-2f);
+  p = fmaf(p, f, 0x1.ec70a8p-2f);
+  p = fmaf(p, f, -0x1.71547p-1f);
+  p = fmaf(p, f, 0x1.715476p+0f);
+  return fmaf(f, p, (float)e);
+}
+__device__ __forceinline__ float det_exp2f(float m)
+{
+  if (m != m) return m;
+  if (m >= 128.f) return __builtin_inff();
+  if (m < -126.f) return 0.f;
+  const float n = floorf(m + 0.5f);
+  const float r = m - n;
+  float p = 0x1.00c0e4p-16f;
+  p = fmaf(p, r, 0x1.446c7ap-13f);
+  p = fmaf(p, r, 0x1.5d8776p-10f);
+  p = fmaf(p, r, 0x1.3b29d8p-7f);
+  p = fmaf(p, r, 0x1.c6b08ep-5f);
+  p = fmaf(p, r, 0x1.ebfbep-3f);
+  p = fmaf(p, r, 0x1.62e43p-1f);
+  p = fmaf(p, r, 1.f);
+  const int in = (int)n;
+  const int h = in / 2;
+  const float s = p * __uint_as_float((unsigned int)(h + 127) << 23) * __uint_as_float((unsigned int)(in - h + 127) << 23);
+  return s < 1.175494351e-38f ? 0.f : s;
+}
+__device__ __forceinline__ float det_powf(float x, float y) { return det_exp2f(y * det_log2f(x)); }
 template <bool BF>
 __device__ __forceinline__ float opacity_correction(float a, float adj)
 {
+#if OVR_PARITY_EXACT
+  if (!(fabsf(adj - 1.f) < 1e-7f)) a = clamp01(1.f - det_powf(1.f - a, adj));
+  return a;
+#endif
   if (BF) {
     const float pw = __builtin_amdgcn_exp2f(adj * __builtin_amdgcn_logf(1.f - a));
     const float c = clamp01(1.f - pw);
@@ -400,15 +464,22 @@ __device__ __forceinline__ void tap_issue(const VolConsts& vc, f3 p, Tap& t)
 template <int VT>
 __device__ __forceinline__ float tap_finish(const VolConsts& vc, Tap t)
 {
+#if OVR_PARITY_EXACT
+  if (Vox<VT>::kScale) { // the texture's normalized read, voxel by voxel: v / 255, max(v / 127, -1) (array.cpp:304-306, array.h:68-106)
+    float* c = &t.c000;
+    for (int k = 0; k < 8; ++k) c[k] = Vox<VT>::kClamp ? fmaxf(c[k] / 127.f, -1.f) : c[k] / 255.f;
+  }
+#else
   if (Vox<VT>::kClamp) {
     t.c000 = fmaxf(t.c000, vc.vmin); t.c100 = fmaxf(t.c100, vc.vmin); t.c010 = fmaxf(t.c010, vc.vmin); t.c110 = fmaxf(t.c110, vc.vmin);
     t.c001 = fmaxf(t.c001, vc.vmin); t.c101 = fmaxf(t.c101, vc.vmin); t.c011 = fmaxf(t.c011, vc.vmin); t.c111 = fmaxf(t.c111, vc.vmin);
   }
+#endif
   const float c00 = lerpf(t.c000, t.c100, t.fx), c10 = lerpf(t.c010, t.c110, t.fx);
   const float c01 = lerpf(t.c001, t.c101, t.fx), c11 = lerpf(t.c011, t.c111, t.fx);
   const float c0 = lerpf(c00, c10, t.fy), c1 = lerpf(c01, c11, t.fy);
   float s = lerpf(c0, c1, t.fz);
-  if (Vox<VT>::kScale) s *= vc.vscale;
+  if (Vox<VT>::kScale && !OVR_PARITY_EXACT) s *= vc.vscale;
   return s;
 }
 
@@ -458,6 +529,9 @@ __device__ __forceinline__ void tap_coords2(const VolConsts& vc, f2 px, f2 py, f
 template <int VT>
 __device__ __forceinline__ f2 tap_finish2(const VolConsts& vc, Tap a, Tap b)
 {
+#if OVR_PARITY_EXACT
+  return mk2(tap_finish<VT>(vc, a), tap_finish<VT>(vc, b));
+#endif
   if (Vox<VT>::kClamp) {
     a.c000 = fmaxf(a.c000, vc.vmin); a.c100 = fmaxf(a.c100, vc.vmin); a.c010 = fmaxf(a.c010, vc.vmin); a.c110 = fmaxf(a.c110, vc.vmin);
     a.c001 = fmaxf(a.c001, vc.vmin); a.c101 = fmaxf(a.c101, vc.vmin); a.c011 = fmaxf(a.c011, vc.vmin); a.c111 = fmaxf(a.c111, vc.vmin);
@@ -1011,9 +1085,15 @@ __device__ __forceinline__ void shade_request(const RayMarchParams& P, const Vol
   tap_issue<VT, AM>(vc, mk3(po.x, po.y, po.z + (flz ? -mc.gstep.z : mc.gstep.z)), tgz);
   const f3 rgb = tf_color(tf, r.v);
   f3 g;
+#if OVR_PARITY_EXACT
+  g.x = (tap_finish<VT>(vc, tgx) - r.s) / (flx ? -mc.gstep.x : mc.gstep.x); // (sample(c + stp) - v) / stp, shaders_common.h:195-215
+  g.y = (tap_finish<VT>(vc, tgy) - r.s) / (fly ? -mc.gstep.y : mc.gstep.y);
+  g.z = (tap_finish<VT>(vc, tgz) - r.s) / (flz ? -mc.gstep.z : mc.gstep.z);
+#else
   g.x = (tap_finish<VT>(vc, tgx) - r.s) * (flx ? -mc.ginv.x : mc.ginv.x);
   g.y = (tap_finish<VT>(vc, tgy) - r.s) * (fly ? -mc.ginv.y : mc.ginv.y);
   g.z = (tap_finish<VT>(vc, tgz) - r.s) * (flz ? -mc.ginv.z : mc.ginv.z);
+#endif
   const f3 gn = normalize3(g);
   const f3 n_o = mk3(-gn.x, -gn.y, -gn.z);
   const f3 n_w = normalize3(mk3(n_o.x * mc.otw_it.x, n_o.y * mc.otw_it.y, n_o.z * mc.otw_it.z));

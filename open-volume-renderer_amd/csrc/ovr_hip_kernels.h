@@ -229,6 +229,8 @@ size_t sparse_mask_workspace_elems(int width, int height);
 hipError_t launch_sparse_mask(const SparseMaskParams& p, hipStream_t stream);
 
 hipError_t launch_tea(uint32_t* v0v1, float* out, int64_t n, hipStream_t stream);
+hipError_t launch_pow(const float* x, const float* y, float* out, int64_t n, int which, hipStream_t stream);
+int built_for_exact_parity();
 
 // macrocells (reference accel/sp_singlemc.cu): (min,max) per 16^3 cell once per volume; majorant per cell on every TF change
 hipError_t launch_macrocell_ranges(const VolumeDesc& vd, float* out_minmax, hipStream_t stream);

@@ -1176,6 +1176,23 @@ hipError_t launch_tea(uint32_t* v0v1, float* out, int64_t n, hipStream_t stream)
   return hipGetLastError();
 }
 
+// known-answer entry of the pow the kernels evaluate for __powf (shaders_raymarching.cu:64-66,118-122): which = 0 the one this library was BUILT with
+// (v_exp_f32(y * v_log_f32(x)), or the deterministic pair under -DOVR_PARITY_EXACT=1), 1 = the deterministic pair whatever the build
+__global__ void pow_kernel(const float* x, const float* y, float* out, long long n, int which)
+{
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float xv = x[i], yv = y[i];
+  out[i] = (which == 1 || OVR_PARITY_EXACT) ? det_powf(xv, yv) : __builtin_amdgcn_exp2f(yv * __builtin_amdgcn_logf(xv));
+}
+hipError_t launch_pow(const float* x, const float* y, float* out, int64_t n, int which, hipStream_t stream)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, y, out, (long long)n, which);
+  return hipGetLastError();
+}
+int built_for_exact_parity() { return OVR_PARITY_EXACT; }
+
 // ------------------------------------------------------------------------------------------------------------------
 // tile pack / unpack (payload of the per-frame RCCL gather): slot k = k-th tile owned by `rank` in row-major tile order
 // ------------------------------------------------------------------------------------------------------------------

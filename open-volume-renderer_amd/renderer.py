@@ -438,6 +438,17 @@ class DeviceHIP:
         return out.cpu().numpy(), st.cpu().numpy().view(np.uint32)
 
 
+    def pow_floats(self, x, y, which=0):
+        """the kernels' `__powf(x, y)` on the device (known-answer entry): which = 0 the pow this library was built with, 1 the deterministic pair"""
+        import torch
+        dev = torch.device("cuda", self.device_id)
+        xd = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+        yd = torch.as_tensor(np.ascontiguousarray(y, dtype=np.float32)).to(dev)
+        out = torch.empty(xd.numel(), dtype=torch.float32, device=dev)
+        L.check(self._lib.ovr_hip_pow_floats(self._h, C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), C.c_void_p(out.data_ptr()), xd.numel(), int(which)))
+        return out.cpu().numpy()
+
+
 def create_renderer(name: str, device_id: int = 0, devices=None):
     """create_renderer(name) (reference ovr/renderer.cpp:42-61).  Only "hip" exists here; anything else raises the
     same way the reference's factory does for an unknown device.  devices = [ordinals]: an in-process device group."""

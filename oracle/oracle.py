@@ -32,7 +32,7 @@ class Scene(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("shaded_samples", C.c_uint64),
-                ("shadow_samples", C.c_uint64), ("shadow_samples_visible", C.c_uint64)]
+                ("shadow_samples", C.c_uint64), ("shadow_samples_visible", C.c_uint64), ("borderline_samples", C.c_uint64)]
 
 
 _lib = None
@@ -65,6 +65,9 @@ def load():
     lib.ovr_oracle_set_powf_mode.argtypes = [C.c_int]
     lib.ovr_oracle_set_powf_mode.restype = C.c_int
     lib.ovr_oracle_get_powf_mode.restype = C.c_int
+    for name, nargs in (("ovr_oracle_det_log2f", 1), ("ovr_oracle_det_exp2f", 1), ("ovr_oracle_det_powf", 2)):
+        getattr(lib, name).argtypes = [C.c_float] * nargs
+        getattr(lib, name).restype = C.c_float
     lib.ovr_oracle_render_frame.argtypes = [C.POINTER(Scene), C.c_int, C.c_int, fp, fp, fp, C.POINTER(Counters), C.c_int]
     lib.ovr_oracle_trace_ray.argtypes = [C.POINTER(Scene), fp, fp, fp, fp, C.POINTER(Counters)]
     lib.ovr_oracle_rgba8.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
@@ -91,7 +94,7 @@ def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
-POWF_EXP2_LOG2, POWF_LIBM = 0, 1
+POWF_EXP2_LOG2, POWF_LIBM, POWF_DET = 0, 1, 2
 
 
 def set_powf_mode(mode):

@@ -297,21 +297,76 @@ static int g_powf_mode = -1;
 int ovr_oracle_set_powf_mode(int mode)
 {
   const int old = g_powf_mode;
-  g_powf_mode = mode ? 1 : 0;
+  g_powf_mode = (mode == 1 || mode == 2) ? mode : 0;
   return old < 0 ? 0 : old;
 }
 static inline int powf_mode(void)
 {
   if (g_powf_mode < 0) {
     const char* e = getenv("OVR_ORACLE_POWF");
-    g_powf_mode = (e && strcmp(e, "libm") == 0) ? 1 : 0;
+    g_powf_mode = (e && strcmp(e, "libm") == 0) ? 1 : (e && strcmp(e, "det") == 0) ? 2 : 0;
   }
   return g_powf_mode;
 }
 int ovr_oracle_get_powf_mode(void) { return powf_mode(); }
+
+/* mode 2 - a log2 / exp2 pair that is the SAME float arithmetic on every machine: fmaf Horner chains, integer exponent handling, no library call.
+ * Neither libm's log2f / exp2f nor the GPU's v_log_f32 / v_exp_f32 nor CUDA's lg2.approx / ex2.approx round the last bit alike, and 1 - (1 - a)^dt sits on a
+ * 6e-8 grid next to 1 where that bit decides whether a sample has opacity 0 (is it shaded?) or an alpha reaches 0.9999 (does the ray end one step
+ * earlier?).  The HIP library can be built with the same pair (-DOVR_PARITY_EXACT=1: libovr_hip_parity.so, a test instrument, not the product): then every
+ * count equals the oracle's EXACTLY (tests/test_parity_exact_gpu.py) - the proof that the transcendental's last bit is the only thing the tolerated
+ * differences of the parity tests come from.  ~1 ulp each, like the hardware instructions; coefficients: Chebyshev fits, tests/golden/make_detpow.py. */
+static inline float bits_to_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t float_to_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+float ovr_oracle_det_log2f(float x)
+{
+  if (!(x > 0.f)) return x == 0.f ? -INFINITY : NAN;      /* 0 -> -inf, negative / NaN -> NaN */
+  if (x > FLT_MAX) return x;                               /* +inf */
+  uint32_t ix = float_to_bits(x);
+  int e = (int)(ix >> 23) - 127;
+  if (e == -127) { ix = float_to_bits(x * 8388608.f); e = (int)(ix >> 23) - 127 - 23; } /* subnormal: scale by 2^23 (exact) */
+  float m = bits_to_float((ix & 0x007fffffu) | 0x3f800000u); /* [1, 2) */
+  if (m > 0x1.6a09e6p+0f) { m = m * 0.5f; e += 1; }           /* [sqrt(1/2), sqrt(2)] */
+  const float f = m - 1.f;                                     /* exact */
+  float p = -0x1.b8f078p-4f;                                   /* log2(1 + f) / f on [-0.294, 0.415], degree 9 */
+  p = fmaf(p, f, 0x1.7aec18p-3f);
+  p = fmaf(p, f, -0x1.881ca4p-3f);
+  p = fmaf(p, f, 0x1.a37bc2p-3f);
+  p = fmaf(p, f, -0x1.eab168p-3f);
+  p = fmaf(p, f, 0x1.277a9ap-2f);
+  p = fmaf(p, f, -0x1.715a9p-2f);
+  p = fmaf(p, f, 0x1.ec70a8p-2f);
+  p = fmaf(p, f, -0x1.71547p-1f);
+  p = fmaf(p, f, 0x1.715476p+0f);
+  return fmaf(f, p, (float)e);
+}
+float ovr_oracle_det_exp2f(float m)
+{
+  if (m != m) return m;
+  if (m >= 128.f) return INFINITY;
+  if (m < -126.f) return 0.f;                                  /* results below the normal range are flushed (2^-126 itself is kept) */
+  const float n = floorf(m + 0.5f);
+  const float r = m - n;                                       /* [-0.5, 0.5], exact */
+  float p = 0x1.00c0e4p-16f;                                   /* 2^r, degree 7 */
+  p = fmaf(p, r, 0x1.446c7ap-13f);
+  p = fmaf(p, r, 0x1.5d8776p-10f);
+  p = fmaf(p, r, 0x1.3b29d8p-7f);
+  p = fmaf(p, r, 0x1.c6b08ep-5f);
+  p = fmaf(p, r, 0x1.ebfbep-3f);
+  p = fmaf(p, r, 0x1.62e43p-1f);
+  p = fmaf(p, r, 1.f);
+  const int in = (int)n;                                       /* [-126, 128] */
+  const int h = in / 2;                                        /* two exact power-of-two factors: each in range */
+  const float s = p * bits_to_float((uint32_t)(h + 127) << 23) * bits_to_float((uint32_t)(in - h + 127) << 23);
+  return s < FLT_MIN ? 0.f : s;                                /* p < 1 can push n = -126 below the normal range: flushed like the rest */
+}
+float ovr_oracle_det_powf(float x, float y) { return ovr_oracle_det_exp2f(y * ovr_oracle_det_log2f(x)); }
+
 static inline float fast_powf(float x, float y)
 {
-  if (powf_mode() == 1) return powf(x, y);
+  const int mode = powf_mode();
+  if (mode == 1) return powf(x, y);
+  if (mode == 2) return ovr_oracle_det_powf(x, y);
   const float l = log2f(x);
   const float m = y * l;
   return exp2f(m);
@@ -475,9 +530,13 @@ static void trace_ray(const frame_consts* fc, v3 org, v3 dir, float out_rgba[4],
       const float sample = ovr_oracle_sample_volume(s, p);
       float rgba[4];
       tfn_rgba_at(s, &fc->tr, sample, rgba);
+      const float a_tf = rgba[3];
       rgba[3] = ovr_oracle_opacity_correction(rgba[3], fc->base, ty - tx);
       cnt->samples++;
       if (rgba[3] > 0.f) cnt->shaded_samples++;
+      /* a sample whose table opacity is > 0 but whose CORRECTED opacity lies within four 6e-8 steps of 0: whether it counts as shaded is decided
+         by the last bit of the pow (libm here, v_exp / v_log on the GPU, ex2.approx / lg2.approx in the reference) */
+      if (a_tf > 0.f && rgba[3] <= 0x1p-22f && rgba[3] != a_tf) cnt->borderline_samples++;
 
       v3 n_c = v3_make(0, 0, 0);
       /* skip_zero_opacity: a sample with corrected opacity exactly 0 adds fma(tr * clamp01(x), 0, acc) == acc to colour,
@@ -648,6 +707,7 @@ static void add_counters(ovr_oracle_counters* a, const ovr_oracle_counters* b)
   a->shaded_samples += b->shaded_samples;
   a->shadow_samples += b->shadow_samples;
   a->shadow_samples_visible += b->shadow_samples_visible;
+  a->borderline_samples += b->borderline_samples;
 }
 
 static void process_items(frame_job* j, ovr_oracle_counters* cnt)

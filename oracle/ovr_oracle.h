@@ -101,6 +101,8 @@ typedef struct ovr_oracle_counters {
   uint64_t shaded_samples;  /* primary samples whose corrected opacity is > 0 */
   uint64_t shadow_samples;  /* shadow-march iterations the reference performs (one march per primary sample) */
   uint64_t shadow_samples_visible; /* shadow-march iterations belonging to primary samples with opacity > 0 */
+  uint64_t borderline_samples; /* primary samples the opacity correction's pow took to within 2^-22 of 0 from a table opacity > 0: whether such a
+                                  sample is "shaded" hangs on the pow's last bit - the bound of the shaded-count difference between two pow implementations */
 } ovr_oracle_counters;
 
 /* ovr/common/random/random.h:146-188 - two floats from 16 TEA rounds; state is updated in place */
@@ -136,9 +138,15 @@ uint16_t ovr_oracle_float_to_half(float f);
 float ovr_oracle_half_to_float(uint16_t h);
 
 /* how __powf (shaders_raymarching.cu:64-66,118-122) is restated: 0 (default) = exp2f(y * log2f(x)), CUDA's documented definition of the
- * intrinsic; 1 = libm's powf (rounds 1-4).  Process-wide; returns the previous mode.  OVR_ORACLE_POWF=libm sets the initial mode. */
+ * intrinsic; 1 = libm's powf (rounds 1-4); 2 = the deterministic pair below.  Process-wide; returns the previous mode.  OVR_ORACLE_POWF=libm|det sets the initial mode. */
 int ovr_oracle_set_powf_mode(int mode);
 int ovr_oracle_get_powf_mode(void);
+/* mode 2: a machine-independent log2 / exp2 pair (fmaf Horner chains, ~1 ulp each - the accuracy class of the hardware instructions), the same float
+ * arithmetic the HIP library evaluates when it is built with -DOVR_PARITY_EXACT=1 (libovr_hip_parity.so, a test instrument): with the same pow on both
+ * sides every sample count is equal exactly - what is left of the parity tests' tolerances is the last bit of the transcendentals */
+float ovr_oracle_det_log2f(float x);
+float ovr_oracle_det_exp2f(float m);
+float ovr_oracle_det_powf(float x, float y);
 
 /* ovr/devices/optix7/shaders_common.h:186-193 + texture setup array.cpp:300-306: clamp p to [0,1]^3,
  * linear-filtered, clamp-addressed sample at normalized coordinate p (object space) */

@@ -16,7 +16,7 @@ import ovr_amd as ovr  # noqa: E402
 import oracle as O  # noqa: E402
 from helpers import make_case, oracle_scene, hip_setup, hip_frame  # noqa: E402
 
-MODES = (("libm", O.POWF_LIBM), ("exp2", O.POWF_EXP2_LOG2))
+MODES = (("libm", O.POWF_LIBM), ("exp2", O.POWF_EXP2_LOG2), ("det", O.POWF_DET))
 q = lambda x: (np.clip(np.asarray(x, dtype=np.float32), np.float32(0.0), np.float32(1.0)) * np.float32(255.0)).astype(np.uint8).astype(np.int32)
 
 
@@ -54,7 +54,7 @@ def scenes():
             t["dshaded"] += d; t["shaded"] += int(cnt.shaded_samples); t["worst_abs"] = max(t["worst_abs"], d)
             t["worst_rel"] = max(t["worst_rel"], d / max(int(cnt.shaded_samples), 1)); t["dcol_all"] = max(t["dcol_all"], dall)
             t["dcol_vis"] = max(t["dcol_vis"], dvis); t["dalpha"] = max(t["dalpha"], da); t["dprim"] += abs(int(st.samples) - int(cnt.samples))
-            line += f" | {m}: dshaded {d:6d} ({d / max(int(cnt.shaded_samples), 1):.2e}) dcol all {dall:.3g} vis {dvis:.3g} dalpha {da:.3g} d8vis {int(np.abs(q(got[..., :3]) - q(ref[..., :3]))[vis].max()) if vis.any() else 0}"
+            line += f" | {m}: dshaded {d:6d} of {int(cnt.borderline_samples)} borderline ({d / max(int(cnt.shaded_samples), 1):.2e}) dcol all {dall:.3g} vis {dvis:.3g} dalpha {da:.3g} d8vis {int(np.abs(q(got[..., :3]) - q(ref[..., :3]))[vis].max()) if vis.any() else 0}"
         print(line, flush=True)
     for m, _ in MODES:
         print(f"scenes total {m}: {tot[m]}", flush=True)

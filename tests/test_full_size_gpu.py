@@ -229,10 +229,12 @@ def test_c1_full_frame_vs_oracle(ovr, oracle, hip_renderer_factory):
     sc = oracle.OracleScene(vol.cpu().numpy(), colors, alphas, vr, cam, size[0], size[1], shading=oracle.SHADE_FULL)
     ref, _, cnt = sc.render()
     # the oracle marches a shadow ray for every sample like the reference; those of samples with opacity > 0 are the GPU's.
-    # Primary counts are exact; a shadow ray may end one iteration apart when its alpha sits on the 0.9999 threshold (the
-    # GPU's v_exp(y * v_log(x)) for __powf differs from the oracle's powf in the last bit): 1 of 5.67 M here
+    # Primary counts are exact; a shadow ray may end one iteration apart when its alpha sits on the 0.9999 threshold: 1 of 5.67 M here.  Round 5 found
+    # its cause: not the pow (all three restatements of __powf in the oracle count the same 5 670 167) but the 8-bit voxels being normalised behind the
+    # filter instead of one by one - the exact-parity build, which normalises them like the texture unit, counts 5 670 167 too and gives this frame bit for
+    # bit (tests/test_parity_exact_gpu.py).  The bar: what was measured, doubled
     assert (st.samples, st.shaded_samples) == (cnt.samples, cnt.shaded_samples)
-    assert abs(int(st.shadow_samples) - int(cnt.shadow_samples_visible)) <= 8
+    assert abs(int(st.shadow_samples) - int(cnt.shadow_samples_visible)) <= 2
     d8 = np.abs(oracle.rgba8(got, flip=False).astype(int) - oracle.rgba8(ref, flip=False).astype(int))
     assert d8.max() <= 1
     assert np.abs(got - ref).max() <= 2e-4

@@ -84,9 +84,11 @@ def test_shipped_scene(ovr, oracle, hip_renderer_factory, name):
         st = ren.stats()
         compare_visible(oracle, frames[skip], ref, name=f"{name} skip={skip}")
         assert st.samples + st.skipped_samples == cnt.samples, name
-        # the scenes' sampling rates are 4 and 20, so every opacity goes through 1 - (1 - a)^(dt) - `v_exp(dt * v_log(1 - a))` on the GPU, powf in
-        # the oracle: a sample whose opacity is a few ulp above 0 on one side can be exactly 0 on the other.  Such a
-        # sample changes no pixel (the frame comparison above is the parity bar) but it is or is not counted as shaded
-        assert abs(int(st.shaded_samples) - int(cnt.shaded_samples)) <= max(8, int(0.02 * cnt.shaded_samples)), (name, st.shaded_samples, cnt.shaded_samples)
+        # the scenes' sampling rates are 4 and 20, so every opacity goes through 1 - (1 - a)^(dt) - `v_exp(dt * v_log(1 - a))` on the GPU, exp2f(dt *
+        # log2f(1 - a)) in the oracle: a sample whose opacity is a few 6e-8 steps above 0 on one side can be exactly 0 on the other.
+        # Such a sample changes no pixel (the frame comparison above is the parity bar) but it is or is not counted as shaded.  Round 5: the bound is no
+        # longer a percentage but the oracle's own count of such samples (table opacity > 0, corrected opacity within 2^-22 of 0: measured 0 ... 618
+        # differences against 0 ... 687 722 borderline samples); with the same pow on both sides the counts are equal (tests/test_parity_exact_gpu.py)
+        assert abs(int(st.shaded_samples) - int(cnt.shaded_samples)) <= int(cnt.borderline_samples), (name, st.shaded_samples, cnt.shaded_samples, cnt.borderline_samples)
         ren.close()
     assert np.array_equal(frames[False], frames[True]), f"{name}: empty-space skipping changed the frame"
