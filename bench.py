@@ -262,10 +262,14 @@ def _leg_summary(leg):
     out = {"ms_per_step": _sig(leg.get("ms_per_step")), "value": _sig(leg.get("value", (leg.get("gsamples_per_s") or 0.0) * 1e3 if leg.get("gsamples_per_s") is not None else None)),
            "bound": r.get("bound", leg.get("bound")), "frac": _sig(r.get("frac", leg.get("frac"))),
            "traffic_ratio": _sig(kd.get("traffic_ratio", leg.get("traffic_ratio")))}
-    for k in ("gather_line_rate_frac", "compulsory_floor_bytes", "march_ms", "shade_ms", "upload_ms", "host_us_per_frame", "gather"):
+    for k in ("gather_line_rate_frac", "compulsory_floor_bytes", "upload_ms"):
         v = kd.get(k, r.get(k, leg.get(k)))
         if v is not None:
             out[k] = _sig(v)
+    g = leg.get("device_group")
+    if isinstance(g, dict):   # the in-process device group: which way the tiles travelled and what the leader's thread spent on launching + shipping a frame
+        out["gather"] = g.get("gather")
+        out["host_us_per_frame"] = _sig(g.get("host_us_per_frame"))
     return out
 
 

@@ -227,11 +227,13 @@ int ovr_hip_commit(ovr_hip_renderer* r);
 /* replaces DeviceOptix7::render (optix7/device.cpp:35-43, device_impl.cpp:199-269): one frame, blocking until the
  * frame is complete on the device; adds the elapsed milliseconds to the value ovr_hip_render_time_ms() returns. */
 int ovr_hip_render(ovr_hip_renderer* r);
-/* non-blocking variant: enqueues the frame on the renderer's stream and returns (for hipEvent timing / graphs).  (Round 4: the first frame after
- * a camera / volume / size / spp / jitter change reads 8 bytes back from the device before it launches - how many 8x8-pixel blocks have a ray that
- * meets the volume's box; the others get no workgroup, their pixels are cleared - a stream synchronisation of ~20 us.  Such a frame cannot be
- * captured into a hipGraph: on a caller's stream under capture it fails with OVR_HIP_ESTATE - render it once outside the capture; the frames of an
- * unchanged configuration launch without a host wait and capture.) */
+/* non-blocking variant: enqueues the frame on the renderer's stream and returns (hipEvent timing around it, overlap with the caller's other work -
+ * e.g. the gather of the previous frame).  The first frame after a camera / volume / size / spp / jitter change reads 8 bytes back from the device
+ * before it launches - how many 8x8-pixel blocks have a ray that meets the volume's box; the others get no workgroup, their pixels are cleared - a
+ * stream synchronisation of ~20 us (a device group's members wait side by side, each on its own host thread).  A frame is NOT a unit for hipGraph
+ * capture - it records timed events and its counters are read by the host when it is resolved: with a caller's stream (ovr_hip_set_stream) that is
+ * capturing, the call fails with OVR_HIP_ESTATE and leaves the capture intact.  (A frame is five launches, ~10 us of host time that overlap its
+ * first kernel: there is nothing for a graph to take) */
 int ovr_hip_render_async(ovr_hip_renderer* r);
 /* waits for the frame enqueued by render_async and for everything else enqueued on the renderer's stream
  * (ovr_hip_pack_tiles / ovr_hip_unpack_tiles launches included) */

@@ -667,8 +667,18 @@ int build_schedule_list(ovr_hip_renderer* r)
   // listed supertile by supertile (4x4 blocks = 32x32 pixels, row-major inside): 16 consecutive entries are a compact square,
   // which the schedule kernel keeps together on one XCD
   const int sw = (bw + 3) / 4, sh = (bh + 3) / 4;
+  // order of the supertiles: row-major (0, default) or along a Z curve (OVR_HIP_SCHED_ORDER=morton, round 5 experiment for C4: the blocks of one
+  // ray-length class form a ring around the volume's silhouette - in row-major order consecutive entries of a class alternate between the ring's left and
+  // right side, on the Z curve they are 2-D patches: do workgroups that run at the same time then share DRAM pages?)
+  static const bool morton = getenv("OVR_HIP_SCHED_ORDER") && std::string(getenv("OVR_HIP_SCHED_ORDER")) == "morton";
+  std::vector<std::pair<unsigned int, unsigned int>> order; // (key, sx | sy << 16)
+  order.reserve((size_t)sw * sh);
+  auto spread = [](unsigned int v) { v &= 0xffffu; v = (v | (v << 8)) & 0x00ff00ffu; v = (v | (v << 4)) & 0x0f0f0f0fu; v = (v | (v << 2)) & 0x33333333u; return (v | (v << 1)) & 0x55555555u; };
   for (int sy = 0; sy < sh; ++sy)
-    for (int sx = 0; sx < sw; ++sx)
+    for (int sx = 0; sx < sw; ++sx) order.push_back({ morton ? (spread((unsigned int)sx) | (spread((unsigned int)sy) << 1)) : (unsigned int)(sy * sw + sx), (unsigned int)sx | ((unsigned int)sy << 16) });
+  if (morton) std::sort(order.begin(), order.end());
+  for (const auto& o : order) {
+      const int sx = (int)(o.second & 0xffffu), sy = (int)(o.second >> 16);
       for (int k = 0; k < 16; ++k) {
         const int bx = sx * 4 + (k & 3), by = sy * 4 + (k >> 2);
         if (bx >= bw || by >= bh) continue;
@@ -681,6 +691,7 @@ int build_schedule_list(ovr_hip_renderer* r)
         }
         if (mine) list.push_back((unsigned int)bx | ((unsigned int)by << 16));
       }
+  }
   if (r->d_sched_src) HIP_TRY(hipFree(r->d_sched_src));
   if (r->d_sched) HIP_TRY(hipFree(r->d_sched));
   r->d_sched_src = r->d_sched = nullptr;
@@ -792,6 +803,15 @@ int enqueue_frame(ovr_hip_renderer* r)
   const int W = r->fbsize.current.w, H = r->fbsize.current.h;
   if (W <= 0 || H <= 0) return 0; // device_impl.cpp:216-217
   hipStream_t st = r->stream();
+  if (r->use_user_stream) {
+    // A frame is not a capturable unit: its first and last events carry timing, the frame after a camera / volume / size change waits for two
+    // words from the device, and the host reads the frame's counters when it resolves it - a caller's stream under graph capture is refused, not corrupted
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+      return fail(OVR_HIP_ESTATE, "[hip] ovr_hip_render_async: the caller's stream is capturing a graph - frames cannot be captured (they record timed events and hand "
+                                  "counters back to the host); enqueue them on the stream outside the capture");
+    (void)hipGetLastError();
+  }
   if (r->tf_copy_pending) { HIP_TRY(hipStreamWaitEvent(st, r->ev_tf, 0)); r->tf_copy_pending = false; } // the tables' copy may sit on the other set's stream
   RayMarchParams& P = r->P;
   const bool accumulate = r->accumulate.current != 0;
@@ -975,13 +995,7 @@ int enqueue_frame(ovr_hip_renderer* r)
       r->n_work = r->n_sched;
       r->empty_pixels = 0;
       if (exact && r->n_sched > 0) { // how many entries need a workgroup: two words from the device, once per camera / volume / size change
-        // (a stream under graph capture cannot be waited for: the frame after a change is rendered outside the capture - ADVICE r4; frames of an
-        // unchanged configuration launch without any host wait and capture as before.  In a device group every member waits on its own thread.)
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (r->use_user_stream && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-          return fail(OVR_HIP_ESTATE, "[hip] ovr_hip_render_async: the first frame after a camera / volume / size / spp / jitter change reads 8 bytes back from the device and "
-                                      "cannot be captured into a graph - render it once outside the capture");
-        (void)hipGetLastError();
+        // (in a device group every member waits on its own thread, side by side - round 5)
         HIP_TRY(hipStreamSynchronize(st));
         r->n_work = std::min(r->d_sched_info[0], r->n_sched);
         r->empty_pixels = r->d_sched_info[1];
@@ -2290,6 +2304,14 @@ namespace {
 int commit_one(ovr_hip_renderer* r)
 {
   std::lock_guard<std::mutex> lk(r->mtx);
+  // test hook (tests/test_round5_gpu.py): OVR_HIP_TEST_FAIL_MEMBER=k makes member k of a device group fail the commit of a framebuffer 4242 pixels wide -
+  // the way a member that cannot allocate its framebuffer would - so that the group's refusal to render in mixed state can be exercised on one card
+  if (r->fbsize.dirty && r->fbsize.queued.w == 4242)
+    if (const char* t = getenv("OVR_HIP_TEST_FAIL_MEMBER"))
+      if ((r->leader ? r->group_rank : 0) == atoi(t) && (r->leader || r->members.size() > 1)) {
+        r->fbsize.dirty = false; // (the value is consumed, like a real failure half-way through)
+        return fail(OVR_HIP_EDEVICE, "[hip] commit failed on member " + std::string(t) + " (OVR_HIP_TEST_FAIL_MEMBER)");
+      }
   const bool reset_pending = r->fb_reset; // (without accumulation the flag is never consumed)
   r->fb_reset = false;
   bool fb_size_updated = false, camera_changed = false;

@@ -159,6 +159,34 @@ def test_c3_shards_and_oracle_subset(ovr, oracle, hip_renderer_factory, c3_volum
     d8 = np.abs(oracle.rgba8(ref, flip=False).astype(int) - oracle.rgba8(o_rgba, flip=False).astype(int))[mask]
     assert d8.max() <= 1
     assert np.abs(ref - o_rgba)[mask].max() <= 2e-4
+    # (round 5) ... and the frame the headline benchmark TIMES - reference shading incl. the shadow march, the pooled pipeline the automatic
+    # choice takes, with and without empty-space skipping - on the same anti-diagonal: the HIP renderer draws exactly that shard, so its counters are the
+    # subset's and must equal the oracle's (primary and shaded exactly; the shadow march within the borderline class of tests/test_parity_exact_gpu.py)
+    sc = oracle.OracleScene(vol_host, colors, alphas, vr, cam, size[0], size[1], shading=oracle.SHADE_FULL, shard=(23, 64, tile, tile), skip_zero_opacity=True)
+    o_rgba, _, cnt = sc.render()
+    for skip in (False, True):
+        ren = _setup(ovr, hip_renderer_factory(), c3_volume, n, size, 2, shard=(23, 64, tile, tile), skip=skip)
+        ren.render()
+        got, st = _frame(ovr, ren), ren.stats()
+        ren.close()
+        assert st.pipeline == 2 and st.samples + st.skipped_samples == cnt.samples and st.shaded_samples == cnt.shaded_samples, (skip, st.samples, cnt.samples)
+        assert cnt.shadow_samples_visible > 1e6 and abs(int(st.shadow_samples + st.skipped_shadow_samples) - int(cnt.shadow_samples_visible)) <= 4, (skip, st.shadow_samples, cnt.shadow_samples_visible)
+        d8 = np.abs(oracle.rgba8(got, flip=False).astype(int) - oracle.rgba8(o_rgba, flip=False).astype(int))[mask]
+        assert d8.max() <= 1 and np.abs(got - o_rgba)[mask].max() <= 2e-4, skip
+        assert np.array_equal(got[mask], _headline_frame(ovr, hip_renderer_factory, c3_volume, n, size)[mask]), skip   # the shard's pixels are the unsharded headline frame's
+
+
+_HEADLINE = {}
+
+
+def _headline_frame(ovr, hip_renderer_factory, vol, n, size):
+    """the unsharded frame of the headline configuration (rendered once per module)"""
+    if "f" not in _HEADLINE:
+        ren = _setup(ovr, hip_renderer_factory(), vol, n, size, 2)
+        ren.render()
+        _HEADLINE["f"] = _frame(ovr, ren)
+        ren.close()
+    return _HEADLINE["f"]
 
 
 def test_c2_and_c4_sizes(ovr, oracle, hip_renderer_factory):
@@ -171,6 +199,21 @@ def test_c2_and_c4_sizes(ovr, oracle, hip_renderer_factory):
     b.render()
     assert np.array_equal(_frame(ovr, a), _frame(ovr, b))
     assert a.stats().samples == b.stats().samples + b.stats().skipped_samples
+    # (round 5) C2 as benchmarked against the oracle itself: the 16 64x64 tiles of the anti-diagonal tx + ty == 15 through the image centre
+    tile = 64
+    colors, alphas, vr = ovr.synth.make_tfn("sparse", 1024)
+    sc = oracle.OracleScene(vol.cpu().numpy(), colors, alphas, vr, ovr.synth.make_camera("oblique", 512), 1024, 1024, shading=oracle.SHADE_NONE, shard=(15, 32, tile, tile))
+    o_rgba, _, cnt = sc.render()
+    c = _setup(ovr, hip_renderer_factory(), vol, 512, (1024, 1024), 0, shard=(15, 32, tile, tile))
+    c.render()
+    mask = np.zeros((1024, 1024), bool)
+    for tx, ty in ovr.tiles.owned_tiles(1024, 1024, tile, tile, 15, 32):
+        mask[ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile] = True
+    got, whole = _frame(ovr, c), _frame(ovr, a)
+    assert mask.sum() == 16 * tile * tile and cnt.samples > 1e6 and c.stats().samples == cnt.samples
+    assert np.array_equal(got[mask], whole[mask])                       # the shard's pixels are the whole frame's
+    assert np.abs(oracle.rgba8(got, flip=False).astype(int) - oracle.rgba8(o_rgba, flip=False).astype(int))[mask].max() <= 1
+    assert np.abs(got - o_rgba)[mask].max() <= 2e-4
     del vol
     torch.cuda.empty_cache()
     # 1600 x 1280 x 1200 u16: 2.46 G voxels -> 6.6 GB bricked: element offsets still fit 32 bits (addressing mode 1) ...

@@ -1,0 +1,141 @@
+"""Round 5: the host side of the C ABI - where an upload spends its time (ABI v10), a device group driven by one host thread per member, the group's refusal to
+render after a member's failure, a capturing stream refused instead of corrupted."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import hip_frame, hip_setup, make_case, oracle_scene
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_upload_times_are_split(ovr, oracle, hip_renderer_factory):
+    """ovr_hip_get_upload_times: allocation / copies into the device / kernels of the last ovr_hip_set_volume.  A host array is copied
+    (through the staging buffer), a device array is not; the parts do not exceed the whole"""
+    import torch
+    case = make_case(ovr, oracle, n=96, size=(64, 48))
+    ren = hip_renderer_factory()
+    hip_setup(ovr, ren, case)
+    t = ren.upload_times()
+    assert t["total_ms"] > 0 and t["kernels_ms"] > 0 and t["copy_ms"] > 0 and t["alloc_ms"] >= 0          # numpy volume: host memory
+    assert t["alloc_ms"] + t["copy_ms"] + t["kernels_ms"] <= t["total_ms"] + 0.05
+    vol = torch.as_tensor(case["vol"]).cuda()
+    ren2 = hip_renderer_factory()
+    hip_setup(ovr, ren2, dict(case, vol=vol))
+    t2 = ren2.upload_times()
+    assert t2["copy_ms"] == 0.0 and t2["kernels_ms"] > 0 and t2["total_ms"] >= t2["kernels_ms"]
+    ren.render(); ren2.render()
+    assert np.array_equal(hip_frame(ovr, ren)[0], hip_frame(ovr, ren2)[0])
+    assert ren.group_host_times() == (0.0, 0.0, 0.0, 0.0)                                                # not a group
+
+
+def test_a_capturing_stream_is_refused_not_corrupted(ovr, oracle, hip_renderer_factory):
+    """a frame records timed events and hands counters to the host - it is not a unit for hipGraph capture.  On a caller's stream that is
+    capturing, render_async fails with OVR_HIP_ESTATE; the capture survives, and so does the renderer"""
+    import torch
+    case = make_case(ovr, oracle, n=24, size=(48, 32))
+    ren = hip_renderer_factory()
+    hip_setup(ovr, ren, case)
+    ren.render()
+    ref = hip_frame(ovr, ren)[0]
+    s = torch.cuda.Stream()
+    ren.set_stream(s.cuda_stream)
+    ren.render()
+    assert np.array_equal(hip_frame(ovr, ren)[0], ref)
+    x = torch.zeros(16, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        x += 1.0
+        with pytest.raises(RuntimeError, match="capturing"):
+            ren.render_async()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(x[0]) == 1.0                       # the capture was left intact (replayed once)
+    ren.render()                                    # ... and so was the renderer
+    assert np.array_equal(hip_frame(ovr, ren)[0], ref)
+    ren.set_stream(None)
+
+
+@pytest.mark.parametrize("members", [2, 8])
+def test_group_members_are_driven_by_their_own_threads(ovr, oracle, members):
+    """one host thread per follower.  Frames and counters equal the one-device renderer's through camera moves (every member re-classifies its
+    blocks and waits for its two words on its own thread), accumulation and swaps; the leader thread's time to launch and ship a frame is reported"""
+    case = make_case(ovr, oracle, n=40, size=(160, 96), tf="bumps", cam="oblique")
+    one = ovr.create_renderer("hip")
+    grp = ovr.create_renderer("hip", 0, devices=[0] * members)
+    for r in (one, grp):
+        hip_setup(ovr, r, case, accumulate=True)
+    eye, at, up = case["cam"]
+    host = []
+    for i in range(12):
+        e = tuple(np.array(eye) + np.array([0.7 * i, -0.3 * i, 0.0]))
+        for r in (one, grp):
+            if i % 3 == 0:
+                r.set_camera(e, at, up)
+                r.commit()
+            r.render()
+            if i % 4 == 3:
+                fb = ovr.FrameBufferData(); r.mapframe(fb); r.swap()
+        a, b = one.stats(), grp.stats()
+        assert (a.rays, a.samples, a.shaded_samples, a.shadow_samples, a.frame_index) == (b.rays, b.samples, b.shaded_samples, b.shadow_samples, b.frame_index), i
+        assert all(np.array_equal(x, y) for x, y in zip(hip_frame(ovr, one), hip_frame(ovr, grp))), i
+        host.append(grp.group_host_times())
+    h = np.array(host)
+    assert (h[:, 0] > 0).all() and (h[:, 2] > 0).all()
+    assert np.median(h[:, 0] + h[:, 1]) < 2000.0     # microseconds (one card shared by all members; round 4: 225 us for the launches alone at 8 members)
+    n, kind, _ = grp.group_info()
+    assert n == members and kind == 1                # a device listed twice: peer copies
+    one.close(); grp.close()
+
+
+def test_a_group_refuses_to_render_in_mixed_state():
+    """a commit that fails on ONE member leaves the members on different states - the group must not render frames whose tiles come from two
+    configurations.  OVR_HIP_TEST_FAIL_MEMBER=k fails member k's commit of a 4242-pixel-wide framebuffer (a stand-in for an allocation failure)"""
+    code = r'''
+import sys, numpy as np
+sys.path[:0] = [%r, %r + "/tests", %r + "/oracle"]
+import ovr_amd as ovr, oracle as O
+from helpers import make_case, hip_setup, hip_frame
+case = make_case(ovr, O, n=24, size=(64, 48))
+one = ovr.create_renderer("hip"); grp = ovr.create_renderer("hip", 0, devices=[0, 0, 0])
+for r in (one, grp): hip_setup(ovr, r, case)
+one.render(); grp.render()
+assert np.array_equal(hip_frame(ovr, one)[0], hip_frame(ovr, grp)[0])
+grp.set_fbsize((4242, 16))
+try:
+    grp.commit(); print("NO ERROR")
+except RuntimeError as e:
+    print("commit:", e)
+try:
+    grp.render(); print("RENDERED")
+except RuntimeError as e:
+    print("render:", e)
+grp.set_fbsize((64, 48)); grp.commit(); grp.render()          # a commit that succeeds everywhere and leaves the members in agreement heals the group
+assert np.array_equal(hip_frame(ovr, one)[0], hip_frame(ovr, grp)[0])
+print("HEALED")
+''' % (ROOT, ROOT, ROOT)
+    for k in ("0", "2"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OVR_HIP_TEST_FAIL_MEMBER=k, OVR_HIP_QUIET="1"), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        assert f"commit failed on member {k}" in out.stdout and "render: " in out.stdout and "not renderable" in out.stdout and "HEALED" in out.stdout, out.stdout
+        assert "NO ERROR" not in out.stdout and "RENDERED" not in out.stdout
+
+
+def test_the_default_bench_command_prints_one_compact_line():
+    """VERDICT r4 #1, on the GPU: `python bench.py --steps 2 --warmup 1` (every leg of the default command) - exactly one `{` line on stdout, below 4 KB,
+    with the dominant kernel's roofline and the CPU baseline; the full record is in the detail file"""
+    from helpers import run_bench
+    c, d, out = run_bench(["--steps", "2", "--warmup", "1"], timeout=1500)
+    assert c["steps"] == 2 and c["warmup"] == 1 and c["n_gpus"] == 1 and c["value"] > 0 and c["config"]["name"] == "c3"
+    r = c["roofline"]
+    assert r["bound"] in ("hbm", "ta", "valu") and r["kernel"].startswith("raymarch_kernel") and r["kernel_ms"] > 0 and r["algorithmic_bytes_per_launch"] > 1e9
+    assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["cores"] >= 1
+    assert set(c["extra"]) == {"c4_one_gpu", "c5_one_gpu", "c3_shard_of_8", "c3_device_group_rehearsal"} and all("ms_per_step" in v for v in c["extra"].values()), c["extra"]
+    assert c["variants"]["sampling_rate_4"]["ms_per_step"] > 5 * c["ms_per_step"]        # the scene files' own rate: what renderapp users get
+    assert set(r["upload_ms"]) == {"total_ms", "alloc_ms", "copy_ms", "kernels_ms"}
+    assert "views" in d["roofline"] and "kernels" in d["roofline"] and d["extra"]["c4_one_gpu"]["roofline"]["compulsory_floor_bytes"] > 2e10
+    assert d["extra"]["c3_device_group_rehearsal"]["device_group"]["host_us_per_frame"] > 0
