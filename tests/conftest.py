@@ -17,6 +17,11 @@ def pytest_configure(config):
 def oracle():
     import oracle as O
     O.load()
+    if os.environ.get("OVR_PARITY_EXACT_RUN") == "1":
+        # the whole parity suite against the exact-parity build of the kernels (tests/test_parity_exact_gpu.py): same pow on both sides, frames must be EQUAL
+        import ovr_amd
+        assert ovr_amd._lib.load().ovr_hip_built_for_exact_parity() == 1, "OVR_PARITY_EXACT_RUN needs OVR_HIP_LIBRARY = libovr_hip_parity.so"
+        O.set_powf_mode(O.POWF_DET)
     return O
 
 
