@@ -44,7 +44,7 @@ def test_the_product_library_knows_the_deterministic_pair_too(ovr, oracle, hip_r
 @pytest.mark.parametrize("parts", [["kat", "scenes", "c1"], ["sweep"]], ids=["scenes_and_c1", "hunt_sweep_seed_303"])
 def test_counts_are_exact_with_the_same_pow_on_both_sides(parts):
     assert os.path.exists(DETLIB), "libovr_hip_parity.so is missing: make -C open-volume-renderer_amd/csrc parity (build() does)"
-    env = dict(os.environ, OVR_HIP_LIBRARY=DETLIB, OVR_DETPOW_CASES=os.environ.get("OVR_DETPOW_CASES", "450"))
+    env = dict(os.environ, OVR_HIP_LIBRARY=DETLIB, OVR_ORACLE_POWF="det", OVR_DETPOW_CASES=os.environ.get("OVR_DETPOW_CASES", "450"))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "parity_exact_check.py")] + parts, env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0 and "all exact" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
@@ -55,7 +55,7 @@ def test_the_parity_suites_pass_with_equality_instead_of_tolerance():
     shipped scenes, the layouts / pipelines / skipping / sparse-sampling / shard / accumulation tests of rounds 2-4, the state-machine fuzzers and C1's full frame.
     (Left out: what tests the plugin boundary with the product library, bench.py, and the full-size invariants that involve no oracle.)"""
     assert os.path.exists(DETLIB), "libovr_hip_parity.so is missing: make -C open-volume-renderer_amd/csrc parity (build() does)"
-    env = dict(os.environ, OVR_HIP_LIBRARY=DETLIB, OVR_PARITY_EXACT_RUN="1")
+    env = dict(os.environ, OVR_HIP_LIBRARY=DETLIB, OVR_PARITY_EXACT_RUN="1", OVR_ORACLE_POWF="det")   # (the variable: for the scripts the suites start themselves)
     t = os.path.join(ROOT, "tests")
     cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
            os.path.join(t, "test_parity_gpu.py"), os.path.join(t, "test_config_sweep_gpu.py"), os.path.join(t, "test_shipped_scenes_gpu.py"), os.path.join(t, "test_robustness_gpu.py"),
