@@ -139,3 +139,33 @@ def test_the_default_bench_command_prints_one_compact_line():
     assert set(r["upload_ms"]) == {"total_ms", "alloc_ms", "copy_ms", "kernels_ms"}
     assert "views" in d["roofline"] and "kernels" in d["roofline"] and d["extra"]["c4_one_gpu"]["roofline"]["compulsory_floor_bytes"] > 2e10
     assert d["extra"]["c3_device_group_rehearsal"]["device_group"]["host_us_per_frame"] > 0
+
+
+def test_group_on_distinct_devices_when_the_box_has_them(ovr, oracle):
+    """every group test so far lists device 0 several times (one-GPU boxes) - the peer-copy branch.  On a box with >= 2 GPUs this one runs the
+    group on DISTINCT devices, RCCL (one ncclGroupStart / End per frame) and peer copies: frames and counters must equal the one-device renderer's."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("one GPU visible: the distinct-device branches (RCCL send / recv, hipMemcpyPeerAsync) wait for a multi-GPU node")
+    case = make_case(ovr, oracle, n=48, size=(256, 160), tf="bumps", cam="oblique")
+    one = ovr.create_renderer("hip")
+    hip_setup(ovr, one, case, accumulate=True)
+    for _ in range(3):
+        one.render()
+    ref, st = hip_frame(ovr, one), one.stats()
+    one.close()
+    for gather in ("rccl", "copy"):
+        os.environ["OVR_HIP_GATHER"] = gather
+        try:
+            grp = ovr.create_renderer("hip", 0, devices=list(range(min(n, 8))))
+        finally:
+            del os.environ["OVR_HIP_GATHER"]
+        hip_setup(ovr, grp, case, accumulate=True)
+        for _ in range(3):
+            grp.render()
+        got, sg = hip_frame(ovr, grp), grp.stats()
+        assert grp.group_info()[1] == (2 if gather == "rccl" else 1)
+        assert all(np.array_equal(a, b) for a, b in zip(ref, got)), gather
+        assert (st.rays, st.samples, st.shaded_samples, st.shadow_samples) == (sg.rays, sg.samples, sg.shaded_samples, sg.shadow_samples), gather
+        grp.close()
