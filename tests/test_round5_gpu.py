@@ -169,3 +169,11 @@ def test_group_on_distinct_devices_when_the_box_has_them(ovr, oracle):
         assert all(np.array_equal(a, b) for a, b in zip(ref, got)), gather
         assert (st.rays, st.samples, st.shaded_samples, st.shadow_samples) == (sg.rays, sg.samples, sg.shaded_samples, sg.shadow_samples), gather
         grp.close()
+
+
+def test_group_workers_that_sleep_between_commands():
+    """OVR_HIP_WORKER_SPIN_US=0: a member's host thread goes to sleep on its condition variable at once instead of spinning for its next command - the wake-up
+    path a render loop rarely takes.  The state-machine fuzzer on a group of four: every frame the oracle's whole frame."""
+    e = dict(os.environ, OVR_HIP_WORKER_SPIN_US="0", OVR_FUZZ_GROUP="4", OVR_HIP_QUIET="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_states.py"), "8", "77", "10"], capture_output=True, text=True, timeout=900, env=e)
+    assert out.returncode == 0 and "8 episodes, 0 failed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
