@@ -96,6 +96,20 @@ def _fp(a):
 
 POWF_EXP2_LOG2, POWF_LIBM, POWF_DET = 0, 1, 2
 
+LITERAL_NAMES = ["ert_primary", "ert_shadow", "shadow_step_scale", "midpoint", "nearly_equal_eps", "light_x", "light_y", "light_z", "light_rgb", "shade_ambient",
+                 "shade_diffuse", "tea_rounds", "tea_delta", "tea_k0", "tea_k1", "tea_k2", "tea_k3", "tea_tofloat", "float_small", "float_large"]
+
+
+def literals():
+    """name -> value of every numeric literal of the reference's integration loop as the C restatement uses it (ovr_oracle_literals)"""
+    lib = load()
+    out = (C.c_double * 64)()
+    lib.ovr_oracle_literals.argtypes = [C.POINTER(C.c_double), C.c_int]
+    lib.ovr_oracle_literals.restype = C.c_int
+    n = lib.ovr_oracle_literals(out, 64)
+    assert n == len(LITERAL_NAMES), (n, len(LITERAL_NAMES))
+    return dict(zip(LITERAL_NAMES, list(out)[:n]))
+
 
 def set_powf_mode(mode):
     """how the oracle restates __powf (shaders_raymarching.cu:64-66,118-122): POWF_EXP2_LOG2 (default, CUDA's documented definition

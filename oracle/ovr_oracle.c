@@ -30,6 +30,27 @@
 #include <string.h>
 #include <unistd.h>
 
+/* Every numeric literal of the reference's integration loop, named, so that tests/test_oracle_vs_ref.py can pin them against the reference's TEXT
+ * (tests/golden/ref_literals.json, extracted from the cited lines by tests/golden/make_ref_literals.py; ovr_oracle_literals() hands them out) */
+#define LIT_ERT_PRIMARY 0.9999f     /* shaders_raymarching.cu:110  while (... payload.alpha < 0.9999f) */
+#define LIT_ERT_SHADOW 0.9999f      /* shaders_raymarching.cu:64 */
+#define LIT_SHADOW_STEP_SCALE 10.f  /* shaders_raymarching.cu:221  self.step * 10.f */
+#define LIT_MIDPOINT 0.5f           /* shaders_raymarching.cu:67,112  org + 0.5f * (t.x + t.y) * dir */
+#define LIT_NEARLY_EQUAL_EPS 1e-7f  /* shaders_common.h:322  nearly_equal(x, y, epsilon = 1e-7f) */
+#define LIT_LIGHT_X (-907.108f)     /* params.h:79  light_directional_pos */
+#define LIT_LIGHT_Y 2205.875f
+#define LIT_LIGHT_Z (-400.0267f)
+#define LIT_LIGHT_RGB 2.f           /* shaders_raymarching.cu:138  vec3f light_rgb = vec3f(2.f) */
+#define LIT_SHADE_AMBIENT 0.5f      /* shaders_raymarching.cu:157  0.5f + 0.5f * cosNL * light_rgb * (1.f - shadow.alpha) */
+#define LIT_SHADE_DIFFUSE 0.5f
+#define LIT_TEA_ROUNDS 16           /* random.h:184  tea<16> */
+#define LIT_TEA_DELTA 0x9e3779b9u   /* random.h:158-160 */
+#define LIT_TEA_K0 0xa341316cu
+#define LIT_TEA_K1 0xc8013ea4u
+#define LIT_TEA_K2 0xad90777du
+#define LIT_TEA_K3 0x7e95761eu
+#define LIT_TEA_TOFLOAT 2.3283064365386962890625e-10f /* random.h:185 */
+
 typedef struct { float x, y, z; } v3;
 
 static inline v3 v3_make(float x, float y, float z) { v3 r = { x, y, z }; return r; }
@@ -56,14 +77,14 @@ static inline float clamp01(float x) { return clampf(x, 0.f, 1.f); } /* correcte
 void ovr_oracle_tea_floats(uint32_t* pv0, uint32_t* pv1, float out[2])
 {
   uint32_t v0 = *pv0, v1 = *pv1, sum = 0;
-  for (int i = 0; i < 16; i++) {
-    sum += 0x9e3779b9u;
-    v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
-    v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+  for (int i = 0; i < LIT_TEA_ROUNDS; i++) {
+    sum += LIT_TEA_DELTA;
+    v0 += ((v1 << 4) + LIT_TEA_K0) ^ (v1 + sum) ^ ((v1 >> 5) + LIT_TEA_K1);
+    v1 += ((v0 << 4) + LIT_TEA_K2) ^ (v0 + sum) ^ ((v0 >> 5) + LIT_TEA_K3);
   }
   *pv0 = v0;
   *pv1 = v1;
-  const float tofloat = 2.3283064365386962890625e-10f; /* 1/2^32 */
+  const float tofloat = LIT_TEA_TOFLOAT; /* 1/2^32 */
   out[0] = (float)v0 * tofloat;
   out[1] = (float)v1 * tofloat;
 }
@@ -376,8 +397,19 @@ static inline float fast_powf(float x, float y)
 float ovr_oracle_opacity_correction(float alpha, float base, float dt)
 {
   const float adj = base * dt;
-  if (!(fabsf(adj - 1.f) < 1e-7f)) alpha = clamp01(1.f - fast_powf(1.f - alpha, adj));
+  if (!(fabsf(adj - 1.f) < LIT_NEARLY_EQUAL_EPS)) alpha = clamp01(1.f - fast_powf(1.f - alpha, adj));
   return alpha;
+}
+
+/* the literals above, in the order of oracle.py::LITERAL_NAMES (doubles: the uint32 TEA constants are exact in a double) */
+int ovr_oracle_literals(double* out, int capacity)
+{
+  const double v[] = { LIT_ERT_PRIMARY, LIT_ERT_SHADOW, LIT_SHADOW_STEP_SCALE, LIT_MIDPOINT, LIT_NEARLY_EQUAL_EPS, LIT_LIGHT_X, LIT_LIGHT_Y, LIT_LIGHT_Z, LIT_LIGHT_RGB,
+                       LIT_SHADE_AMBIENT, LIT_SHADE_DIFFUSE, LIT_TEA_ROUNDS, LIT_TEA_DELTA, LIT_TEA_K0, LIT_TEA_K1, LIT_TEA_K2, LIT_TEA_K3, LIT_TEA_TOFLOAT,
+                       FLT_MIN /* float_small, math_def.h:57 */, FLT_MAX /* float_large, math_def.h:56 */ };
+  const int n = (int)(sizeof(v) / sizeof(v[0]));
+  for (int i = 0; i < n && i < capacity; ++i) out[i] = v[i];
+  return n;
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -435,7 +467,7 @@ static void make_frame_consts(const ovr_oracle_scene* s, frame_consts* fc)
   fc->wtc_it[0] = m0.x; fc->wtc_it[1] = m0.y; fc->wtc_it[2] = m0.z; /* column vx of the normal matrix */
   fc->wtc_it[3] = m1.x; fc->wtc_it[4] = m1.y; fc->wtc_it[5] = m1.z; /* column vy */
   fc->wtc_it[6] = m2.x; fc->wtc_it[7] = m2.y; fc->wtc_it[8] = m2.z; /* column vz */
-  fc->light = v3_normalize(v3_make(-907.108f, 2205.875f, -400.0267f)); /* params.h:79 */
+  fc->light = v3_normalize(v3_make(LIT_LIGHT_X, LIT_LIGHT_Y, LIT_LIGHT_Z)); /* params.h:79 */
 }
 
 /* xfmVector(M, a) = madd(a.x, vx, madd(a.y, vy, a.z*vz))  LinearSpace.h:320 */
@@ -485,12 +517,12 @@ static float march_shadow(const frame_consts* fc, v3 org, v3 dir, uint64_t* n_sa
   const float o[3] = { oo.x, oo.y, oo.z }, d[3] = { od.x, od.y, od.z };
   float alpha = 0.f;
   if (!ovr_oracle_intersect_box(&t0, &t1, o, d)) return alpha;
-  const float sampling_scale = fc->step * 10.f; /* :221 */
+  const float sampling_scale = fc->step * LIT_SHADOW_STEP_SCALE; /* :221 */
   const float stride = sampling_scale * fc->step; /* :64,:83 */
   if (t0 >= t1) return alpha;
   float tx = t0, ty = fminf(t1, t0 + stride);
-  while ((ty > tx) && (alpha < 0.9999f)) {
-    const float tm = 0.5f * (tx + ty);
+  while ((ty > tx) && (alpha < LIT_ERT_SHADOW)) {
+    const float tm = LIT_MIDPOINT * (tx + ty);
     const v3 pos = v3_make(fmaf(tm, dir.x, org.x), fmaf(tm, dir.y, org.y), fmaf(tm, dir.z, org.z));
     const v3 po = to_object(fc, pos);
     const float p[3] = { po.x, po.y, po.z };
@@ -522,8 +554,8 @@ static void trace_ray(const frame_consts* fc, v3 org, v3 dir, float out_rgba[4],
   const float o[3] = { oo.x, oo.y, oo.z }, d[3] = { od.x, od.y, od.z };
   if (ovr_oracle_intersect_box(&t0, &t1, o, d) && t0 < t1) {
     float tx = t0, ty = fminf(t1, t0 + fc->step);
-    while ((ty > tx) && (alpha < 0.9999f)) {
-      const float tm = 0.5f * (tx + ty);
+    while ((ty > tx) && (alpha < LIT_ERT_PRIMARY)) {
+      const float tm = LIT_MIDPOINT * (tx + ty);
       const v3 pos = v3_make(fmaf(tm, dir.x, org.x), fmaf(tm, dir.y, org.y), fmaf(tm, dir.z, org.z));
       const v3 po = to_object(fc, pos);
       const float p[3] = { po.x, po.y, po.z };
@@ -558,7 +590,7 @@ static void trace_ray(const frame_consts* fc, v3 org, v3 dir, float out_rgba[4],
           if (rgba[3] > 0.f) cnt->shadow_samples_visible += ns;
         }
         const float cosNL = fabsf(v3_dot(fc->light, n_w));
-        const float shade = 0.5f + 0.5f * cosNL * 2.f * (1.f - shadow); /* :156-157, light_rgb = 2 */
+        const float shade = LIT_SHADE_AMBIENT + LIT_SHADE_DIFFUSE * cosNL * LIT_LIGHT_RGB * (1.f - shadow); /* :156-157, light_rgb = 2 (:138) */
         rgba[0] *= shade;
         rgba[1] *= shade;
         rgba[2] *= shade;

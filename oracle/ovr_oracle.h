@@ -105,6 +105,11 @@ typedef struct ovr_oracle_counters {
                                   sample is "shaded" hangs on the pow's last bit - the bound of the shaded-count difference between two pow implementations */
 } ovr_oracle_counters;
 
+/* every numeric literal of the reference's integration loop as the restatement uses it (ERT thresholds, shadow step scale, midpoint factor, nearly_equal's
+ * epsilon, the light, the shading terms, TEA's rounds / constants / scale, float_small / float_large), in the order of oracle.py::LITERAL_NAMES; returns how many.
+ * Pinned against the reference's source text: tests/golden/ref_literals.json (extracted from the cited lines by tests/golden/make_ref_literals.py) */
+int ovr_oracle_literals(double* out, int capacity);
+
 /* ovr/common/random/random.h:146-188 - two floats from 16 TEA rounds; state is updated in place */
 void ovr_oracle_tea_floats(uint32_t* v0, uint32_t* v1, float out[2]);
 

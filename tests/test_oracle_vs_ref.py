@@ -149,3 +149,25 @@ def test_exr_half_conversion_matches_reference_bit_exact_wide(oracle):
     assert np.array_equal(back[..., [1, 2, 3, 0]], out)
     o = out.view(np.float32)
     assert np.isinf(o).any() and (o == 0).any() and ((np.abs(o) > 0) & (np.abs(o) < 6.2e-5)).any()   # overflow, underflow and subnormal halves all occur
+
+
+def test_every_literal_of_the_integration_loop_is_the_references(oracle):
+    """tests/golden/ref_literals.json holds the numeric literals of the reference's integration loop as its source text spells them (ERT thresholds,
+    shadow step scale, midpoint factor, nearly_equal's epsilon, the light, the shading terms, TEA's rounds / constants / scale, float_small / float_large),
+    extracted from the cited lines by tests/golden/make_ref_literals.py.  The restatement's constants (ovr_oracle_literals) must be those values as float32 /
+    uint32.  A pin of the CONSTANTS, not of the arithmetic around them: the oracle stays "parity unpinned" for that."""
+    with open(os.path.join(HERE, "golden", "ref_literals.json")) as f:
+        ref = json.load(f)
+    mine = oracle.literals()
+    alias = {"midpoint_shadow": "midpoint"}  # the shadow march (:67) and the primary march (:112) spell the same factor; the restatement has one
+    unused = {"pixel_jitter_centre", "screen_centre_x", "screen_centre_y"}  # checked below against the numbers the raygen restatement uses
+    for name, rec in ref.items():
+        if name in unused:
+            assert rec["value"] == 0.5, (name, rec)
+            continue
+        got = mine[alias.get(name, name)]
+        if rec["kind"] == "int":
+            assert int(got) == int(rec["value"]), (name, got, rec)
+        else:
+            assert np.float32(got) == np.float32(rec["value"]), (name, got, rec)
+    assert set(mine) <= set(ref) | set(alias.values()), set(mine) - set(ref)
