@@ -954,6 +954,16 @@ __device__ __forceinline__ float bperm(int src_lane, float x)
 }
 __device__ __forceinline__ int bperm_i(int src_lane, int x) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, x); }
 
+// shade order by light beams (PoolDesc): the beam a world-space position projects into, permuted so that the beams of one XCD list are
+// contiguous: list = (cu + 3 cv) % 8 - neighbours in both directions go to different lists -, index = list * G*G/8 + cv * G/8 + cu / 8
+__device__ __forceinline__ unsigned int beam_index(const PoolDesc& Q, float px, float py, float pz)
+{
+  const int G = Q.order_grid;
+  const int cu = min(max((int)fmaf(px, Q.order_u[0], fmaf(py, Q.order_u[1], fmaf(pz, Q.order_u[2], Q.order_u[3]))), 0), G - 1); // (NaN -> 0)
+  const int cv = min(max((int)fmaf(px, Q.order_v[0], fmaf(py, Q.order_v[1], fmaf(pz, Q.order_v[2], Q.order_v[3]))), 0), G - 1);
+  return ((unsigned int)(cu + 3 * cv) & 7u) * (unsigned int)(G * G / 8) + (unsigned int)(cv * (G / 8) + (cu >> 3));
+}
+
 __device__ __forceinline__ void setup_consts(const RayMarchParams& P, VolConsts& vc, MarchConsts& mc)
 {
   vc.data = P.vol.data;
@@ -1495,6 +1505,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
       if (lane == 0) {
         Q.chunk_n[c] = n;
         if (prev_chunk >= 0) Q.chunk_next[prev_chunk] = (int)c; else Q.tile_first[tile] = (int)c;
+        if (Q.order && (c & (unsigned int)(kRun - 1)) == 0u) { // the first chunk of a run: its beam (shade order, PoolDesc)
+          const ShadeReq& r0 = queue[q_head & (QCAP - 1)];
+          const unsigned int key = beam_index(Q, r0.px, r0.py, r0.pz);
+          Q.order_key[c / (unsigned int)kRun] = key;
+          atomicAdd(&Q.order_ws[kOrderHist + key], 1u);
+        }
       }
       if (pend > 0 && (last - q_head) < n) last_gidx = c * 64u + (last - q_head);
       prev_chunk = (int)c;
@@ -1881,7 +1897,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
   if (POOLED) {
     if (q_tail != q_head) spill(q_tail - q_head); // the tile's last, partial chunk
     if (lane == 0 && run_ok)
-      for (unsigned int i = run_size - run_left; i < run_size && run_left != 0; ++i) Q.chunk_n[run_base + i] = 0; // unused tail of the reservation
+      for (unsigned int i = run_size - run_left; i < run_size && run_left != 0; ++i) { // unused tail of the reservation
+        Q.chunk_n[run_base + i] = 0;
+        if (Q.order && ((run_base + i) & (unsigned int)(kRun - 1)) == 0u) Q.order_key[(run_base + i) / (unsigned int)kRun] = kOrderNoKey;
+      }
     if (lane == 0) Q.tile_count[tile] = q_tail;
     if (active && owner) Q.pix_state[pixel_index] = make_float4(alpha, __uint_as_float(first), __int_as_float(pend), 0.f);
   }
@@ -1948,6 +1967,55 @@ __global__ __launch_bounds__(kBlock) void shade_pool_kernel(const RayMarchParams
   // kernel's time (0.45 ms on C3: ~16 ns per same-address atomic); there the cap is always kTicketRuns (shade 0.45 -> 0.20 ms, profiles/r02_notes.md §11)
   // (with the shadow march the batches cost more in balance and locality than the tickets do - also in the skipping kernel: 0.668 -> 0.729 ms)
   const unsigned int ticket_cap = SHADE == 1 ? (unsigned int)kTicketRuns : min((unsigned int)kTicketRuns, max(1u, total_runs / (32u * gridDim.x)));
+  auto shade_chunk = [&](unsigned int c) {
+    const unsigned int n = Q.chunk_n[c];
+    if ((unsigned int)lane < n) {
+      ShadeReq r = Q.reqs[(size_t)c * 64 + lane];
+      if (r.a > 0.f) { // a == 0: null request (a step of the quad that needs no shading)
+        shade_request<VT, SHADE, AM, SKIP>(P, vc, tf, mc, r, n_shadow, n_shadow_skipped);
+        Q.reqs[(size_t)c * 64 + lane] = r;
+      }
+    }
+  };
+  if (Q.order) {
+    // (the next generation's march counts into a zeroed histogram; the order kernel's fill counters likewise)
+    for (unsigned int i = blockIdx.x * kBlock + threadIdx.x; i < 2u * (unsigned int)kOrderMaxKeys; i += gridDim.x * kBlock) {
+      const unsigned int e = i < (unsigned int)kOrderMaxKeys ? i : i - (unsigned int)kOrderMaxKeys;
+      if (e < (unsigned int)(Q.order_grid * Q.order_grid)) Q.order_ws[i] = 0u;
+    }
+    // Runs sorted by light beam (PoolDesc::order, shade_order_kernel): 8 lists with a ticket counter each; the workgroups of an XCD start on
+    // "their" list, so the bricks a beam's shadow rays sweep are fetched into ONE L2 and hit there by the beam's later runs; a workgroup whose
+    // list is done helps with the others (the cursors only grow: every workgroup passes every list once and leaves)
+    const unsigned int* ls = Q.order_ws + kOrderListStart;
+    unsigned int* tick = Q.order_ws + kOrderTickets;
+    unsigned int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    const unsigned int total = overflow ? 0u : ls[kOrderLists];
+    const unsigned int cap = SHADE == 1 ? (unsigned int)kTicketRuns : min((unsigned int)kTicketRuns, max(1u, total / (32u * gridDim.x)));
+    const unsigned int wgs = max(1u, gridDim.x / (unsigned int)kOrderLists);
+    for (unsigned int li = 0; li < (unsigned int)kOrderLists; ++li) {
+      const unsigned int l = (xcc + li) & (unsigned int)(kOrderLists - 1);
+      const unsigned int beg = ls[l], n_l = overflow ? 0u : ls[l + 1] - beg;
+      unsigned int seen = 0;
+      for (;;) {
+        const unsigned int left = n_l > seen ? n_l - seen : 0u;
+        const unsigned int batch = min(cap, max(1u, left / (2u * wgs)));
+        __syncthreads();
+        if (threadIdx.x == 0) s_run = atomicAdd(&tick[32u * l], batch);
+        __syncthreads();
+        const unsigned int run0 = s_run;
+        if (run0 >= n_l) break;
+        seen = run0 + batch;
+        const unsigned int run1 = min(run0 + batch, n_l);
+        for (unsigned int ticket = run0; ticket < run1; ++ticket) {
+          if (ticket != run0) __syncthreads(); // the 4 waves stay on ONE run
+          const unsigned int c0 = Q.order[beg + ticket] * (unsigned int)kRun;
+          for (unsigned int i = (unsigned int)wave; i < (unsigned int)kRun; i += kWaves) shade_chunk(c0 + i);
+        }
+      }
+    }
+  }
+  else {
   unsigned int seen = 0; // a lower bound of the global cursor: the end of this workgroup's last batch
   for (;;) {
     const unsigned int left = n_runs > seen ? n_runs - seen : 0u;
@@ -1967,18 +2035,9 @@ __global__ __launch_bounds__(kBlock) void shade_pool_kernel(const RayMarchParams
       const unsigned int grp = ticket / kTicketBlock, sub = grp & (unsigned int)(kPoolSubs - 1);
       const unsigned int run = (grp / (unsigned int)kPoolSubs) * kTicketBlock + ticket % kTicketBlock;
       if (run >= s_runs[sub]) continue; // idle ticket (workgroup-uniform)
-      for (unsigned int i = (unsigned int)wave; i < (unsigned int)kRun; i += kWaves) {
-        const unsigned int c = sub * Q.sub_capacity + run * kRun + i;
-        const unsigned int n = Q.chunk_n[c];
-        if ((unsigned int)lane < n) {
-          ShadeReq r = Q.reqs[(size_t)c * 64 + lane];
-          if (r.a > 0.f) { // a == 0: null request (a step of the quad that needs no shading)
-            shade_request<VT, SHADE, AM, SKIP>(P, vc, tf, mc, r, n_shadow, n_shadow_skipped);
-            Q.reqs[(size_t)c * 64 + lane] = r;
-          }
-        }
-      }
+      for (unsigned int i = (unsigned int)wave; i < (unsigned int)kRun; i += kWaves) shade_chunk(sub * Q.sub_capacity + run * kRun + i);
     }
+  }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -2000,6 +2059,7 @@ constexpr int kReduceBlocks = 64;
 
 // the two kernels of the pooled pipeline that do not depend on the voxel type live in ovr_hip_kernels.hip
 hipError_t launch_composite(const RayMarchParams& q, dim3 grid, hipStream_t stream);
+hipError_t launch_shade_order(const RayMarchParams& q, hipStream_t stream);
 hipError_t launch_reduce_counters(const unsigned int* partials, int n_blocks, const unsigned int* shade_partials, int n_shade_blocks,
                                   unsigned long long* counters, unsigned int* pool_ctrl, unsigned long long* publish, unsigned int* done, hipStream_t stream);
 
@@ -2091,6 +2151,7 @@ inline hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
         if ((e = hipMemsetAsync(p.counters, 0, 8 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
     }
     RayMarchParams q = p;
+    if (SHADE != 2) q.pool.order = nullptr; // no shadow rays: creation order (its tickets' batches, profiles/r02_notes.md section 11)
     for (int g = 0; g < p.spp; ++g) {
       q.spp_index = g;
       if (g > 0 && (e = hipMemsetAsync(p.pool.ctrl, 0, (size_t)32 * (kPoolSubs + 1) * sizeof(unsigned int), stream)) != hipSuccess) return e; // all but the frame's maximum
@@ -2114,6 +2175,7 @@ inline hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
         if ((e = hipGetLastError()) != hipSuccess) return e;
       }
       if (ev && ev[1] && g == p.spp - 1) (void)hipEventRecord(ev[1], stream);
+      if (q.pool.order && (e = launch_shade_order(q, stream)) != hipSuccess) return e; // runs sorted by light beam (PoolDesc)
       {
         const size_t lds = std::max<size_t>(tf_lds + table_lds_bytes(p, AM), 64);
         auto kern = shade_pool_kernel<VT, SHADE, AM, SKIP>;

@@ -95,7 +95,33 @@ struct PoolDesc {
   unsigned int* tile_count;     // per tile: requests pushed
   float4* pix_state;            // per pixel: alpha, first request position, request count
   unsigned int* shade_counters; // per shade workgroup: 2 words (shadow-march iterations fetched, skipped)
+  // shade order by light beams (round 5, below): null = the shade kernel meets the runs in creation order
+  unsigned int* order;          // capacity / 4 entries: the runs (first chunk / 4) sorted by XCD list, then by beam
+  unsigned int* order_key;      // per run slot: its beam index - written by the march when it spills the run's first chunk - or kOrderNoKey
+  unsigned int* order_ws;       // kOrderWsWords words: [hist G*G][fill G*G][list_start 32][ticket counters 8 x 32]
+  int order_grid;               // G: beams per side of the light-perpendicular grid (32, 64 or 128)
+  float order_u[4], order_v[4]; // beam (cu, cv) of a world position p: cu = (int)(p . u.xyz + u.w), clamped to [0, G)
 };
+// Shade order by LIGHT BEAMS.  The shadow rays of a frame all run along ONE direction; a shaded sample's ray sweeps the column of bricks
+// that lies toward the light from it, and every other sample in that column sweeps the same bricks.  In creation order (view-space
+// tiles) those samples meet the shade kernel at unrelated times and on unrelated XCDs: the headline's shade kernel fetched 7.7 GB, a
+// quarter of its L2 lookups hit.  So the runs (4 chunks = 256 requests of one tile: a compact cluster in space) are counting-sorted by
+// the cell of a G x G grid perpendicular to the light that their first request projects into (a beam); beams are dealt to 8 lists, and
+// the workgroups of XCD x (HW_REG_XCC_ID) take the runs of list x in order: a beam's bricks are fetched once into ONE L2 and hit there
+// by every later ray of the beam (2.7 GB, three quarters hit).  A workgroup whose list is done takes from the other lists (balance).
+//   march          lane 0 of a wave that spills the first chunk of a run: key -> order_key[run], hist[key] += 1
+//   order kernel   every workgroup scans the histogram in LDS; a thread per run slot: order[scan[key] + fill[key]++] = run
+//   shade kernel   zeroes hist / fill for the next generation, then takes tickets from its XCD's list first
+// Frames are bit-identical: the order in which requests are shaded never enters a result.
+constexpr int kOrderMaxGrid = 128;
+constexpr int kOrderMaxKeys = kOrderMaxGrid * kOrderMaxGrid;
+constexpr unsigned int kOrderNoKey = 0xffffffffu;
+constexpr int kOrderLists = 8;
+constexpr int kOrderHist = 0;
+constexpr int kOrderFill = kOrderMaxKeys;
+constexpr int kOrderListStart = 2 * kOrderMaxKeys;
+constexpr int kOrderTickets = kOrderListStart + 32;
+constexpr int kOrderWsWords = kOrderTickets + kOrderLists * 32;
 
 struct RayMarchParams {
   // framebuffer (optix7/params.h:56-63)

@@ -391,6 +391,73 @@ hipError_t launch_composite(const RayMarchParams& q, dim3 grid, hipStream_t stre
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// shade order by light beams (PoolDesc): the march has left a key per run and the histogram of the keys; every workgroup scans
+// the histogram in LDS (G*G entries, the same result everywhere), then a thread per run slot writes its run to its place
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shade_order_kernel(const RayMarchParams P)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned int s_off[]; // G*G exclusive offsets
+  __shared__ unsigned int s_wave[4];
+  const PoolDesc& Q = P.pool;
+  const int n = Q.order_grid * Q.order_grid, ipt = n / 256; // 4, 16 or 64 consecutive entries per thread
+  const unsigned int* hist = Q.order_ws + kOrderHist;
+  const int e0 = threadIdx.x * ipt;
+  unsigned int sum = 0;
+  for (int i = 0; i < ipt; i += 4) { // (16-byte loads)
+    const uint4 h = *reinterpret_cast<const uint4*>(hist + e0 + i);
+    s_off[e0 + i] = sum; sum += h.x;
+    s_off[e0 + i + 1] = sum; sum += h.y;
+    s_off[e0 + i + 2] = sum; sum += h.z;
+    s_off[e0 + i + 3] = sum; sum += h.w;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned int incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  unsigned int base = incl - sum;
+  for (int w = 0; w < wave; ++w) base += s_wave[w];
+  for (int i = 0; i < ipt; ++i) s_off[e0 + i] += base;
+  __syncthreads();
+  if (blockIdx.x == 0) { // the lists' bounds and their ticket counters
+    if (threadIdx.x < (unsigned int)kOrderLists) {
+      Q.order_ws[kOrderListStart + threadIdx.x] = s_off[threadIdx.x * (n / kOrderLists)];
+      Q.order_ws[kOrderTickets + 32 * threadIdx.x] = 0u;
+    }
+    if (threadIdx.x == 255) Q.order_ws[kOrderListStart + kOrderLists] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  }
+  const unsigned int rps = Q.sub_capacity / (unsigned int)kRun; // run slots per sub-pool
+  const unsigned int gid = blockIdx.x * 256u + threadIdx.x;
+  if (gid >= rps * (unsigned int)kPoolSubs) return;
+  const unsigned int sub = gid / rps, run = gid - sub * rps;
+  if (run >= min(Q.ctrl[32u * (sub + 1u)], Q.sub_capacity) / (unsigned int)kRun) return; // not reserved in this generation
+  const unsigned int key = Q.order_key[gid];
+  if (key >= (unsigned int)n) return; // kOrderNoKey: the unused tail of a reservation
+  const unsigned int pos = s_off[key] + atomicAdd(&Q.order_ws[kOrderFill + key], 1u);
+  if (pos < rps * (unsigned int)kPoolSubs) Q.order[pos] = gid; // (always, unless a launch was lost between a march and its shade kernel)
+}
+
+hipError_t launch_shade_order(const RayMarchParams& q, hipStream_t stream)
+{
+  const unsigned int slots = q.pool.capacity / (unsigned int)kRun;
+  const dim3 grid((slots + 255u) / 256u);
+  if (grid.x == 0) return hipSuccess;
+  const size_t lds = (size_t)q.pool.order_grid * q.pool.order_grid * sizeof(unsigned int);
+  static bool attr = false; // 128 x 128 beams: 64 KiB of offsets + the static words
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(shade_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kOrderMaxKeys * (int)sizeof(unsigned int));
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(shade_order_kernel, grid, dim3(256), lds, stream, q);
+  return hipGetLastError();
+}
+
 hipError_t launch_reduce_counters(const unsigned int* partials, int n_blocks, const unsigned int* shade_partials, int n_shade_blocks,
                                   unsigned long long* counters, unsigned int* pool_ctrl, unsigned long long* publish, unsigned int* done, hipStream_t stream)
 {
