@@ -161,6 +161,8 @@ struct ovr_hip_renderer {
                                // across camera moves while the rule still says the same (the thin replicas are view-dependent)
   int tune_frame = -1;         // candidate index of the frame in flight, -1 = not a tuned frame
   bool tune_on = true;
+  bool shade_order_on = true; // OVR_HIP_SHADE_ORDER, read when the renderer is created (shade_order_params)
+  float shade_beam = 32.f;    // OVR_HIP_SHADE_BEAM: voxels across a light beam
   // A camera that moves on every frame (the interactive app) never sits still long enough to be measured: when only the camera changed, a
   // measured decision is kept (the regime - transfer function, sampling rate, volume - is what decides, not the view), dropped as soon as a
   // frame is no longer shade-heavy, and measured again once the configuration has been static for tune_recheck frames.
@@ -396,10 +398,9 @@ int resize_framebuffers(ovr_hip_renderer* r, int w, int h)
 // OVR_HIP_SHADE_ORDER=0: creation order (rounds 1-4).  Called once RayMarchParams holds the frame's light and volume transform.
 void shade_order_params(ovr_hip_renderer* r, PoolDesc& pd)
 {
-  static const int on = getenv("OVR_HIP_SHADE_ORDER") ? atoi(getenv("OVR_HIP_SHADE_ORDER")) : 1;
-  static const float beam = getenv("OVR_HIP_SHADE_BEAM") ? std::max(1.f, (float)atof(getenv("OVR_HIP_SHADE_BEAM"))) : 32.f;
+  const float beam = r->shade_beam;
   pd.order_grid = 0;
-  if (!on || !pd.order || !pd.order_key || !pd.order_ws) { pd.order = nullptr; return; }
+  if (!r->shade_order_on || !pd.order || !pd.order_key || !pd.order_ws) { pd.order = nullptr; return; }
   const RayMarchParams& P = r->P;
   const double diag = std::sqrt((double)r->vd.nx * r->vd.nx + (double)r->vd.ny * r->vd.ny + (double)r->vd.nz * r->vd.nz);
   const int G = diag <= 32.0 * beam ? 32 : diag <= 64.0 * beam ? 64 : 128;
@@ -1703,6 +1704,8 @@ int ovr_hip_create(ovr_hip_renderer** out, int device_id)
   if (const char* f = getenv("OVR_HIP_LAYOUTS")) r->layouts.current = r->layouts.queued = atoi(f); // diagnostic override
   if (const char* f = getenv("OVR_HIP_SKIP_ADAPTIVE")) r->skip_adaptive = atoi(f) != 0;
   if (const char* f = getenv("OVR_HIP_TUNE")) r->tune_on = atoi(f) != 0;
+  if (const char* f = getenv("OVR_HIP_SHADE_ORDER")) r->shade_order_on = atoi(f) != 0;
+  if (const char* f = getenv("OVR_HIP_SHADE_BEAM")) r->shade_beam = std::max(1.f, (float)atof(f));
   *out = r;
   return 0;
 }

@@ -400,29 +400,42 @@ __global__ __launch_bounds__(256) void shade_order_kernel(const RayMarchParams P
   extern __shared__ __attribute__((aligned(16))) unsigned int s_off[]; // G*G exclusive offsets
   __shared__ unsigned int s_wave[4];
   const PoolDesc& Q = P.pool;
-  const int n = Q.order_grid * Q.order_grid, ipt = n / 256; // 4, 16 or 64 consecutive entries per thread
-  const unsigned int* hist = Q.order_ws + kOrderHist;
-  const int e0 = threadIdx.x * ipt;
-  unsigned int sum = 0;
-  for (int i = 0; i < ipt; i += 4) { // (16-byte loads)
-    const uint4 h = *reinterpret_cast<const uint4*>(hist + e0 + i);
-    s_off[e0 + i] = sum; sum += h.x;
-    s_off[e0 + i + 1] = sum; sum += h.y;
-    s_off[e0 + i + 2] = sum; sum += h.z;
-    s_off[e0 + i + 3] = sum; sum += h.w;
-  }
+  const int n = Q.order_grid * Q.order_grid; // 1024, 4096 or 16384 keys
+  // each wave scans a contiguous quarter, 256 entries (one uint4 per lane) at a time, four loads in flight
+  const int it = n / 1024;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned int incl = sum;
+  const uint4* h4 = reinterpret_cast<const uint4*>(Q.order_ws + kOrderHist) + wave * (n / 16);
+  uint4* o4 = reinterpret_cast<uint4*>(s_off) + wave * (n / 16);
+  unsigned int carry = 0;
+  for (int g = 0; g < it; g += 4) {
+    uint4 h[4];
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const unsigned int t = __shfl_up(incl, off);
-    if (lane >= off) incl += t;
+    for (int k = 0; k < 4; ++k) h[k] = (g + k < it) ? h4[(g + k) * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (g + k < it) {
+        const unsigned int sum = h[k].x + h[k].y + h[k].z + h[k].w;
+        unsigned int incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const unsigned int t = __shfl_up(incl, off);
+          if (lane >= off) incl += t;
+        }
+        const unsigned int ex = carry + incl - sum;
+        o4[(g + k) * 64 + lane] = make_uint4(ex, ex + h[k].x, ex + h[k].x + h[k].y, ex + h[k].x + h[k].y + h[k].z);
+        carry += __shfl(incl, 63);
+      }
   }
-  if (lane == 63) s_wave[wave] = incl;
+  if (lane == 0) s_wave[wave] = carry;
   __syncthreads();
-  unsigned int base = incl - sum;
+  unsigned int base = 0;
   for (int w = 0; w < wave; ++w) base += s_wave[w];
-  for (int i = 0; i < ipt; ++i) s_off[e0 + i] += base;
+  if (wave > 0)
+    for (int j = lane; j < n / 16; j += 64) {
+      uint4 v = o4[j];
+      v.x += base; v.y += base; v.z += base; v.w += base;
+      o4[j] = v;
+    }
   __syncthreads();
   if (blockIdx.x == 0) { // the lists' bounds and their ticket counters
     if (threadIdx.x < (unsigned int)kOrderLists) {

@@ -177,3 +177,47 @@ def test_group_workers_that_sleep_between_commands():
     e = dict(os.environ, OVR_HIP_WORKER_SPIN_US="0", OVR_FUZZ_GROUP="4", OVR_HIP_QUIET="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_states.py"), "8", "77", "10"], capture_output=True, text=True, timeout=900, env=e)
     assert out.returncode == 0 and "8 episodes, 0 failed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def test_the_shade_order_never_enters_a_frame(ovr, oracle, hip_renderer_factory, monkeypatch):
+    """Round 5, second half: the pooled pipeline's shade kernel takes its runs sorted by LIGHT BEAM (the march leaves a key per run and their histogram,
+    shade_order_kernel sorts, the workgroups of an XCD start on their own list - PoolDesc in ovr_hip_kernels.h) instead of in creation order.  The order in
+    which requests are shaded is no input of any result: frames, gradient layer and every counter equal the creation-order renderer's
+    (OVR_HIP_SHADE_ORDER=0, read when a renderer is created) bit for bit - three beam widths (32 x 32, 64 x 64, 128 x 128 beams), several samples per pixel,
+    accumulation, empty-space skipping, a camera move, an anisotropic grid, a 16-bit volume, sparse sampling; and the oracle's frame within the bar"""
+    from helpers import compare
+    cases = [dict(n=64, size=(160, 120), cam="oblique"), dict(n=48, size=(96, 64), cam="front", spp=2), dict(n=40, dims=(56, 40, 24), size=(96, 80), cam="oblique", spacing=(1.0, 0.5, 2.0), origin=(3.0, -2.0, 1.0)),
+             dict(n=48, size=(96, 64), cam="oblique", dtype=np.uint16), dict(n=32, size=(64, 48), cam="oblique", tf="dense")]
+    for kw in cases:
+        case = make_case(ovr, oracle, **kw)
+        frames = {}
+        for tag, env in (("creation", {"OVR_HIP_SHADE_ORDER": "0"}), ("beam32", {}), ("beam4", {"OVR_HIP_SHADE_BEAM": "4"}), ("beam1", {"OVR_HIP_SHADE_BEAM": "1"})):
+            for k in ("OVR_HIP_SHADE_ORDER", "OVR_HIP_SHADE_BEAM"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            ren = hip_renderer_factory()
+            hip_setup(ovr, ren, case, accumulate=True, pipeline=2)
+            got = []
+            for step in range(3):
+                ren.render()
+                st = ren.stats()
+                assert st.pipeline == 2
+                got.append(hip_frame(ovr, ren) + (st.samples, st.shaded_samples, st.shadow_samples))
+            ren.set_empty_space_skipping(True)
+            ren.commit(); ren.render()
+            got.append(hip_frame(ovr, ren) + (ren.stats().shaded_samples, ren.stats().skipped_shadow_samples))
+            eye, at, up = case["cam"]
+            ren.set_camera(ovr.Camera(tuple(np.array(eye) * 0.9 + 1.5), at, up, case["fovy"]))
+            ren.commit(); ren.render()
+            got.append(hip_frame(ovr, ren) + (ren.stats().shadow_samples,))
+            frames[tag] = got
+        ref = frames["creation"]
+        for tag, got in frames.items():
+            for a, b in zip(ref, got):
+                assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), (kw, tag)
+                assert a[2:] == b[2:], (kw, tag, a[2:], b[2:])
+        if case["spp"] == 1:
+            sc = oracle_scene(oracle, case)
+            rgba, _, _ = sc.render()
+            compare(oracle, frames["beam32"][0][0], rgba, name=f"shade order {kw}")
