@@ -357,6 +357,35 @@ __device__ __forceinline__ unsigned int tap_cell(const VolConsts& vc, const Tap&
   return (unsigned int)cx + (unsigned int)(vc.mcx1 + 1) * ((unsigned int)cy + (unsigned int)(vc.mcy1 + 1) * (unsigned int)cz);
 }
 
+// The pair (x0, x0 + 1) of a brick row.  The texture addresser merges the lanes of a quad that read one 128-byte line only for loads of 8
+// bytes or more: a 64-lane gather whose quads each stay inside one line costs 18 clocks as dwordx2 / dwordx4 and 66 - as if every lane had a
+// line of its own - as dword or ushort, whatever the alignment (tools/ubench_align.hip, profiles/r05_notes.md section 10; a dwordx2 at a 4-byte
+// boundary - the 32-bit bricks' odd pairs - costs the 18; dwords merge only when the quad's four are consecutive).  The 16-bit layouts' pairs are
+// 4 bytes: OVR_ROW_LOADS loads the ALIGNED 8 bytes around the pair (a brick row of the general layout, two rows of a thin replica) and shifts the
+// pair out of them - the same voxels, so the same frame.  C4: shade 3.21 -> 2.87 ms, frame 7.5 -> 7.2 ms; front view (thin replica) 3.57 -> 3.29;
+// a 512^3 u16 volume at 512^2 0.353 -> 0.335.  The 8-bit layouts (2-byte pairs) keep their loads: C1 is bound by vector issue and the shifts cost
+// it 3 % (0.183 -> 0.188 ms).
+#ifndef OVR_ROW_LOADS
+#define OVR_ROW_LOADS 1
+#endif
+template <int VT, typename B>
+__device__ __forceinline__ typename Vox<VT>::P load_pair(const B* base, unsigned long long off) // off in units of B (bytes for char, else elements)
+{
+  typedef typename Vox<VT>::T T;
+  typedef typename Vox<VT>::P P;
+  if constexpr (OVR_ROW_LOADS && sizeof(T) == 2 && !Vox<VT>::kQuad) {
+    constexpr unsigned per = 8u / (unsigned)sizeof(B);                 // units of B per 8 bytes
+    const unsigned long long al = off & ~(unsigned long long)(per - 1u);
+    const unsigned sh = ((unsigned)off & (per - 1u)) * (8u * (unsigned)sizeof(B));
+    const uint2 row = *reinterpret_cast<const uint2*>(base + al);
+    const unsigned w = (unsigned)((((unsigned long long)row.y << 32) | (unsigned long long)row.x) >> sh); // (a pair never crosses its 8 bytes: rows are 8 bytes or 4)
+    P r;
+    r.x = (T)(w & 0xffffu); r.y = (T)(w >> 16);
+    return r;
+  }
+  else return *reinterpret_cast<const P*>(base + off);
+}
+
 // (A non-temporal hint on these loads - `global_load ... nt` - was measured: the march takes 3.50 instead of 1.51 ms, the shade
 // kernel 3.17 instead of 1.13 ms on C3: neighbouring quads and consecutive rounds do re-use the lines; profiles/r02_notes.md §7.)
 template <int VT, int AM>
@@ -418,8 +447,8 @@ __device__ __forceinline__ void tap_loads(const VolConsts& vc, Tap& t)
     const unsigned o0 = ox + vc.tab_y[b0], o1 = ox + vc.tab_y[b0 + 1];
     const unsigned long long oz0 = vc.tab_z64[z0], oz1 = vc.tab_z64[z0 + 1];
     const T* base = static_cast<const T*>(vc.data);
-    p00 = *reinterpret_cast<const P*>(base + (oz0 + o0)); p10 = *reinterpret_cast<const P*>(base + (oz0 + o1));
-    p01 = *reinterpret_cast<const P*>(base + (oz1 + o0)); p11 = *reinterpret_cast<const P*>(base + (oz1 + o1));
+    p00 = load_pair<VT>(base, oz0 + o0); p10 = load_pair<VT>(base, oz0 + o1);
+    p01 = load_pair<VT>(base, oz1 + o0); p11 = load_pair<VT>(base, oz1 + o1);
   }
   else {
     // three LDS lookups (one b32 + two adjacent pairs) replace ~40 bit-field / multiply instructions per tap: the march is
@@ -430,13 +459,13 @@ __device__ __forceinline__ void tap_loads(const VolConsts& vc, Tap& t)
     const unsigned o0 = ox + oy0, o1 = ox + oy1;
     if (AM == 1) { // < 2^32 elements: 32-bit element offsets, one 64-bit shift-add per load
       const T* base = static_cast<const T*>(vc.data);
-      p00 = *reinterpret_cast<const P*>(base + (oz0 + o0)); p10 = *reinterpret_cast<const P*>(base + (oz0 + o1));
-      p01 = *reinterpret_cast<const P*>(base + (oz1 + o0)); p11 = *reinterpret_cast<const P*>(base + (oz1 + o1));
+      p00 = load_pair<VT>(base, (unsigned long long)(oz0 + o0)); p10 = load_pair<VT>(base, (unsigned long long)(oz0 + o1));
+      p01 = load_pair<VT>(base, (unsigned long long)(oz1 + o0)); p11 = load_pair<VT>(base, (unsigned long long)(oz1 + o1));
     }
     else { // the whole volume is <= 4 GiB: 32-bit BYTE offsets, the loads use the SGPR-base + 32-bit-VGPR-offset form
       const char* cb = static_cast<const char*>(vc.data);
-      p00 = *reinterpret_cast<const P*>(cb + (oz0 + o0)); p10 = *reinterpret_cast<const P*>(cb + (oz0 + o1));
-      p01 = *reinterpret_cast<const P*>(cb + (oz1 + o0)); p11 = *reinterpret_cast<const P*>(cb + (oz1 + o1));
+      p00 = load_pair<VT>(cb, (unsigned long long)(oz0 + o0)); p10 = load_pair<VT>(cb, (unsigned long long)(oz0 + o1));
+      p01 = load_pair<VT>(cb, (unsigned long long)(oz1 + o0)); p11 = load_pair<VT>(cb, (unsigned long long)(oz1 + o1));
     }
   }
 #ifdef OVR_EXP_HALF_LOADS /* timing experiment only (wrong pictures): what would half the gather instructions buy? */
