@@ -522,6 +522,84 @@ __device__ __forceinline__ float sample_volume(const VolConsts& vc, f3 p)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Quad-cooperative taps (round 5).  The texture addresser works through a gather quad by quad - 4 consecutive lanes - and a quad costs by the
+// number of 128-byte lines its lanes touch: 1.1 clocks for one line, 2.8 for two, 4.4 for four (tools/ubench_align.hip, 8-byte loads).  In the
+// shade kernel a quad is 4 consecutive steps of one primary ray; when every lane loads the pairs of its OWN tap, one instruction reads pair j of
+// four taps that lie 1 voxel apart along the view direction - 2.7 bricks on the oblique view (3 x 4 x 2 cells a brick).  Transposed: instruction i
+// reads the FOUR pairs of request i's tap, lane j the pair j = (y0 + (j & 1), z0 + (j >> 1)) - one tap's pairs share a brick unless the tap
+// straddles a y or z face: 1.9 lines (1.6 for the 16-bit bricks).  The lerps follow the data: lane j lerps its pair along x, the even lanes along
+// y with their neighbour's value, lane 0 along z, and lane i takes the result of request i - the same fma of the same operands as tap_finish
+// (lerp(a, b, f) = fma(f, b - a, a), x then y then z), so frames stay bit-identical, with 6 instead of 7 x 2 lerp instructions per tap and lane.
+// All 4 lanes of a quad must be active around these calls (the callers enter per quad, with a per-lane `use` flag).
+// Not for the transposed and quad replicas (their pair axis / cell differs) and not without LDS tables (addressing mode 3): those keep tap_loads.
+// MEASURED (profiles/r05_notes.md section 11): bit-identical (211 parity tests with it on) and SLOWER - C3 shade 0.92 -> 1.08 ms, C4 2.85 -> 3.38, C5 2.80 ->
+// 3.53: the transposition is paid in vector instructions.  Per tap and lane the addresses take 12 v_mov_dpp + 12 v_lshl_add + 12 ds_read_b32 (each lane
+// looks up the table entries of FOUR taps) where the own tap took 3 + 3 + 6 adds, and the lerps 12 instructions per request (the weights' broadcasts are not
+// folded into v_fmac as DPP operands, the final select branches): 2339 instead of 1545 vector instructions in the kernel, and the shade kernel was at 0.58 of
+// vector issue before.  What the texture addresser saves the ALUs spend.  Off; a transposition through LDS (ds_write_b64 x 4 / ds_read_b128 x 2 per tap, no
+// vector instructions) is the untried alternative - it would put the LDS pipe at ~50-70 clocks per wave and tap beside the addresser's 100-150.
+// ------------------------------------------------------------------------------------------------------------------
+#ifndef OVR_COOP_TAPS
+#define OVR_COOP_TAPS 0
+#endif
+template <int VT, int AM> struct Coop { static constexpr bool ok = OVR_COOP_TAPS && !Vox<VT>::kQuad && !Vox<VT>::kTransposed && AM != 3; };
+template <int B> __device__ __forceinline__ int qb_i(int x) { return __builtin_amdgcn_update_dpp(0, x, B * 0x55, 0xf, 0xf, true); } // lane B of the quad
+template <int B> __device__ __forceinline__ float qb_f(float x) { return __int_as_float(qb_i<B>(__float_as_int(x))); }
+template <int CTRL> __device__ __forceinline__ float qperm_f(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true)); }
+
+// lane `sub` of the quad loads pair (sub & 1, sub >> 1) of the tap of the quad's lane I (its corner t.x0 / y0 / z0); use == 0: the tap is not
+// wanted - the four lanes read the volume's first bytes instead (one hot line)
+template <int VT, int AM, int I>
+__device__ __forceinline__ typename Vox<VT>::P coop_load(const VolConsts& vc, const Tap& t, int use, int sub)
+{
+  typedef typename Vox<VT>::T T;
+  const int xi = qb_i<I>(t.x0), yi = qb_i<I>(t.y0) + (sub & 1), zi = qb_i<I>(t.z0) + (sub >> 1);
+  const unsigned int m = (unsigned int)qb_i<I>(use);
+  const unsigned int oxy = vc.tab_x[xi] + vc.tab_y[yi];
+  if (AM == 2) {
+    const unsigned long long off = (vc.tab_z64[zi] + oxy) & (((unsigned long long)m << 32) | m);
+    return load_pair<VT>(static_cast<const T*>(vc.data), off);
+  }
+  const unsigned int off = (vc.tab_z[zi] + oxy) & m;
+  if (AM == 1) return load_pair<VT>(static_cast<const T*>(vc.data), (unsigned long long)off);
+  return load_pair<VT>(static_cast<const char*>(vc.data), (unsigned long long)off);
+}
+// the value of request I's tap from the four lanes' pairs; returned in every lane of the quad (fx / fy / fz: the OWN tap's weights of each lane)
+template <int VT, int I>
+__device__ __forceinline__ float coop_lerp(const VolConsts& vc, typename Vox<VT>::P p, float fx, float fy, float fz)
+{
+  float lo = (float)p.x, hi = (float)p.y;
+#if OVR_PARITY_EXACT
+  if (Vox<VT>::kScale) { lo = Vox<VT>::kClamp ? fmaxf(lo / 127.f, -1.f) : lo / 255.f; hi = Vox<VT>::kClamp ? fmaxf(hi / 127.f, -1.f) : hi / 255.f; }
+#else
+  if (Vox<VT>::kClamp) { lo = fmaxf(lo, vc.vmin); hi = fmaxf(hi, vc.vmin); }
+#endif
+  const float cx = fmaf(qb_f<I>(fx), hi - lo, lo);                       // lane j: c(y_j, z_j) = lerp along x
+  const float cy = fmaf(qb_f<I>(fy), qperm_f<0xB1>(cx) - cx, cx);        // lanes 0, 2: lerp(c(y0, z), c(y1, z), fy)   (quad_perm 1,0,3,2)
+  float cz = fmaf(qb_f<I>(fz), qperm_f<0x4E>(cy) - cy, cy);              // lane 0: lerp(c(z0), c(z1), fz)               (quad_perm 2,3,0,1)
+  if (Vox<VT>::kScale && !OVR_PARITY_EXACT) cz *= vc.vscale;
+  return qb_f<0>(cz);
+}
+// one tap per lane of the quad, all four in flight: issue, then finish (own result per lane; garbage where use == 0)
+template <int VT, int AM>
+struct CoopTap {
+  typename Vox<VT>::P p[4];
+  float fx, fy, fz;
+  __device__ __forceinline__ void issue(const VolConsts& vc, const Tap& t, int use, int sub)
+  {
+    fx = t.fx; fy = t.fy; fz = t.fz;
+    p[0] = coop_load<VT, AM, 0>(vc, t, use, sub); p[1] = coop_load<VT, AM, 1>(vc, t, use, sub);
+    p[2] = coop_load<VT, AM, 2>(vc, t, use, sub); p[3] = coop_load<VT, AM, 3>(vc, t, use, sub);
+  }
+  __device__ __forceinline__ float finish(const VolConsts& vc, int sub) const
+  {
+    const float s0 = coop_lerp<VT, 0>(vc, p[0], fx, fy, fz), s1 = coop_lerp<VT, 1>(vc, p[1], fx, fy, fz);
+    const float s2 = coop_lerp<VT, 2>(vc, p[2], fx, fy, fz), s3 = coop_lerp<VT, 3>(vc, p[3], fx, fy, fz);
+    return sub == 0 ? s0 : sub == 1 ? s1 : sub == 2 ? s2 : s3;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
 // packed FP32: two taps of ONE lane side by side in 64-bit register pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: each half
 // is the IEEE operation of the scalar instruction, so results are bit-identical to the scalar form).  Measured issue cost relative
 // to v_fma_f32 (tools/ubench_valu.hip): v_pk_fma_f32 1.3 for two fmas, v_pk_add / v_pk_mul 1.1 for two.  Only what is naturally
@@ -846,6 +924,71 @@ __device__ __forceinline__ float march_shadow(const VolConsts& vc, const TfConst
   return alpha;
 }
 
+// The same march with quad-cooperative taps (CoopTap): entered by all 4 lanes of a quad with a request to shade in any of them (`want`: this
+// lane's own), left when none of the quad's rays is live any more; a lane whose ray has ended keeps loading its share of the others' taps.
+template <int VT, int AM, int KS, bool SKIP>
+__device__ __forceinline__ float march_shadow_coop(const VolConsts& vc, const TfConsts& tf, const MarchConsts& mc, f3 org, bool want, unsigned int& n_shadow,
+                                                   unsigned int& n_shadow_skipped)
+{
+  const int sub = (int)(threadIdx.x & 3u);
+  const unsigned int qshift = threadIdx.x & 60u; // first lane of the quad within the wave
+  const f3 oo = to_object(mc, org);
+  const f3 od = mk3(mc.light.x * mc.inv_scale.x, mc.light.y * mc.inv_scale.y, mc.light.z * mc.inv_scale.z);
+  float t0 = 0.f, t1 = FLT_MAX;
+  float alpha = 0.f;
+  bool live = intersect_unit_box(t0, t1, oo, od) && want;
+  float tx = t0, ty = fminf(t1, t0 + mc.shadow_stride);
+  float skip_first = FLT_MAX, skip_last = -FLT_MAX;
+  if (SKIP && live) skip_walk<false>(vc, oo, od, t0, t1, skip_first, skip_last);
+  for (;;) {
+    if (((unsigned int)(__ballot(live) >> qshift) & 0xfu) == 0u) break; // no live ray in this quad
+    Tap taps[KS];
+    float dts[KS], mj[KS];
+    bool valid[KS];
+    bool any_inside = false;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      valid[k] = ty > tx;
+      dts[k] = ty - tx;
+      const float tm = 0.5f * (tx + ty);
+      const bool inside = live && (!SKIP || (tm >= skip_first && tm <= skip_last));
+      taps[k] = Tap{};
+      mj[k] = SKIP ? 0.f : 1.f;
+      if (inside || !SKIP) {
+        const f3 pos = mk3(fmaf(tm, mc.light.x, org.x), fmaf(tm, mc.light.y, org.y), fmaf(tm, mc.light.z, org.z));
+        tap_coords(vc, to_object(mc, pos), taps[k]);
+        if (SKIP) mj[k] = vc.majorant[tap_cell(vc, taps[k])]; // empty-space skipping: max TF opacity of the macrocell
+      }
+      any_inside = any_inside || (live && mj[k] > 0.f);
+      tx = ty;
+      ty = fminf(tx + mc.shadow_stride, t1);
+    }
+    if (SKIP && __ballot(any_inside) == 0ull) { // nothing to fetch for any lane of the wave: bookkeeping only
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        live = live && valid[k] && (alpha < 0.9999f);
+        n_shadow_skipped += live ? 1u : 0u;
+      }
+      continue;
+    }
+    CoopTap<VT, AM> ct[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) ct[k].issue(vc, taps[k], (live && mj[k] > 0.f) ? -1 : 0, sub);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const float s = ct[k].finish(vc, sub);
+      float a = tf_alpha(tf, tf_coord(tf, s));
+      a = opacity_correction<true>(a, mc.base * dts[k]);
+      if (SKIP) a = mj[k] > 0.f ? a : 0.f; // a macrocell whose majorant is 0 holds no sample with opacity > 0
+      live = live && valid[k] && (alpha < 0.9999f);
+      alpha = live ? fmaf(1.f - alpha, a, alpha) : alpha;
+      n_shadow += (live && (!SKIP || mj[k] > 0.f)) ? 1u : 0u;
+      if (SKIP) n_shadow_skipped += (live && !(mj[k] > 0.f)) ? 1u : 0u;
+    }
+  }
+  return alpha;
+}
+
 // The same march with its taps in pairs (packed FP32, see f2 above): the all-shaded frames - most of the reference's shipped scenes, and
 // every frame at the scene files' sampling rate 4 - are bound by this loop's instruction stream (profiles/r03_notes.md: VALU ~100 % busy).
 // Per pair of steps: positions, object coordinates and cell coordinates as 9 v_pk_fma_f32 (18 v_fma_f32 in the scalar form), the y / z lerps,
@@ -1111,27 +1254,47 @@ __device__ __forceinline__ void write_pixel(const RayMarchParams& P, unsigned in
 // shade one request: gradient (shaders_common.h:195-215), normals, shadow march, Lambert-ish term
 // (shaders_raymarching.cu:124-158).  Writes the result over the request.
 template <int VT, int SHADE, int AM, bool SKIP>
-__device__ __forceinline__ void shade_request(const RayMarchParams& P, const VolConsts& vc, const TfConsts& tf, const MarchConsts& mc, ShadeReq& r,
+__device__ __forceinline__ void shade_request(const RayMarchParams& P, const VolConsts& vc, const TfConsts& tf, const MarchConsts& mc, ShadeReq& r, bool want,
                                               unsigned int& n_shadow, unsigned int& n_shadow_skipped)
 {
+  // (entered by whole quads: `want` says whether this lane's request is a real one - the others only help with the quad-cooperative taps and
+  // compute on whatever their slot holds; their result is not stored)
+  constexpr bool COOP = Coop<VT, AM>::ok;
+  if (!COOP && !want) return;
   const f3 pos = mk3(r.px, r.py, r.pz);
   const f3 po = to_object(mc, pos);
   // one-sided differences, flipped at the upper bound; the three taps are issued together
   const bool flx = (po.x + mc.gstep.x) > 1.f, fly = (po.y + mc.gstep.y) > 1.f, flz = (po.z + mc.gstep.z) > 1.f;
-  Tap tgx, tgy, tgz;
-  tap_issue<VT, AM>(vc, mk3(po.x + (flx ? -mc.gstep.x : mc.gstep.x), po.y, po.z), tgx);
-  tap_issue<VT, AM>(vc, mk3(po.x, po.y + (fly ? -mc.gstep.y : mc.gstep.y), po.z), tgy);
-  tap_issue<VT, AM>(vc, mk3(po.x, po.y, po.z + (flz ? -mc.gstep.z : mc.gstep.z)), tgz);
-  const f3 rgb = tf_color(tf, r.v);
+  const f3 pgx = mk3(po.x + (flx ? -mc.gstep.x : mc.gstep.x), po.y, po.z), pgy = mk3(po.x, po.y + (fly ? -mc.gstep.y : mc.gstep.y), po.z);
+  const f3 pgz = mk3(po.x, po.y, po.z + (flz ? -mc.gstep.z : mc.gstep.z));
+  float sgx, sgy, sgz;
+  f3 rgb;
+  if constexpr (COOP) {
+    const int sub = (int)(threadIdx.x & 3u), use = want ? -1 : 0;
+    Tap tx_, ty_, tz_;
+    tap_coords(vc, pgx, tx_); tap_coords(vc, pgy, ty_); tap_coords(vc, pgz, tz_);
+    CoopTap<VT, AM> cgx, cgy, cgz;
+    cgx.issue(vc, tx_, use, sub); cgy.issue(vc, ty_, use, sub); cgz.issue(vc, tz_, use, sub);
+    rgb = tf_color(tf, want ? r.v : 0.f);
+    sgx = cgx.finish(vc, sub); sgy = cgy.finish(vc, sub); sgz = cgz.finish(vc, sub);
+  }
+  else {
+    Tap tgx, tgy, tgz;
+    tap_issue<VT, AM>(vc, pgx, tgx);
+    tap_issue<VT, AM>(vc, pgy, tgy);
+    tap_issue<VT, AM>(vc, pgz, tgz);
+    rgb = tf_color(tf, r.v);
+    sgx = tap_finish<VT>(vc, tgx); sgy = tap_finish<VT>(vc, tgy); sgz = tap_finish<VT>(vc, tgz);
+  }
   f3 g;
 #if OVR_PARITY_EXACT
-  g.x = (tap_finish<VT>(vc, tgx) - r.s) / (flx ? -mc.gstep.x : mc.gstep.x); // (sample(c + stp) - v) / stp, shaders_common.h:195-215
-  g.y = (tap_finish<VT>(vc, tgy) - r.s) / (fly ? -mc.gstep.y : mc.gstep.y);
-  g.z = (tap_finish<VT>(vc, tgz) - r.s) / (flz ? -mc.gstep.z : mc.gstep.z);
+  g.x = (sgx - r.s) / (flx ? -mc.gstep.x : mc.gstep.x); // (sample(c + stp) - v) / stp, shaders_common.h:195-215
+  g.y = (sgy - r.s) / (fly ? -mc.gstep.y : mc.gstep.y);
+  g.z = (sgz - r.s) / (flz ? -mc.gstep.z : mc.gstep.z);
 #else
-  g.x = (tap_finish<VT>(vc, tgx) - r.s) * (flx ? -mc.ginv.x : mc.ginv.x);
-  g.y = (tap_finish<VT>(vc, tgy) - r.s) * (fly ? -mc.ginv.y : mc.ginv.y);
-  g.z = (tap_finish<VT>(vc, tgz) - r.s) * (flz ? -mc.ginv.z : mc.ginv.z);
+  g.x = (sgx - r.s) * (flx ? -mc.ginv.x : mc.ginv.x);
+  g.y = (sgy - r.s) * (fly ? -mc.ginv.y : mc.ginv.y);
+  g.z = (sgz - r.s) * (flz ? -mc.ginv.z : mc.ginv.z);
 #endif
   const f3 gn = normalize3(g);
   const f3 n_o = mk3(-gn.x, -gn.y, -gn.z);
@@ -1144,7 +1307,8 @@ __device__ __forceinline__ void shade_request(const RayMarchParams& P, const Vol
   }
   float shadow = 0.f;
   if (SHADE == 2) {
-    if (OVR_SHADOW_PACKED && !SKIP) shadow = march_shadow_packed<VT, AM, kShadowTaps>(vc, tf, mc, pos, n_shadow);
+    if constexpr (COOP) shadow = march_shadow_coop<VT, AM, kShadowTaps, SKIP>(vc, tf, mc, pos, want, n_shadow, n_shadow_skipped);
+    else if (OVR_SHADOW_PACKED && !SKIP) shadow = march_shadow_packed<VT, AM, kShadowTaps>(vc, tf, mc, pos, n_shadow);
     else shadow = march_shadow<VT, AM, kShadowTaps, SKIP>(vc, tf, mc, pos, n_shadow, n_shadow_skipped);
   }
   const float cosNL = fabsf(dot3(mc.light, n_w));
@@ -1606,7 +1770,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP &&
           r.px = r.py = r.pz = r.s = r.v = r.tr = r.a = 0.f; r.next = 0;
           if ((unsigned int)lane < n) {
             r = queue[(q_head + lane) & (QCAP - 1)];
-            if (r.a > 0.f) shade_request<VT, SHADE, AM, SKIP>(P, vc, tf, mc, r, n_shadow, n_shadow_skipped); // a == 0: null request
+            const bool want = r.a > 0.f; // a == 0: null request
+            if (Coop<VT, AM>::ok) { // whole quads enter (n is a multiple of 4): quad-cooperative taps, CoopTap
+              if (((unsigned int)(__ballot(want) >> (lane & 60)) & 0xfu) != 0u) {
+                ShadeReq rr = r;
+                shade_request<VT, SHADE, AM, SKIP>(P, vc, tf, mc, rr, want, n_shadow, n_shadow_skipped);
+                if (want) r = rr;
+              }
+            }
+            else if (want) shade_request<VT, SHADE, AM, SKIP>(P, vc, tf, mc, r, true, n_shadow, n_shadow_skipped);
           }
           int opend = owner ? pend : 0;
           apply_batch(r, q_head, n, lane, opend, first, color, gradient);
@@ -2000,9 +2172,11 @@ __global__ __launch_bounds__(kBlock) void shade_pool_kernel(const RayMarchParams
     const unsigned int n = Q.chunk_n[c];
     if ((unsigned int)lane < n) {
       ShadeReq r = Q.reqs[(size_t)c * 64 + lane];
-      if (r.a > 0.f) { // a == 0: null request (a step of the quad that needs no shading)
-        shade_request<VT, SHADE, AM, SKIP>(P, vc, tf, mc, r, n_shadow, n_shadow_skipped);
-        Q.reqs[(size_t)c * 64 + lane] = r;
+      const bool want = r.a > 0.f; // a == 0: null request (a step of the quad that needs no shading)
+      // whole quads enter (a chunk holds whole quads): the taps are quad-cooperative where the layout allows (CoopTap)
+      if (Coop<VT, AM>::ok ? (((unsigned int)(__ballot(want) >> (lane & 60)) & 0xfu) != 0u) : want) {
+        shade_request<VT, SHADE, AM, SKIP>(P, vc, tf, mc, r, want, n_shadow, n_shadow_skipped);
+        if (want) Q.reqs[(size_t)c * 64 + lane] = r;
       }
     }
   };
