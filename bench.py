@@ -132,11 +132,15 @@ def kernel_bound(kms, abytes, ctr):
     u = {"hbm": traffic / t_prof / (HBM_PEAK_GBS * 1e9),
          "ta": ctr.get("SQ_INSTS_VMEM_RD", 0.0) * GATHER_CLK / (N_CU * clocks),
          "valu": min(ctr.get("SQ_INSTS_VALU", 0.0) * VALU_CLK / (N_SIMD * clocks), 1.0)}
+    # (round 5) the L1's line lookups - one per quad of a gather and 128-byte line it touches, at most about one per clock and CU: what the texture path
+    # really spends (the instruction rate above prices every quad at ONE line; tools/ubench_align.hip: 1 / 2 / 4 lines cost a quad 1.1 / 2.8 / 4.4 clocks)
+    if ctr.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+        u["l1"] = min(ctr["TCP_TOTAL_CACHE_ACCESSES_sum"] / (N_CU * clocks), 1.0)
     bound = max(u, key=lambda k: u[k])
     # (15 % tolerance: the headline's march moves 7.1 GB for 7.6 GB of algorithmic bytes - the caches serve 7 % of them and the memory side
     # is still what it waits for; at 4K or at sampling rate 4 the algorithmic bytes are 2.5 ... 10 x the traffic)
     if bound == "hbm" and abytes > traffic * 1.15:
-        bound = max(("ta", "valu"), key=lambda k: u[k])
+        bound = max((k for k in u if k != "hbm"), key=lambda k: u[k])
     out = {"bound": bound, "utilisation": {k: round(v, 4) for k, v in u.items()}, "traffic": traffic, "clock_ghz": clocks / t_prof / 1e9,
            "l1_fill_bytes": ctr.get("TCP_TCC_READ_REQ_sum", 0.0) * 128.0, "ta_busy": ctr.get("TA_TA_BUSY_sum", 0.0) / (N_CU * clocks)}
     # the memory side's read requests (one per 128-byte line: FETCH_SIZE x 2 KiB / 128) against the measured random-line ceiling: what a gather
@@ -149,6 +153,8 @@ def kernel_bound(kms, abytes, ctr):
         out.update(achieved=ctr["SQ_INSTS_VMEM_RD"] / t_prof / 1e9, peak=N_CU * (clocks / t_prof) / GATHER_CLK / 1e9, unit="G gather instr/s")
     elif bound == "valu":
         out.update(achieved=ctr["SQ_INSTS_VALU"] / t_prof / 1e9, peak=N_SIMD * (clocks / t_prof) / VALU_CLK / 1e9, unit="G vector instr/s")
+    elif bound == "l1":
+        out.update(achieved=ctr["TCP_TOTAL_CACHE_ACCESSES_sum"] / t_prof / 1e9, peak=N_CU * (clocks / t_prof) / 1e9, unit="G L1 line lookups/s")
     if bound != "hbm":
         # (the 4-clock price is v_fma_f32's; v_add / v_mul / v_mov issue in 2.4-2.8 clocks, tools/ubench_valu.hip: a kernel full of them can
         # exceed the nominal peak - the fraction is capped, the utilisation says "saturated")
@@ -941,8 +947,9 @@ def worker(args, world):
             "roofline": {"bound": kern[dom]["bound"], "achieved": kern[dom]["achieved"], "peak": kern[dom]["peak"], "unit": kern[dom]["unit"],
                          "frac": kern[dom]["frac"], "traffic": kern[dom]["traffic"], "traffic_source": traffic_source,
                          "bound_note": "bound = the busiest of: HBM side of L2 (FETCH x 2 + WRITE vs 8 TB/s), gather-instruction rate of the texture addressers "
-                                       "(16 clk per instruction and CU), vector-instruction issue (4 clk per instruction and SIMD), from the PMC profile of this "
-                                       "configuration; achieved / peak / frac are in that resource's unit, utilisation lists all three",
+                                       "(16 clk per instruction and CU), the L1's line lookups (l1: one per quad and line, one per clock and CU), vector-instruction "
+                                       "issue (4 clk per instruction and SIMD), from the PMC profile of this configuration; achieved / peak / frac are in that "
+                                       "resource's unit, utilisation lists all of them",
                          "utilisation": kern[dom].get("utilisation"), "hbm_algorithmic_frac": kern[dom].get("hbm_algorithmic_frac", kern[dom]["frac"]),
                          "kernel": dom + ("" if "pipeline" in dom else " (pooled pipeline: march -> shade -> composite)" if pooled else " (in-place pipeline)"),
                          "kernel_ms": kern[dom]["ms"], "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes_per_launch"],

@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 KERNELS = ("raymarch_kernel", "shade_pool_kernel", "composite_kernel")
-COUNTERS = ("FETCH_SIZE", "WRITE_SIZE", "TCP_TCC_READ_REQ_sum", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VALU", "TA_TA_BUSY_sum", "TD_TD_BUSY_sum", "GRBM_GUI_ACTIVE", "SQ_INSTS_LDS")
+COUNTERS = ("FETCH_SIZE", "WRITE_SIZE", "TCP_TCC_READ_REQ_sum", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VALU", "TA_TA_BUSY_sum", "TD_TD_BUSY_sum", "GRBM_GUI_ACTIVE", "SQ_INSTS_LDS", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCC_HIT_sum", "TCC_MISS_sum")
 
 
 def summary(path):
