@@ -1250,7 +1250,12 @@ int finish_frame_one(ovr_hip_renderer* r)
       if (r->tune_cur >= r->tune_n) {
         if (r->tune_phase == 0) {
           const int pbest = (r->tune_n > 1 && r->tune_cand[1].ms < r->tune_cand[0].ms) ? r->tune_cand[1].pipeline : r->tune_cand[0].pipeline;
+          // the two pipelines within a quarter of each other on the rules' layout: the quad replica may order them the other way round (round 5: a 256 x 256 x 226
+          // u16 volume, all samples shaded - general layout pooled 1.00 / in place 1.08 ms, quad replica pooled 0.89 / in place 0.77) - it gets both
+          const bool close = r->tune_n > 1 && std::min(r->tune_cand[0].ms, r->tune_cand[1].ms) * 1.25f >= std::max(r->tune_cand[0].ms, r->tune_cand[1].ms);
+          const int pother = pbest == 2 ? 1 : 2;
           add_layouts(pbest);
+          if (close && tune_l && tune_p && r->tune_cand[0].layout != LAYOUT_QUAD && r->replica_state[LAYOUT_QUAD] != 0 && r->tune_n < 6) r->tune_cand[r->tune_n++] = { LAYOUT_QUAD, pother, 0, 0.f };
           if (r->tune_cur >= r->tune_n) decide();
         }
         else decide();
@@ -1705,6 +1710,7 @@ int ovr_hip_create(ovr_hip_renderer** out, int device_id)
   if (const char* f = getenv("OVR_HIP_SKIP_ADAPTIVE")) r->skip_adaptive = atoi(f) != 0;
   if (const char* f = getenv("OVR_HIP_TUNE")) r->tune_on = atoi(f) != 0;
   if (const char* f = getenv("OVR_HIP_SHADE_ORDER")) r->shade_order_on = atoi(f) != 0;
+  if (const char* f = getenv("OVR_HIP_ROW_LOADS")) r->P.row_loads = atoi(f) != 0 ? 2 : 1; // (RayMarchParams::row_loads; 0 = by size)
   if (const char* f = getenv("OVR_HIP_SHADE_BEAM")) r->shade_beam = std::max(1.f, (float)atof(f));
   *out = r;
   return 0;

@@ -368,12 +368,16 @@ __device__ __forceinline__ unsigned int tap_cell(const VolConsts& vc, const Tap&
 #ifndef OVR_ROW_LOADS
 #define OVR_ROW_LOADS 1
 #endif
-template <int VT, typename B>
+// Which launches take the row loads: the 16-bit volumes whose layout is too large for the caches to serve (addressing modes 1 and 2, and mode 4 = mode 0's
+// 32-bit byte offsets + row loads: launch_vs upgrades a 16-bit layout of more than 128 MB).  Small 16-bit volumes are bound by vector issue and keep the
+// 4-byte loads (a 256 x 256 x 226 u16 volume, all samples shaded in place: 0.88 -> 1.08 ms WITH the row loads; the 1024 x 1024 x 1080 one 34 -> 24 ms).
+template <int VT, int AM> struct RowLoads { static constexpr bool on = OVR_ROW_LOADS && sizeof(typename Vox<VT>::T) == 2 && !Vox<VT>::kQuad && (AM == 1 || AM == 2 || AM == 4); };
+template <int VT, int AM, typename B>
 __device__ __forceinline__ typename Vox<VT>::P load_pair(const B* base, unsigned long long off) // off in units of B (bytes for char, else elements)
 {
   typedef typename Vox<VT>::T T;
   typedef typename Vox<VT>::P P;
-  if constexpr (OVR_ROW_LOADS && sizeof(T) == 2 && !Vox<VT>::kQuad) {
+  if constexpr (RowLoads<VT, AM>::on) {
     constexpr unsigned per = 8u / (unsigned)sizeof(B);                 // units of B per 8 bytes
     const unsigned long long al = off & ~(unsigned long long)(per - 1u);
     const unsigned sh = ((unsigned)off & (per - 1u)) * (8u * (unsigned)sizeof(B));
@@ -447,8 +451,8 @@ __device__ __forceinline__ void tap_loads(const VolConsts& vc, Tap& t)
     const unsigned o0 = ox + vc.tab_y[b0], o1 = ox + vc.tab_y[b0 + 1];
     const unsigned long long oz0 = vc.tab_z64[z0], oz1 = vc.tab_z64[z0 + 1];
     const T* base = static_cast<const T*>(vc.data);
-    p00 = load_pair<VT>(base, oz0 + o0); p10 = load_pair<VT>(base, oz0 + o1);
-    p01 = load_pair<VT>(base, oz1 + o0); p11 = load_pair<VT>(base, oz1 + o1);
+    p00 = load_pair<VT, AM>(base, oz0 + o0); p10 = load_pair<VT, AM>(base, oz0 + o1);
+    p01 = load_pair<VT, AM>(base, oz1 + o0); p11 = load_pair<VT, AM>(base, oz1 + o1);
   }
   else {
     // three LDS lookups (one b32 + two adjacent pairs) replace ~40 bit-field / multiply instructions per tap: the march is
@@ -459,13 +463,13 @@ __device__ __forceinline__ void tap_loads(const VolConsts& vc, Tap& t)
     const unsigned o0 = ox + oy0, o1 = ox + oy1;
     if (AM == 1) { // < 2^32 elements: 32-bit element offsets, one 64-bit shift-add per load
       const T* base = static_cast<const T*>(vc.data);
-      p00 = load_pair<VT>(base, (unsigned long long)(oz0 + o0)); p10 = load_pair<VT>(base, (unsigned long long)(oz0 + o1));
-      p01 = load_pair<VT>(base, (unsigned long long)(oz1 + o0)); p11 = load_pair<VT>(base, (unsigned long long)(oz1 + o1));
+      p00 = load_pair<VT, AM>(base, (unsigned long long)(oz0 + o0)); p10 = load_pair<VT, AM>(base, (unsigned long long)(oz0 + o1));
+      p01 = load_pair<VT, AM>(base, (unsigned long long)(oz1 + o0)); p11 = load_pair<VT, AM>(base, (unsigned long long)(oz1 + o1));
     }
     else { // the whole volume is <= 4 GiB: 32-bit BYTE offsets, the loads use the SGPR-base + 32-bit-VGPR-offset form
       const char* cb = static_cast<const char*>(vc.data);
-      p00 = load_pair<VT>(cb, (unsigned long long)(oz0 + o0)); p10 = load_pair<VT>(cb, (unsigned long long)(oz0 + o1));
-      p01 = load_pair<VT>(cb, (unsigned long long)(oz1 + o0)); p11 = load_pair<VT>(cb, (unsigned long long)(oz1 + o1));
+      p00 = load_pair<VT, AM>(cb, (unsigned long long)(oz0 + o0)); p10 = load_pair<VT, AM>(cb, (unsigned long long)(oz0 + o1));
+      p01 = load_pair<VT, AM>(cb, (unsigned long long)(oz1 + o0)); p11 = load_pair<VT, AM>(cb, (unsigned long long)(oz1 + o1));
     }
   }
 #ifdef OVR_EXP_HALF_LOADS /* timing experiment only (wrong pictures): what would half the gather instructions buy? */
@@ -558,11 +562,11 @@ __device__ __forceinline__ typename Vox<VT>::P coop_load(const VolConsts& vc, co
   const unsigned int oxy = vc.tab_x[xi] + vc.tab_y[yi];
   if (AM == 2) {
     const unsigned long long off = (vc.tab_z64[zi] + oxy) & (((unsigned long long)m << 32) | m);
-    return load_pair<VT>(static_cast<const T*>(vc.data), off);
+    return load_pair<VT, AM>(static_cast<const T*>(vc.data), off);
   }
   const unsigned int off = (vc.tab_z[zi] + oxy) & m;
-  if (AM == 1) return load_pair<VT>(static_cast<const T*>(vc.data), (unsigned long long)off);
-  return load_pair<VT>(static_cast<const char*>(vc.data), (unsigned long long)off);
+  if (AM == 1) return load_pair<VT, AM>(static_cast<const T*>(vc.data), (unsigned long long)off);
+  return load_pair<VT, AM>(static_cast<const char*>(vc.data), (unsigned long long)off);
 }
 // the value of request I's tap from the four lanes' pairs; returned in every lane of the quad (fx / fy / fz: the OWN tap's weights of each lane)
 template <int VT, int I>
@@ -1179,7 +1183,7 @@ __device__ __forceinline__ size_t stage_tables(const RayMarchParams& P, unsigned
   // AM 0: byte offsets (the volume is <= 4 GiB), AM 1: element offsets (< 2^32 stored voxels) - 32 bits hold every entry
   unsigned int* tx = reinterpret_cast<unsigned int*>(base);
   unsigned int* tz = tx + nab;
-  const unsigned int mul = AM == 0 ? (unsigned int)sizeof(typename Vox<VT>::T) : 1u;
+  const unsigned int mul = (AM == 0 || AM == 4) ? (unsigned int)sizeof(typename Vox<VT>::T) : 1u;
   for (int i = threadIdx.x; i < nab; i += kBlock) tx[i] = gab[i] * mul;
   for (int i = threadIdx.x; i < ez; i += kBlock) tz[i] = (unsigned int)gz[i] * mul;
   vc.tab_x = tx + 1; vc.tab_y = tx + ea + 1; vc.tab_z = tz + 1;
@@ -1544,7 +1548,7 @@ template <int VT, int SHADE, int AM, bool POOLED, bool SKIP, bool LDSB = false, 
 #define OVR_PIN_AM 1 /* the 64-bit addressing modes would spill to scratch under the pin */
 #endif
 // (the skipping pooled march sits at the edge of the 3-waves budget: 169 VGPRs - one too many - cost it 15 %; it is pinned to 3)
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP && POOLED && AM <= OVR_PIN_AM) ? OVR_MARCH_WPE : 1, OVR_MARCH_WPE))) void raymarch_kernel(const RayMarchParams P)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((SKIP && POOLED && (AM == 4 ? 0 : AM) <= OVR_PIN_AM) ? OVR_MARCH_WPE : 1, OVR_MARCH_WPE))) void raymarch_kernel(const RayMarchParams P)
 {
   static_assert(!LDSB || (SHADE == 0 && !POOLED && !SKIP && AM <= 1 && !Vox<VT>::kTransposed), "LDS-staged bricks: unshaded in-place march only");
   using Cfg = QCfg<SHADE, POOLED>;
@@ -2362,7 +2366,7 @@ inline hipError_t launch_vsbs(const RayMarchParams& p, hipStream_t stream, const
         constexpr int SH = SHADE;
         const size_t lds = (size_t)kWaves * QCfg<SH, true>::QCAP * sizeof(ShadeReq) + table_lds_bytes(p, AM) + (size_t)p.n_alpha * sizeof(float) + 64;
         bool launched = false;
-        if constexpr (!SKIP && AM <= 1) {
+        if constexpr (!SKIP && (AM <= 1 || AM == 4)) {
           if (use_deep_rounds(p)) { // a small image shard: the longest ray's chain of rounds is the floor - deeper rounds
             auto kern = raymarch_kernel<VT, SH, AM, true, SKIP, false, true>;
             if ((e = set_lds(kern, lds)) != hipSuccess) return e;
@@ -2414,6 +2418,11 @@ inline hipError_t launch_vs(const RayMarchParams& p, hipStream_t stream, const h
   int am = addressing_mode(p.vol, p.n_color, p.n_alpha);
   if (const char* f = getenv("OVR_HIP_ADDRESSING")) am = std::max(am, atoi(f)); // diagnostic: a more general mode than needed (tests)
   if (am < 3 && (!p.vol.axis_ab || !p.vol.axis_z)) return hipErrorInvalidValue; // the layout's offset tables (launch_axis_tables)
+  if constexpr (sizeof(typename Vox<VT>::T) == 2 && !Vox<VT>::kQuad && OVR_ROW_LOADS) {
+    // mode 4 = mode 0 with the 16-bit pairs read as aligned 8-byte rows (RowLoads): layouts the caches do not serve; OVR_HIP_ROW_LOADS=0|1, read when a renderer is created, forces (tests, measurements)
+    const int forced = p.row_loads - 1; // RayMarchParams::row_loads: 0 = by size, 1 = never, 2 = always
+    if (am == 0 && (forced >= 0 ? forced != 0 : p.vol.bytes > (128ull << 20))) return launch_vsb<VT, SHADE, 4>(p, stream, ev);
+  }
   switch (am) {
   case 0: return launch_vsb<VT, SHADE, 0>(p, stream, ev);
   case 1: return launch_vsb<VT, SHADE, 1>(p, stream, ev);

@@ -133,6 +133,7 @@ struct RayMarchParams {
   int accumulate;
   int spp;
   int spp_index;        // pooled pipeline: the sample-per-pixel generation this launch renders
+  int row_loads;        // 16-bit layouts' aligned 8-byte pair loads (launch_vs): 0 = by the layout's size, 1 = never, 2 = always
   float* spp_sum_rgba;  // pooled pipeline, spp > 1: per-pixel sums over the generations (W*H*4, W*H*3)
   float* spp_sum_grad;
   // camera (params.h:65-70), basis from device_impl.cpp:125-144

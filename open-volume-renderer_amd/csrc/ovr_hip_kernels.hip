@@ -395,6 +395,7 @@ hipError_t launch_composite(const RayMarchParams& q, dim3 grid, hipStream_t stre
 // shade order by light beams (PoolDesc): the march has left a key per run and the histogram of the keys; every workgroup scans
 // the histogram in LDS (G*G entries, the same result everywhere), then a thread per run slot writes its run to its place
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int kOrderSlots = 4; // run slots per thread of the order kernel
 __global__ __launch_bounds__(256) void shade_order_kernel(const RayMarchParams P)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned int s_off[]; // G*G exclusive offsets
@@ -444,28 +445,35 @@ __global__ __launch_bounds__(256) void shade_order_kernel(const RayMarchParams P
     }
     if (threadIdx.x == 255) Q.order_ws[kOrderListStart + kOrderLists] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
   }
-  const unsigned int rps = Q.sub_capacity / (unsigned int)kRun; // run slots per sub-pool
-  const unsigned int gid = blockIdx.x * 256u + threadIdx.x;
-  if (gid >= rps * (unsigned int)kPoolSubs) return;
-  const unsigned int sub = gid / rps, run = gid - sub * rps;
-  if (run >= min(Q.ctrl[32u * (sub + 1u)], Q.sub_capacity) / (unsigned int)kRun) return; // not reserved in this generation
-  const unsigned int key = Q.order_key[gid];
-  if (key >= (unsigned int)n) return; // kOrderNoKey: the unused tail of a reservation
-  const unsigned int pos = s_off[key] + atomicAdd(&Q.order_ws[kOrderFill + key], 1u);
-  if (pos < rps * (unsigned int)kPoolSubs) Q.order[pos] = gid; // (always, unless a launch was lost between a march and its shade kernel)
+  const unsigned int rps = Q.sub_capacity / (unsigned int)kRun, slots = rps * (unsigned int)kPoolSubs; // run slots per sub-pool / of the pool
+  // kOrderSlots run slots per thread, their keys loaded together (the chain key -> fill counter -> order entry is all latency)
+  unsigned int key[kOrderSlots], gid[kOrderSlots];
+#pragma unroll
+  for (int k = 0; k < kOrderSlots; ++k) {
+    gid[k] = (blockIdx.x * (unsigned int)kOrderSlots + (unsigned int)k) * 256u + threadIdx.x;
+    key[k] = kOrderNoKey;
+    if (gid[k] < slots) {
+      const unsigned int sub = gid[k] / rps, run = gid[k] - sub * rps;
+      if (run < min(Q.ctrl[32u * (sub + 1u)], Q.sub_capacity) / (unsigned int)kRun) key[k] = Q.order_key[gid[k]]; // reserved in this generation
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kOrderSlots; ++k) {
+    if (key[k] >= (unsigned int)n) continue; // kOrderNoKey: the unused tail of a reservation
+    const unsigned int pos = s_off[key[k]] + atomicAdd(&Q.order_ws[kOrderFill + key[k]], 1u);
+    if (pos < slots) Q.order[pos] = gid[k]; // (always, unless a launch was lost between a march and its shade kernel)
+  }
 }
 
 hipError_t launch_shade_order(const RayMarchParams& q, hipStream_t stream)
 {
   const unsigned int slots = q.pool.capacity / (unsigned int)kRun;
-  const dim3 grid((slots + 255u) / 256u);
+  const dim3 grid((slots + 256u * kOrderSlots - 1u) / (256u * kOrderSlots));
   if (grid.x == 0) return hipSuccess;
   const size_t lds = (size_t)q.pool.order_grid * q.pool.order_grid * sizeof(unsigned int);
-  static bool attr = false; // 128 x 128 beams: 64 KiB of offsets + the static words
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(shade_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kOrderMaxKeys * (int)sizeof(unsigned int));
+  if (lds >= 48 * 1024) { // 128 x 128 beams: 64 KiB of offsets + the static words (per launch: the attribute belongs to the current device's copy of the kernel)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(shade_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr = true;
   }
   hipLaunchKernelGGL(shade_order_kernel, grid, dim3(256), lds, stream, q);
   return hipGetLastError();

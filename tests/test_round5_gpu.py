@@ -221,3 +221,40 @@ def test_the_shade_order_never_enters_a_frame(ovr, oracle, hip_renderer_factory,
             sc = oracle_scene(oracle, case)
             rgba, _, _ = sc.render()
             compare(oracle, frames["beam32"][0][0], rgba, name=f"shade order {kw}")
+
+
+def test_row_loads_of_the_16_bit_layouts_are_bit_identical(ovr, oracle, hip_renderer_factory, monkeypatch):
+    """Round 5: the texture addresser merges the lanes of a quad only for loads of 8 bytes or more (tools/ubench_align.hip), so 16-bit layouts beyond the caches'
+    reach read the ALIGNED 8 bytes around a voxel pair and shift the pair out (addressing mode 4 / RowLoads in ovr_hip_device.h; by size - forced here on small
+    volumes with OVR_HIP_ROW_LOADS).  The same voxels: the same frame, bit for bit - general layout and the thin replicas (front / side view), both pipelines, with
+    empty-space skipping, u16 and i16; and under a more general addressing mode (element offsets, 64-bit z table)"""
+    seen_layouts = {}
+    for dtype in (np.uint16, np.int16):
+        for cam in ("oblique", "front", "side"):
+            case = make_case(ovr, oracle, n=40, dims=(44, 40, 36), size=(96, 72), cam=cam, dtype=dtype)
+            frames = {}
+            for tag, env in (("dword", {"OVR_HIP_ROW_LOADS": "0"}), ("rows", {"OVR_HIP_ROW_LOADS": "1"}), ("rows_am1", {"OVR_HIP_ROW_LOADS": "1", "OVR_HIP_ADDRESSING": "1"}),
+                             ("rows_am2", {"OVR_HIP_ROW_LOADS": "1", "OVR_HIP_ADDRESSING": "2"})):
+                for k in ("OVR_HIP_ROW_LOADS", "OVR_HIP_ADDRESSING"):
+                    monkeypatch.delenv(k, raising=False)
+                if tag.startswith("rows_am") and (dtype is np.int16 or cam == "side"):
+                    continue
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                got = []
+                for pipeline in (1, 2):
+                    ren = hip_renderer_factory()
+                    ren.set_volume_layouts(2)            # every replica resident before the first frame: the layout rule picks the thin ones for the axis views
+                    hip_setup(ovr, ren, case, pipeline=pipeline)
+                    ren.render()
+                    got.append(hip_frame(ovr, ren) + (ren.stats().samples, ren.stats().shadow_samples, ren.stats().layout))
+                    ren.set_empty_space_skipping(True)
+                    ren.commit(); ren.render()
+                    got.append(hip_frame(ovr, ren) + (ren.stats().shaded_samples,))
+                frames[tag] = got
+            seen_layouts.setdefault(np.dtype(dtype).name, set()).update(g[4] for g in frames["rows"][0::2])
+            for tag, got in frames.items():
+                for a, b in zip(frames["dword"], got):
+                    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), (dtype, cam, tag)
+                    assert a[2:4] == b[2:4], (dtype, cam, tag)
+    assert 0 in seen_layouts["uint16"] and seen_layouts["uint16"] & {1, 2}, seen_layouts   # the general layout and a thin replica (an axis view) were both read
