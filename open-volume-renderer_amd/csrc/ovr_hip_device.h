@@ -363,15 +363,15 @@ __device__ __forceinline__ unsigned int tap_cell(const VolConsts& vc, const Tap&
 // boundary - the 32-bit bricks' odd pairs - costs the 18; dwords merge only when the quad's four are consecutive).  The 16-bit layouts' pairs are
 // 4 bytes: OVR_ROW_LOADS loads the ALIGNED 8 bytes around the pair (a brick row of the general layout, two rows of a thin replica) and shifts the
 // pair out of them - the same voxels, so the same frame.  C4: shade 3.21 -> 2.87 ms, frame 7.5 -> 7.2 ms; front view (thin replica) 3.57 -> 3.29;
-// a 512^3 u16 volume at 512^2 0.353 -> 0.335.  The 8-bit layouts (2-byte pairs) keep their loads: C1 is bound by vector issue and the shifts cost
-// it 3 % (0.183 -> 0.188 ms).
+// a 512^3 u16 volume at 512^2 0.353 -> 0.335; the 8-bit layouts' 2-byte pairs likewise (a 1024^3 u8 volume at C3's settings 1.80 -> 1.70 ms, front view 1.085 ->
+// 0.97) - where the layout is large: C1 (256^3 u8) is bound by vector issue and the shifts cost it 3 % (0.183 -> 0.188 ms), see RowLoads.
 #ifndef OVR_ROW_LOADS
 #define OVR_ROW_LOADS 1
 #endif
-// Which launches take the row loads: the 16-bit volumes whose layout is too large for the caches to serve (addressing modes 1 and 2, and mode 4 = mode 0's
-// 32-bit byte offsets + row loads: launch_vs upgrades a 16-bit layout of more than 128 MB).  Small 16-bit volumes are bound by vector issue and keep the
+// Which launches take the row loads: the 16-bit and 8-bit volumes whose layout is too large for the caches to serve (addressing modes 1 and 2, and mode 4 = mode 0's
+// 32-bit byte offsets + row loads: launch_vs upgrades a 16-bit or 8-bit layout of more than 128 MB).  Small 16-bit volumes are bound by vector issue and keep the
 // 4-byte loads (a 256 x 256 x 226 u16 volume, all samples shaded in place: 0.88 -> 1.08 ms WITH the row loads; the 1024 x 1024 x 1080 one 34 -> 24 ms).
-template <int VT, int AM> struct RowLoads { static constexpr bool on = OVR_ROW_LOADS && sizeof(typename Vox<VT>::T) == 2 && !Vox<VT>::kQuad && (AM == 1 || AM == 2 || AM == 4); };
+template <int VT, int AM> struct RowLoads { static constexpr bool on = OVR_ROW_LOADS && sizeof(typename Vox<VT>::T) <= 2 && !Vox<VT>::kQuad && (AM == 1 || AM == 2 || AM == 4); };
 template <int VT, int AM, typename B>
 __device__ __forceinline__ typename Vox<VT>::P load_pair(const B* base, unsigned long long off) // off in units of B (bytes for char, else elements)
 {
@@ -384,7 +384,8 @@ __device__ __forceinline__ typename Vox<VT>::P load_pair(const B* base, unsigned
     const uint2 row = *reinterpret_cast<const uint2*>(base + al);
     const unsigned w = (unsigned)((((unsigned long long)row.y << 32) | (unsigned long long)row.x) >> sh); // (a pair never crosses its 8 bytes: rows are 8 bytes or 4)
     P r;
-    r.x = (T)(w & 0xffffu); r.y = (T)(w >> 16);
+    if constexpr (sizeof(T) == 2) { r.x = (T)(w & 0xffffu); r.y = (T)(w >> 16); }
+    else { r.x = (T)(w & 0xffu); r.y = (T)((w >> 8) & 0xffu); }
     return r;
   }
   else return *reinterpret_cast<const P*>(base + off);
@@ -2418,7 +2419,7 @@ inline hipError_t launch_vs(const RayMarchParams& p, hipStream_t stream, const h
   int am = addressing_mode(p.vol, p.n_color, p.n_alpha);
   if (const char* f = getenv("OVR_HIP_ADDRESSING")) am = std::max(am, atoi(f)); // diagnostic: a more general mode than needed (tests)
   if (am < 3 && (!p.vol.axis_ab || !p.vol.axis_z)) return hipErrorInvalidValue; // the layout's offset tables (launch_axis_tables)
-  if constexpr (sizeof(typename Vox<VT>::T) == 2 && !Vox<VT>::kQuad && OVR_ROW_LOADS) {
+  if constexpr (sizeof(typename Vox<VT>::T) <= 2 && !Vox<VT>::kQuad && OVR_ROW_LOADS) {
     // mode 4 = mode 0 with the 16-bit pairs read as aligned 8-byte rows (RowLoads): layouts the caches do not serve; OVR_HIP_ROW_LOADS=0|1, read when a renderer is created, forces (tests, measurements)
     const int forced = p.row_loads - 1; // RayMarchParams::row_loads: 0 = by size, 1 = never, 2 = always
     if (am == 0 && (forced >= 0 ? forced != 0 : p.vol.bytes > (128ull << 20))) return launch_vsb<VT, SHADE, 4>(p, stream, ev);

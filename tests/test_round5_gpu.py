@@ -227,17 +227,19 @@ def test_row_loads_of_the_16_bit_layouts_are_bit_identical(ovr, oracle, hip_rend
     """Round 5: the texture addresser merges the lanes of a quad only for loads of 8 bytes or more (tools/ubench_align.hip), so 16-bit layouts beyond the caches'
     reach read the ALIGNED 8 bytes around a voxel pair and shift the pair out (addressing mode 4 / RowLoads in ovr_hip_device.h; by size - forced here on small
     volumes with OVR_HIP_ROW_LOADS).  The same voxels: the same frame, bit for bit - general layout and the thin replicas (front / side view), both pipelines, with
-    empty-space skipping, u16 and i16; and under a more general addressing mode (element offsets, 64-bit z table)"""
+    empty-space skipping, u16 / i16 / u8 / i8 (the 8-bit layouts' pairs are 2-byte loads, which never merge); and under a more general addressing mode (element offsets, 64-bit z table)"""
     seen_layouts = {}
-    for dtype in (np.uint16, np.int16):
+    for dtype in (np.uint16, np.int16, np.uint8, np.int8):
         for cam in ("oblique", "front", "side"):
+            if np.dtype(dtype).itemsize == 1 and cam == "side":
+                continue
             case = make_case(ovr, oracle, n=40, dims=(44, 40, 36), size=(96, 72), cam=cam, dtype=dtype)
             frames = {}
             for tag, env in (("dword", {"OVR_HIP_ROW_LOADS": "0"}), ("rows", {"OVR_HIP_ROW_LOADS": "1"}), ("rows_am1", {"OVR_HIP_ROW_LOADS": "1", "OVR_HIP_ADDRESSING": "1"}),
                              ("rows_am2", {"OVR_HIP_ROW_LOADS": "1", "OVR_HIP_ADDRESSING": "2"})):
                 for k in ("OVR_HIP_ROW_LOADS", "OVR_HIP_ADDRESSING"):
                     monkeypatch.delenv(k, raising=False)
-                if tag.startswith("rows_am") and (dtype is np.int16 or cam == "side"):
+                if tag.startswith("rows_am") and (dtype is not np.uint16 or cam == "side"):
                     continue
                 for k, v in env.items():
                     monkeypatch.setenv(k, v)
