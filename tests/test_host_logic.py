@@ -126,6 +126,15 @@ def test_bench_refuses_a_launcher_mismatch_and_keys_traffic_by_the_kernel_hash(t
     assert bench.kernel_bound(1.0, 5.0e9, ctr_hbm)["bound"] == "hbm"
     assert bench.kernel_bound(1.0, 9.0e9, ctr_hbm)["bound"] != "hbm"   # more algorithmic bytes than traffic: the caches serve it, HBM is not the bound
     assert bench.kernel_bound(1.0, 5.0e9, None) is None
+    # round 5: the L1's line lookups as a fourth unit (TCP_TOTAL_CACHE_ACCESSES against the most any kernel reached, 1.4 per clock and CU): the shade kernel's
+    # numbers - 560 M lookups in 2.09 M clocks - make it the bound (0.75); the march's 590 M in 3.42 M clocks (0.48) leave it a memory-bound kernel, because its
+    # memory side is ranked against the random-line ceiling (53 M lines in 1.48 ms = 0.74 of 48.5 G lines/s) while its fraction is still quoted against 8 TB/s
+    shade = dict(GRBM_GUI_ACTIVE=8 * 2.09e6, mean_ms_rocprof=0.92, FETCH_SIZE=1.34e6, WRITE_SIZE=1.9e5, SQ_INSTS_VMEM_RD=1.76e7, SQ_INSTS_VALU=3.11e8, TCP_TOTAL_CACHE_ACCESSES_sum=5.6e8)
+    b = bench.kernel_bound(0.92, 6.4e9, shade)
+    assert b["bound"] == "l1" and abs(b["utilisation"]["l1"] - 5.6e8 / (256 * 2.09e6) / bench.L1_LOOKUPS_PER_CLK) < 1e-3 and b["unit"] == "G L1 line lookups/s" and abs(b["frac"] - b["utilisation"]["l1"]) < 1e-3
+    march = dict(GRBM_GUI_ACTIVE=8 * 3.42e6, mean_ms_rocprof=1.478, FETCH_SIZE=3.34e6, WRITE_SIZE=2.5e5, SQ_INSTS_VMEM_RD=1.585e7, SQ_INSTS_VALU=4.05e8, TCP_TOTAL_CACHE_ACCESSES_sum=5.9e8)
+    b = bench.kernel_bound(1.478, 7.6e9, march)
+    assert b["bound"] == "hbm" and 0.55 < b["utilisation"]["hbm"] < 0.65 and 0.7 < b["gather_lines"]["frac"] < 0.8 and b["utilisation"]["l1"] < b["gather_lines"]["frac"]
 
 
 def test_the_stdout_line_of_bench_is_compact(tmp_path):
